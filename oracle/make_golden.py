@@ -1,0 +1,339 @@
+"""Golden-vector generator - TEST INFRASTRUCTURE ONLY.  Runs ONLY in the build container (needs /root/reference).
+
+Executes the REFERENCE'S OWN Python modules (imported from /root/reference, never copied) on seeded inputs
+and stores their outputs as small fixtures under tests/golden/.  The GPU box has no /root/reference, so
+the fixtures are what travels.  Loader strategy (verified here):
+
+* ``modules.model.Gmidi_conform`` (+ conform / attention / conv) import as-is (torch + einops only).
+* ``modules/rmvpe/spec.py``, ``utils/infer_utils.py``, ``utils/slicer2.py``, ``batch_infer.py`` are loaded
+  file-level (their packages' ``__init__`` pull in lightning / torchaudio, absent here) with stubs for the
+  absent third-party modules: ``librosa.filters.mel`` / ``librosa.midi_to_note`` (-> the restatements in
+  oracle/restate.py and some_amd/utils - "parity unpinned" third-party arithmetic), ``mido`` (recording stub).
+
+Usage:  python oracle/make_golden.py            (from the repo root)
+"""
+import importlib.util
+import json
+import pathlib
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = pathlib.Path(__file__).resolve().parents[1]
+REF = pathlib.Path('/root/reference')
+OUT = REPO / 'tests' / 'golden'
+
+sys.path.insert(0, str(REF))          # reference packages win name clashes (modules/, utils/, inference/)
+sys.path.append(str(REPO))
+
+from oracle import restate  # noqa: E402
+from some_amd import synth  # noqa: E402
+from some_amd.configs import get_config  # noqa: E402
+
+
+def _load_file(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# ---- stubs for absent third-party modules ---------------------------------------------------------
+NOTE_NAMES = ['C', 'C#', 'D', 'D#', 'E', 'F', 'F#', 'G', 'G#', 'A', 'A#', 'B']
+
+
+def _midi_to_note(midi, unicode=False):
+    n = int(np.round(midi))
+    return f'{NOTE_NAMES[n % 12]}{int(n // 12) - 1}'
+
+
+librosa = types.ModuleType('librosa')
+librosa.filters = types.ModuleType('librosa.filters')
+librosa.filters.mel = lambda sr, n_fft, n_mels, fmin, fmax, htk: restate.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+librosa.midi_to_note = _midi_to_note
+librosa.load = None
+sys.modules['librosa'] = librosa
+sys.modules['librosa.filters'] = librosa.filters
+
+
+class _Msg:
+    def __init__(self, kind, **kw):
+        self.kind, self.kw = kind, kw
+
+
+mido = types.ModuleType('mido')
+mido.MidiFile = lambda charset='utf8': types.SimpleNamespace(tracks=[])
+mido.MidiTrack = list
+mido.MetaMessage = lambda kind, **kw: _Msg(kind, **kw)
+mido.Message = lambda kind, **kw: _Msg(kind, **kw)
+mido.bpm2tempo = lambda bpm: int(round(60 * 1e6 / bpm))
+sys.modules['mido'] = mido
+
+ref_spec = _load_file('ref_spec', REF / 'modules/rmvpe/spec.py')
+ref_infer_utils = _load_file('ref_infer_utils', REF / 'utils/infer_utils.py')
+ref_slicer2 = _load_file('ref_slicer2', REF / 'utils/slicer2.py')
+from modules.model.Gmidi_conform import midi_conforms as RefModel  # noqa: E402
+
+
+def ref_model(config, seed):
+    import copy
+    model = RefModel(copy.deepcopy(config)).eval()
+    sd = synth.synth_state_dict(config, seed)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return model
+
+
+def ref_mel(config):
+    return ref_spec.MelSpectrogram(
+        n_mel_channels=config['units_dim'], sampling_rate=config['audio_sample_rate'],
+        win_length=config['win_size'], hop_length=config['hop_size'],
+        mel_fmin=config['fmin'], mel_fmax=config['fmax'])
+
+
+def gen_mel():
+    cfg = get_config('midi_conformer')
+    mel = ref_mel(cfg)
+    out = {}
+    rng = np.random.default_rng(7)
+    cases = {
+        'clip0_1s': synth.synth_clip(0, 1.0),
+        'clip1_odd': synth.synth_clip(1, 0.37)[:16001],
+        'tiny100': (rng.standard_normal(100) * 0.1).astype(np.float32),
+        'zeros3000': np.zeros(3000, dtype=np.float32),
+        'noise_hop': (rng.standard_normal(512 * 9) * 0.05).astype(np.float32),
+    }
+    for k, w in cases.items():
+        with torch.no_grad():
+            u = mel(torch.from_numpy(w)[None]).transpose(1, 2)[0].contiguous().numpy()
+        out[k + '.audio'] = w
+        out[k + '.units'] = u
+    out['mel_basis'] = mel.mel_basis.numpy()
+    np.savez_compressed(OUT / 'mel.npz', **out)
+    print('mel.npz', {k: v.shape for k, v in out.items()})
+
+
+MODEL_CASES = [
+    # name, config, lay, seed, B, T, masked
+    ('conf_lay8', 'midi_conformer', 8, 11, 1, 173, False),
+    ('conf_lay2_b2', 'midi_conformer', 2, 12, 2, 96, False),
+    ('quant_lay3', 'quant_two_head_model', 3, 13, 1, 131, False),
+    ('two_head_lay1_mask', 'two_head_model', 1, 14, 1, 64, True),
+    ('conf_lay1_t1', 'midi_conformer', 1, 15, 1, 1, False),
+    ('conf_lay1_t33', 'midi_conformer', 1, 16, 1, 33, False),
+]
+
+
+def gen_model():
+    out = {}
+    meta = {}
+    for name, cname, lay, seed, b, t, masked in MODEL_CASES:
+        cfg = get_config(cname, lay=lay)
+        model = ref_model(cfg, seed)
+        rng = np.random.default_rng(seed + 100)
+        units = (rng.standard_normal((b, t, cfg['units_dim'])) * 2.0 - 4.0).astype(np.float32)
+        mask = np.ones((b, t), dtype=bool)
+        if masked:
+            mask[:, t - 9:] = False
+            mask[:, 5] = False
+        quant = cname.startswith('quant')
+        with torch.no_grad():
+            x, m = torch.from_numpy(units), torch.from_numpy(mask)
+            logits, bounds = model(x, None, mask=m)
+            probs, bounds2 = model(x, None, mask=m, softmax=quant, sig=not quant)
+        assert torch.equal(bounds, bounds2)
+        out[name + '.units'] = units
+        out[name + '.mask'] = mask
+        out[name + '.logits'] = logits.numpy()
+        out[name + '.probs'] = probs.numpy()
+        out[name + '.bounds'] = bounds.numpy()
+        meta[name] = dict(config=cname, lay=lay, seed=seed, B=b, T=t, quant=quant)
+    np.savez_compressed(OUT / 'model.npz', **out)
+    (OUT / 'model.json').write_text(json.dumps(meta, indent=1))
+    print('model.npz', list(meta))
+
+
+def gen_decode():
+    out = {}
+    cfg = get_config('midi_conformer')
+    iu = ref_infer_utils
+    # (1) the reference's only textual known-answer (utils/infer_utils.py:103-113, commented __main__)
+    f2i = torch.LongTensor([[1, 1, 1, 1, 2, 2, 3, 3, 3, 0, 0, 0, 0, 0], [1, 1, 1, 2, 3, 3, 3, 3, 3, 4, 4, 0, 0, 0]])
+    vals = torch.FloatTensor([[60, 61, 60.5, 63, 57, 57, 50, 55, 54, 0, 0, 0, 0, 0],
+                              [50, 51, 50.5, 53, 47, 47, 40, 45, 44, 38, 38, 0, 0, 0]])
+    iv, idur, im = iu.decode_note_sequence(f2i, vals, f2i > 0)
+    out['kat.frame2item'], out['kat.values'] = f2i.numpy(), vals.numpy()
+    out['kat.item_values'], out['kat.item_dur'], out['kat.item_masks'] = iv.numpy(), idur.numpy(), im.numpy()
+    # (2) seeded random continuous / quantised cases, one clip each (B=1 as the reference runs them)
+    for ci, (t, nb, seed) in enumerate([(400, 128, 1), (862, 128, 2), (37, 128, 3), (500, 129, 4), (2584, 129, 5), (1, 128, 6), (2584, 128, 7)]):
+        rng = np.random.default_rng(seed)
+        quant = nb == 129
+        # note-like probs: a gaussian bump that moves, with some rests
+        centers = np.repeat(rng.uniform(40, 80, t // 20 + 1), 20)[:t] + rng.standard_normal(t) * 0.3
+        idx = np.arange(nb)[None, :]
+        bump = np.exp(-0.5 * (idx - centers[:, None]) ** 2)
+        amp = rng.uniform(0.02, 1.0, (t, 1))
+        logits = (np.log(bump * amp + 1e-4) + rng.standard_normal((t, nb)) * 0.2).astype(np.float32)
+        if quant:
+            probs = torch.softmax(torch.from_numpy(logits), dim=-1)
+        else:
+            probs = torch.sigmoid(torch.from_numpy(logits))
+        bounds = torch.from_numpy((rng.uniform(0, 1, t) ** 6).astype(np.float32))
+        masks = torch.ones(1, t, dtype=torch.bool)
+        p, b = probs[None].clone(), bounds[None].clone()
+        p *= masks[..., None]
+        b *= masks
+        f2i = iu.decode_bounds_to_alignment(b) * masks
+        if quant:
+            midi = p.argmax(dim=-1)
+            rest = midi == 128
+            v = midi.clip(min=0, max=127)
+        else:
+            v, rest = iu.decode_gaussian_blurred_probs(p, vmin=cfg['midi_min'], vmax=cfg['midi_max'],
+                                                       deviation=cfg['midi_prob_deviation'], threshold=cfg['rest_threshold'])
+        nm, nd, nmask = iu.decode_note_sequence(f2i, v, ~rest & masks)
+        k = f'case{ci}'
+        out[k + '.probs'], out[k + '.bounds'] = probs.numpy(), bounds.numpy()
+        out[k + '.frame2item'], out[k + '.values'], out[k + '.rest'] = f2i[0].numpy(), v[0].numpy(), rest[0].numpy()
+        out[k + '.note_midi'] = nm[0].numpy()
+        out[k + '.note_dur'] = nd[0].numpy() * (cfg['hop_size'] / cfg['audio_sample_rate'])
+        out[k + '.note_dur_frames'] = nd[0].numpy()
+        out[k + '.note_rest'] = (~nmask)[0].numpy()
+        out[k + '.quant'] = np.array(quant)
+    np.savez_compressed(OUT / 'decode.npz', **out)
+    print('decode.npz', len(out))
+
+
+def gen_slicer():
+    out = {}
+    cases = {
+        'sil8': synth.synth_clip(3, 20.0, silence_every=4.0),
+        'sil5': synth.synth_clip(4, 26.0, silence_every=7.0),
+        'nosil': synth.synth_clip(5, 8.0),
+        'short': synth.synth_clip(6, 3.0, silence_every=1.0),
+    }
+    lead = synth.synth_clip(7, 12.0, silence_every=5.0)
+    lead[:int(1.7 * 44100)] = 0
+    lead[-int(2.2 * 44100):] = 0
+    cases['lead_trail'] = lead
+    meta = {}
+    for k, w in cases.items():
+        chunks = ref_slicer2.Slicer(sr=44100, max_sil_kept=1000).slice(w)
+        meta[k] = [[float(c['offset']), int(c['waveform'].shape[0])] for c in chunks]
+        rms = ref_slicer2.get_rms(y=w, frame_length=3528, hop_length=882).squeeze(0) if len(w) > 882 * 250 else np.zeros(0, np.float32)
+        out[k + '.rms'] = rms.astype(np.float32)
+    (OUT / 'slicer.json').write_text(json.dumps(meta, indent=1))
+    np.savez_compressed(OUT / 'slicer_rms.npz', **out)
+    print('slicer.json', {k: len(v) for k, v in meta.items()})
+
+
+def gen_midi_msgs():
+    """build_midi_file (utils/infer_utils.py:79-100) through the recording mido stub."""
+    rng = np.random.default_rng(21)
+    cases = {}
+    for ci in range(3):
+        offsets, segs = [], []
+        t0 = 0.0
+        for s in range(3):
+            n = int(rng.integers(3, 9))
+            seg = {'note_midi': rng.uniform(45, 80, n).astype(np.float32),
+                   'note_dur': rng.integers(5, 90, n).astype(np.int64) * (512 / 44100),
+                   'note_rest': rng.uniform(0, 1, n) < 0.25}
+            offsets.append(t0)
+            # make the 2nd case overrun the next chunk offset to exercise the clamp at :92-93
+            t0 += float(seg['note_dur'].sum()) * (0.8 if ci == 1 else 1.2)
+            segs.append(seg)
+        mf = ref_infer_utils.build_midi_file(offsets, segs, tempo=[120, 97.5, 140][ci])
+        msgs = [[m.kind, int(m.kw.get('note', -1)), int(m.kw.get('time', 0)), int(m.kw.get('tempo', -1))] for m in mf.tracks[0]]
+        cases[f'case{ci}'] = {
+            'tempo': [120, 97.5, 140][ci], 'offsets': offsets,
+            'segments': [{k: v.tolist() for k, v in s.items()} for s in segs], 'messages': msgs}
+    (OUT / 'midi_msgs.json').write_text(json.dumps(cases))
+    print('midi_msgs.json')
+
+
+def gen_batch_infer_fns():
+    """Pure-Python helpers of batch_infer.py (:37-46, :84-134) loaded file-level with stubbed imports."""
+    for name in ('inference', 'utils', 'utils.config_utils', 'utils.slicer2'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules['inference'].BaseInference = object
+    sys.modules['utils.config_utils'].print_config = lambda c: None
+    sys.modules['utils.slicer2'].Slicer = ref_slicer2.Slicer
+    bi = _load_file('ref_batch_infer', REF / 'batch_infer.py')
+    rng = np.random.default_rng(33)
+    cases = []
+    for ci in range(6):
+        n_words = int(rng.integers(4, 12))
+        ph_num = rng.integers(1, 4, n_words).tolist()
+        ph_dur = [round(float(x), 6) for x in rng.uniform(0.05, 0.6, int(sum(ph_num)))]
+        words = bi.get_word_durs(ph_dur, ph_num)
+        total = words[-1][1]
+        notes, t = [], 0.0
+        while t < total + 0.3:
+            d = round(float(rng.uniform(0.08, 0.9)), 6)
+            midi = float(np.float32(rng.uniform(48, 76)))
+            rest = bool(rng.uniform() < 0.2)
+            st = round(t + (0.03 if rng.uniform() < 0.3 else 0.0), 6)
+            notes.append({'start_time': st, 'end_time': round(st + d, 6), 'note_seq': bi.calc_seq(midi, rest),
+                          'note_dur': d, '_midi': midi, '_rest': rest})
+            t = notes[-1]['end_time']
+        import copy
+        aligned = bi.midi_align(copy.deepcopy(notes), words)
+        per_word = []
+        for w in words:
+            per_word.append({'max': bi.get_max_overlap_midi(w, aligned),
+                             'all': [s['note_seq'] + '@' + repr(s['start_time']) for s in bi.get_all_overlap_midis(w, aligned)]})
+        cases.append({'ph_dur': ph_dur, 'ph_num': ph_num, 'words': words, 'notes': notes,
+                      'aligned': aligned, 'per_word': per_word})
+    seqs = [[float(np.float32(m)), bi.calc_seq(float(np.float32(m)), False)] for m in
+            [60.0, 60.25, 59.75, 61.5, 62.5, 69.004, 68.996, 0.4, 127.0, 47.51, 47.49, 71.995]]
+    (OUT / 'batch_infer_fns.json').write_text(json.dumps({'cases': cases, 'calc_seq': seqs}))
+    print('batch_infer_fns.json')
+
+
+def gen_e2e():
+    """waveform -> notes through the reference's own front end, model and decoder (B=1, CPU)."""
+    out = {}
+    meta = {}
+    for name, cname, lay, seed, secs in [('e2e_conf', 'midi_conformer', 2, 31, 4.0), ('e2e_quant', 'quant_two_head_model', 1, 32, 2.5)]:
+        cfg = get_config(cname, lay=lay)
+        quant = cname.startswith('quant')
+        model, mel = ref_model(cfg, seed), ref_mel(cfg)
+        w = synth.synth_clip(40 + seed, secs)
+        iu = ref_infer_utils
+        with torch.no_grad():
+            units = mel(torch.from_numpy(w)[None]).transpose(1, 2)
+            masks = torch.ones(units.shape[:2], dtype=torch.bool)
+            probs, bounds = model(x=units, f0=None, mask=masks, softmax=quant, sig=not quant)
+            out[name + '.probs'], out[name + '.bounds'] = probs[0].numpy().copy(), bounds[0].numpy().copy()
+            probs *= masks[..., None]
+            bounds *= masks
+            f2i = iu.decode_bounds_to_alignment(bounds) * masks
+            if quant:
+                midi = probs.argmax(dim=-1)
+                rest = midi == 128
+                v = midi.clip(min=0, max=127)
+            else:
+                v, rest = iu.decode_gaussian_blurred_probs(probs, vmin=0, vmax=127, deviation=1.0, threshold=0.1)
+            nm, nd, nmask = iu.decode_note_sequence(f2i, v, ~rest & masks)
+        out[name + '.note_midi'] = nm[0].numpy()
+        out[name + '.note_dur'] = nd[0].numpy() * (512 / 44100)
+        out[name + '.note_rest'] = (~nmask)[0].numpy()
+        meta[name] = dict(config=cname, lay=lay, seed=seed, clip=40 + seed, seconds=secs, quant=quant)
+    np.savez_compressed(OUT / 'e2e.npz', **out)
+    (OUT / 'e2e.json').write_text(json.dumps(meta, indent=1))
+    print('e2e.npz')
+
+
+if __name__ == '__main__':
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    OUT.mkdir(parents=True, exist_ok=True)
+    gen_mel()
+    gen_model()
+    gen_decode()
+    gen_slicer()
+    gen_midi_msgs()
+    gen_batch_infer_fns()
+    gen_e2e()

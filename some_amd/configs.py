@@ -1,0 +1,86 @@
+"""Built-in copies of the hot-path keys of the reference's YAML configs.
+
+The reference flattens ``configs/base.yaml`` + a model YAML into a ``config.yaml`` that is saved beside
+the checkpoint (reference ``train.py:42-43``) and read back by ``infer.py:20-22``.  Only the keys the
+inference path reads are kept here (list in SURVEY.md section 5, "Config / flags"):
+
+* audio front end: ``configs/base.yaml:11-15``
+* model dims:      ``configs/midi_conformer.yaml:22-33``, ``configs/quant_two_head_model.yaml:8-20``,
+                   ``configs/two_head_model.yaml:24-35``
+* decode:          ``configs/midi_conformer.yaml:16-19``, ``configs/base.yaml:23-24``
+
+They are used by ``bench.py``, the tests and ``some_amd.synth`` to build synthetic checkpoints; a real
+deployment reads the ``config.yaml`` written by the reference's trainer instead.
+"""
+import copy
+
+_BASE = {
+    'hop_size': 512,
+    'win_size': 2048,
+    'audio_sample_rate': 44100,
+    'fmin': 40,
+    'fmax': 8000,
+    'units_encoder': 'mel',
+    'pe': 'rmvpe',
+    'midi_min': 0,
+    'midi_max': 127,
+    'units_dim': 80,
+    'midi_num_bins': 128,
+    'seed': 114514,
+}
+
+
+def _extractor_args(lay):
+    return {
+        'lay': lay,
+        'dim': 512,
+        'use_lay_skip': True,
+        'kernel_size': 31,
+        'conv_drop': 0.1,
+        'ffn_latent_drop': 0.1,
+        'ffn_out_drop': 0.1,
+        'attention_drop': 0.1,
+        'attention_heads': 8,
+        'attention_heads_dim': 64,
+    }
+
+
+_CONFIGS = {
+    'midi_conformer': dict(
+        _BASE,
+        model_cls='modules.model.Gmidi_conform.midi_conforms',
+        task_cls='training.MIDIExtractionTask',
+        midi_prob_deviation=1.0,
+        rest_threshold=0.1,
+        midi_extractor_args=_extractor_args(8),
+    ),
+    'two_head_model': dict(
+        _BASE,
+        model_cls='modules.model.Gmidi_conform.midi_conforms',
+        task_cls='training.MIDIExtractionTask',
+        midi_prob_deviation=1.0,
+        rest_threshold=0.1,
+        midi_extractor_args=_extractor_args(3),
+    ),
+    'quant_two_head_model': dict(
+        _BASE,
+        midi_num_bins=129,
+        model_cls='modules.model.Gmidi_conform.midi_conforms',
+        task_cls='training.QuantizedMIDIExtractionTask',
+        midi_extractor_args=_extractor_args(3),
+    ),
+}
+
+
+def get_config(name: str, **overrides) -> dict:
+    """Return a deep copy of a built-in config; ``lay=...`` overrides ``midi_extractor_args.lay``."""
+    cfg = copy.deepcopy(_CONFIGS[name])
+    lay = overrides.pop('lay', None)
+    if lay is not None:
+        cfg['midi_extractor_args']['lay'] = int(lay)
+    cfg.update(overrides)
+    return cfg
+
+
+def config_names():
+    return sorted(_CONFIGS)

@@ -1,0 +1,98 @@
+"""Pins oracle/restate.py (the CPU restatement) against fixtures produced by the REFERENCE'S OWN code
+(oracle/make_golden.py).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import restate
+from some_amd import synth
+from some_amd.configs import get_config
+
+
+def test_mel_filterbank_matches_reference_buffer(golden_dir):
+    g = np.load(golden_dir / 'mel.npz')
+    fb = restate.mel_filterbank()
+    assert fb.shape == (80, 1025) and fb.dtype == np.float32
+    np.testing.assert_array_equal(fb, g['mel_basis'])
+    nz = np.nonzero(fb.any(axis=0))[0]
+    assert nz.min() == 2 and nz.max() == 371          # only bins 2..371 are touched
+    assert int((fb != 0).sum()) == 727
+
+
+@pytest.mark.parametrize('case', ['clip0_1s', 'clip1_odd', 'tiny100', 'zeros3000', 'noise_hop'])
+def test_logmel(golden_dir, case):
+    g = np.load(golden_dir / 'mel.npz')
+    cfg = get_config('midi_conformer')
+    u = restate.logmel(g[case + '.audio'], cfg)
+    assert u.shape == g[case + '.units'].shape == (1 + len(g[case + '.audio']) // 512, 80)
+    np.testing.assert_allclose(u, g[case + '.units'], rtol=0, atol=1e-6)
+
+
+def _model_cases(golden_dir):
+    return json.loads((golden_dir / 'model.json').read_text())
+
+
+@pytest.mark.parametrize('name', ['conf_lay8', 'conf_lay2_b2', 'quant_lay3', 'two_head_lay1_mask', 'conf_lay1_t1', 'conf_lay1_t33'])
+def test_model_forward(golden_dir, name):
+    meta = _model_cases(golden_dir)[name]
+    g = np.load(golden_dir / 'model.npz')
+    cfg = get_config(meta['config'], lay=meta['lay'])
+    sd = synth.synth_state_dict(cfg, meta['seed'])
+    logits, bounds = restate.model_forward(sd, cfg, g[name + '.units'], mask=g[name + '.mask'])
+    probs, _ = restate.model_forward(sd, cfg, g[name + '.units'], mask=g[name + '.mask'],
+                                     softmax=meta['quant'], sig=not meta['quant'])
+    np.testing.assert_allclose(logits.numpy(), g[name + '.logits'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(probs.numpy(), g[name + '.probs'], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(bounds.numpy(), g[name + '.bounds'], rtol=0, atol=5e-6)
+
+
+def test_decode_known_answer(golden_dir):
+    """The reference's only textual known-answer (utils/infer_utils.py:103-113)."""
+    g = np.load(golden_dir / 'decode.npz')
+    assert g['kat.item_values'].tolist() == [[60.25, 57, 50, 0], [50.25, 53, 47, 38]]
+    assert g['kat.item_dur'].tolist() == [[4, 2, 3, 0], [3, 1, 5, 2]]
+    for r in range(2):
+        f2i = g['kat.frame2item'][r]
+        iv, idur, im = restate.decode_note_sequence(f2i, g['kat.values'][r], f2i > 0)
+        n = int(f2i.max())
+        np.testing.assert_array_equal(iv, g['kat.item_values'][r][:n])
+        np.testing.assert_array_equal(idur, g['kat.item_dur'][r][:n])
+        np.testing.assert_array_equal(im, g['kat.item_masks'][r][:n])
+
+
+@pytest.mark.parametrize('ci', range(7))
+def test_decode_cases(golden_dir, ci):
+    g = np.load(golden_dir / 'decode.npz')
+    k = f'case{ci}'
+    cfg = get_config('midi_conformer')
+    quant = bool(g[k + '.quant'])
+    res = restate.postprocess(g[k + '.probs'], g[k + '.bounds'], cfg, quantized=quant)
+    np.testing.assert_array_equal(res['_frame2item'], g[k + '.frame2item'])
+    np.testing.assert_array_equal(res['_rest'], g[k + '.rest'])
+    if quant:
+        np.testing.assert_array_equal(res['_values'], g[k + '.values'])
+    else:
+        np.testing.assert_allclose(res['_values'], g[k + '.values'], rtol=1e-6, atol=0)
+    np.testing.assert_array_equal(res['note_dur'], g[k + '.note_dur'])
+    assert res['note_dur'].dtype == np.float64
+    np.testing.assert_array_equal(res['note_rest'], g[k + '.note_rest'])
+    np.testing.assert_allclose(res['note_midi'], g[k + '.note_midi'], rtol=1e-6, atol=0)
+    assert res['note_midi'].dtype == np.float32
+
+
+@pytest.mark.parametrize('name', ['e2e_conf', 'e2e_quant'])
+def test_end_to_end_clip(golden_dir, name):
+    meta = json.loads((golden_dir / 'e2e.json').read_text())[name]
+    g = np.load(golden_dir / 'e2e.npz')
+    cfg = get_config(meta['config'], lay=meta['lay'])
+    sd = synth.synth_state_dict(cfg, meta['seed'])
+    w = synth.synth_clip(meta['clip'], meta['seconds'])
+    res = restate.infer_clip(sd, cfg, w)
+    np.testing.assert_allclose(res['_probs'], g[name + '.probs'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(res['_bounds'], g[name + '.bounds'], rtol=0, atol=2e-5)
+    # decode the REFERENCE's probs/bounds with the restated decoder: must reproduce its notes exactly
+    dec = restate.postprocess(g[name + '.probs'], g[name + '.bounds'], cfg, quantized=meta['quant'])
+    np.testing.assert_array_equal(dec['note_dur'], g[name + '.note_dur'])
+    np.testing.assert_array_equal(dec['note_rest'], g[name + '.note_rest'])
+    np.testing.assert_allclose(dec['note_midi'], g[name + '.note_midi'], rtol=1e-6, atol=0)
