@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""Headline benchmark: audio-seconds per second (x real-time) of the SOME inference hot path on MI355X.
+
+One "step" = one pass of the whole hot path (log-mel front end -> conformer forward -> note decode) over one
+batch of synthetic 44.1 kHz clips that is already resident in HBM.  Workload = BASELINE.json configs[1]:
+configs/midi_conformer.yaml (lay 8, 117.6 M params, fp32), batch of 32 x 30 s clips per GPU.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 5 --warmup 2
+
+Multi-GPU: utterance sharding, one process per GPU, weights packed on rank 0 and broadcast once with RCCL,
+no collective in the timed loop (weak scaling: every rank processes its own 32 clips).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_frame(lay, outdim, T):
+    """SURVEY.md section 8(d) 'Algorithmic FLOPs'."""
+    nb = 2 * lay + 2
+    dense = nb * 12_090_368 + lay * 2_097_152 + 163_840 + 1_024 * outdim + 1_024
+    attn = nb * 2_048 * T
+    return dense, attn
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', default='midi_conformer')
+    ap.add_argument('--batch', type=int, default=32, help='clips per GPU per step')
+    ap.add_argument('--seconds', type=float, default=30.0, help='clip length')
+    ap.add_argument('--lay', type=int, default=None, help='override lay (debug only; invalidates the metric)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--cpu-clips', type=int, default=2, help='clips in the bounded CPU-baseline sample')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from some_amd import _lib, synth
+    from some_amd.configs import get_config
+    from some_amd.engine import ClipBatch, Engine
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f'--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} processes')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)      # "nccl" is RCCL on ROCm
+
+    cfg = get_config(args.config, lay=args.lay) if args.lay is not None else get_config(args.config)
+    quant = cfg['task_cls'].endswith('QuantizedMIDIExtractionTask')
+    lay, outdim = cfg['midi_extractor_args']['lay'], cfg['midi_num_bins']
+    eng = Engine(cfg, device=device)
+
+    # ---- weights: rank 0 packs, RCCL broadcast of the flat fp32 arena over xGMI -------------------------
+    sd = None
+    arena = torch.empty(eng.arena_numel, dtype=torch.float32, device=device)
+    if rank == 0:
+        sd = synth.synth_state_dict(cfg, seed=cfg.get('seed', 114514))
+        arena.copy_(eng.pack_state_dict(sd))
+    if world > 1:
+        dist.broadcast(arena, src=0)
+    eng.attach_arena(arena)
+
+    # ---- synthetic clips (8 distinct per rank, tiled to the batch), resident in HBM ---------------------
+    sr = cfg['audio_sample_rate']
+    n_distinct = min(8, args.batch)
+    clips = [synth.synth_clip(rank * 100 + i, args.seconds, sr) for i in range(n_distinct)]
+    wave_list = [clips[i % n_distinct] for i in range(args.batch)]
+    batch = ClipBatch.from_sample_counts([len(w) for w in wave_list], eng.hop, device)
+    audio = torch.from_numpy(np.concatenate(wave_list)).to(device)
+    T = int(batch.frame_counts[0])
+    head = _lib.HEAD_SOFTMAX if quant else _lib.HEAD_SIGMOID
+
+    def step():
+        units = eng.logmel(audio, batch)
+        probs, bounds = eng.forward(units, batch, head_mode=head)
+        return eng.decode(probs, bounds, batch, quantized=quant)
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        out = step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    n_notes = int(out['n_notes'].sum())
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    audio_seconds = world * args.batch * args.seconds * args.steps
+    value = audio_seconds / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+    dense, attn = flops_per_frame(lay, outdim, T)
+    step_flops = (dense + attn) * batch.total_frames
+    result = {
+        'metric': 'audio-seconds/s (x real-time), SOME inference hot path (log-mel + conformer + decode)',
+        'value': round(value, 2), 'unit': 'audio-s/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'configs/{args.config}.yaml inference, batch of {args.batch} x {args.seconds:g} s '
+                               f'44.1 kHz mono clips per GPU (lay {lay}, {outdim} bins, T={T} frames/clip), random-init weights',
+                   'clips_per_gpu': args.batch, 'clip_seconds': args.seconds, 'frames_per_clip': T,
+                   'parallelism': f'utterance-sharded x{world}, RCCL weight broadcast, no data-path collective'},
+        'model_tflops': round(step_flops * world / (ms_per_step * 1e-3) / 1e12, 2),
+        'notes_decoded_last_step': n_notes,
+    }
+
+    if rank == 0:
+        # ---- per-kernel leg: HIP events around every launch on the launch stream (some_profile_*) -------
+        if not args.no_kernel_profile:
+            eng.profile_enable(True)
+            prof_steps = max(1, min(args.steps, 3))
+            for _ in range(prof_steps):
+                step()
+            torch.cuda.synchronize(device)
+            stats = eng.profile_collect()
+            eng.profile_enable(False)
+            tot = sum(s['total_ms'] for s in stats) or 1.0
+            kernels = []
+            for s in sorted(stats, key=lambda s: -s['total_ms']):
+                avg_ms = s['total_ms'] / s['launches']
+                k = {'name': s['name'], 'launches_per_step': s['launches'] // prof_steps, 'avg_ms': round(avg_ms, 4),
+                     'share': round(s['total_ms'] / tot, 4)}
+                if s['flops'] > 0:
+                    k['tflops'] = round(s['flops'] / s['launches'] / (avg_ms * 1e-3) / 1e12, 2)
+                if s['bytes'] > 0:
+                    k['gbs'] = round(s['bytes'] / s['launches'] / (avg_ms * 1e-3) / 1e9, 1)
+                kernels.append(k)
+            result['kernels'] = kernels
+            dom = next((k for k in kernels if 'tflops' in k), None)
+            if dom is not None:
+                result['roofline'] = {
+                    'kernel': dom['name'], 'bound': 'mfma', 'achieved': dom['tflops'], 'peak': F32_MATRIX_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(dom['tflops'] / F32_MATRIX_PEAK_TFLOPS, 4), 'traffic': None,
+                    'avg_launch_ms': dom['avg_ms'],
+                }
+        # ---- p50 single-clip latency (B = 1, the reference's own granularity) ---------------------------
+        one = ClipBatch.from_sample_counts([len(clips[0])], eng.hop, device)
+        a1 = torch.from_numpy(clips[0]).to(device)
+        lat = []
+        for i in range(8):
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            u = eng.logmel(a1, one)
+            p, b = eng.forward(u, one, head_mode=head)
+            eng.decode(p, b, one, quantized=quant)
+            torch.cuda.synchronize(device)
+            lat.append(time.perf_counter() - t1)
+        result['p50_clip_latency_ms'] = round(1e3 * float(np.median(lat[2:])), 3)
+
+        # ---- CPU baseline: the oracle (port of the reference CPU path), bounded sample, rank 0, N = 1 ---
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import restate
+            threads = torch.get_num_threads()
+            sd_t = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+            restate.infer_clip(sd_t, cfg, clips[0][: sr * 2], quantized=quant)            # warm-up (2 s)
+            tc = time.perf_counter()
+            for i in range(args.cpu_clips):
+                restate.infer_clip(sd_t, cfg, clips[i % n_distinct], quantized=quant)      # B = 1 per clip, as the reference
+            dt = time.perf_counter() - tc
+            result['cpu_baseline'] = {
+                'value': round(args.cpu_clips * args.seconds / dt, 2), 'unit': 'audio-s/s', 'cores': threads,
+                'kind': 'port',
+                'sample': f'{args.cpu_clips} x {args.seconds:g} s clips of the same workload, B=1 per clip '
+                          f'(log-mel + forward + decode), torch-CPU fp32 oracle, {threads} threads',
+            }
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,195 @@
+/*
+ * some_amd.h - C ABI of libsome_amd.so: the MI355X (gfx950) implementation of the openvpi/SOME inference
+ * hot path.  Plain C, raw pointers and sizes only; no torch / HIP types in any signature.
+ *
+ * The reference has no native layer: every entry point below replaces a sequence of
+ * PyTorch ATen calls issued by the reference's Python code.  The Python classes in some_amd/ keep the
+ * reference's operator API (names, argument meaning, error behaviour) and call this library via ctypes;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - All *_dev pointers are device (HBM) pointers owned by the CALLER (e.g. the PyTorch caching allocator).
+ *    The library allocates device memory only in some_create (constant tables, a few hundred KB).
+ *  - Clips are packed back to back ("var-len"): clip b owns frames [frame_offsets[b], frame_offsets[b+1]) of
+ *    every [total_frames, C] array and samples [sample_offsets[b], sample_offsets[b+1]) of the audio array.
+ *    Every operator that looks across time (STFT padding, attention, depthwise conv, decode) treats each
+ *    clip independently, exactly as the reference's per-chunk B=1 loop does (inference/base_infer.py:46-53).
+ *  - Every call only ENQUEUES work on `stream` (a hipStream_t passed as void*, NULL = default stream) and
+ *    returns; nothing synchronises except where stated.
+ *  - Return value: 0 on success, negative SOME_E* on failure; some_last_error() gives the message.  The
+ *    library never aborts the process.
+ */
+#ifndef SOME_AMD_H
+#define SOME_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOME_OK 0
+#define SOME_EINVAL (-1)   /* bad argument / unsupported configuration            */
+#define SOME_EKEY (-2)     /* state-dict key set mismatch (strict load)            */
+#define SOME_ESHAPE (-3)   /* state-dict tensor shape mismatch                     */
+#define SOME_EHIP (-4)     /* HIP runtime error (message carries hipGetErrorString) */
+#define SOME_ESTATE (-5)   /* call order error (e.g. forward before attach_arena)  */
+#define SOME_ENOMEM (-6)   /* workspace too small                                  */
+
+typedef struct SomeHandle SomeHandle;
+
+/* Hot-path keys of the reference's config.yaml (configs/base.yaml:11-28, configs/midi_conformer.yaml:16-33). */
+typedef struct SomeConfig {
+    int32_t lay;            /* midi_extractor_args.lay                  */
+    int32_t dim;            /* midi_extractor_args.dim        (512)     */
+    int32_t heads;          /* attention_heads                (8)       */
+    int32_t head_dim;       /* attention_heads_dim            (64)      */
+    int32_t kernel_size;    /* depthwise kernel               (31)      */
+    int32_t indim;          /* units_dim                      (80)      */
+    int32_t outdim;         /* midi_num_bins                  (128|129) */
+    int32_t sample_rate;    /* audio_sample_rate              (44100)   */
+    int32_t hop_size;       /* hop_size                       (512)     */
+    int32_t win_size;       /* win_size == n_fft              (2048)    */
+    float fmin;             /* fmin                           (40)      */
+    float fmax;             /* fmax                           (8000)    */
+    double midi_min;        /* midi_min                       (0)       */
+    double midi_max;        /* midi_max                       (127)     */
+    double midi_deviation;  /* midi_prob_deviation            (1.0)     */
+    double rest_threshold;  /* rest_threshold                 (0.1)     */
+} SomeConfig;
+
+/* One entry of a PyTorch state_dict, host memory, contiguous, as produced by
+ * torch.load(ckpt)['state_dict'] after the 'model.' prefix strip (inference/base_infer.py:27-32). */
+typedef struct SomeTensorDesc {
+    const char* name;       /* e.g. "model.cf_lay.0.att1.ffn1.ln1.weight"  */
+    const void* data;       /* host pointer                                */
+    int32_t dtype;          /* 0 = float32, 1 = int64                      */
+    int32_t ndim;
+    int64_t shape[4];
+} SomeTensorDesc;
+
+/* ---- lifecycle ---------------------------------------------------------------------------------- */
+
+/* Replaces: model construction in BaseInference.build_model (inference/base_infer.py:24-26) and the
+ * MelSpectrogram constructor (modules/rmvpe/spec.py:8-36; mel filterbank, Hann window, FFT twiddles).
+ * Validates the configuration (dim 512, 8x64 heads, k=31, win 2048 / hop 512 are the compiled shapes). */
+int some_create(const SomeConfig* cfg, SomeHandle** out);
+void some_destroy(SomeHandle* h);
+/* Message for the last failing call on this handle (h may be NULL: error of the last failed some_create). */
+const char* some_last_error(const SomeHandle* h);
+/* Library / build identification string ("some_amd <ver> gfx950 ..."). */
+const char* some_version(void);
+
+/* ---- weights ------------------------------------------------------------------------------------ */
+
+/* Replaces: nn.Module.load_state_dict(strict=True) (inference/base_infer.py:33).
+ * Packs the n named host tensors into the library's flat fp32 arena layout (host memory, some_arena_bytes()
+ * long): [N,K] GEMM weights, fused QKV, GLU halves interleaved per 32 columns, BatchNorm folded into the
+ * depthwise weights/bias (eval mode, eps 1e-5; modules/conv/base_conv.py:52,66).  Missing / unexpected
+ * keys -> SOME_EKEY, wrong shapes -> SOME_ESHAPE, like strict=True.  `num_batches_tracked` is accepted
+ * and ignored.  The caller uploads the arena (and, multi-GPU, broadcasts it with RCCL) and attaches it. */
+size_t some_arena_bytes(const SomeHandle* h);
+int some_pack_weights(SomeHandle* h, const SomeTensorDesc* tensors, int32_t n, float* host_arena);
+/* Borrow a device copy of the packed arena; it must stay alive and unchanged while the handle is used. */
+int some_attach_arena(SomeHandle* h, const float* arena_dev, size_t bytes);
+
+/* ---- front end ---------------------------------------------------------------------------------- */
+
+/* Replaces: librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax, htk=True) at modules/rmvpe/spec.py:22-28.
+ * Host-only: writes the float32 [n_mels(80), 1 + win_size/2] basis the device kernel applies. */
+int some_mel_filterbank(const SomeHandle* h, float* basis_host);
+
+/* Replaces: MelSpectrogram.forward(keyshift=0, speed=1, center=True) + transpose(1,2)
+ * (modules/rmvpe/spec.py:38-72, inference/me_infer.py:31).
+ * audio_dev: fp32 packed clips; clip b has n_b = sample_offsets[b+1]-sample_offsets[b] samples and
+ * produces T_b = 1 + n_b / hop frames at rows frame_offsets[b]... of units_dev [total_frames, n_mels].
+ * sample_offsets_dev / frame_offsets_dev: device int64 / int32 arrays of B+1 entries.
+ * max_frames: max_b T_b (host value, sizes the launch). */
+int some_logmel(SomeHandle* h, const float* audio_dev, const int64_t* sample_offsets_dev,
+                const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames,
+                float* units_dev, void* stream);
+
+/* ---- network ------------------------------------------------------------------------------------ */
+
+#define SOME_HEAD_LOGITS 0   /* midi = outln(x)                  (Gmidi_conform.py:30-32)            */
+#define SOME_HEAD_SIGMOID 1  /* sig=True:  sigmoid(midi)         (Gmidi_conform.py:33-34)            */
+#define SOME_HEAD_SOFTMAX 2  /* softmax=True: softmax over bins  (Gmidi_conform.py:36-37)            */
+
+size_t some_workspace_bytes(const SomeHandle* h, int64_t total_frames, int32_t B);
+
+/* Replaces: midi_conforms.forward(x, f0, mask, softmax, sig) (modules/model/Gmidi_conform.py:30-40 over
+ * modules/conform/Gconform.py:119-140).  f0 is ignored by the reference model and has no parameter here.
+ * units_dev [total_frames, indim]; row_mask_dev: optional uint8 [total_frames] (0 = masked frame ->
+ * masked_fill on the midi stream, Gconform.py:126-132), NULL = all ones (what inference passes).
+ * Outputs: midi_dev [total_frames, outdim], bound_dev [total_frames] (already sigmoid).
+ * workspace_dev: at least some_workspace_bytes(total_frames, B) bytes, 256-byte aligned. */
+int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_offsets_dev, int32_t B,
+                 int64_t total_frames, int32_t max_frames, const uint8_t* row_mask_dev, int32_t head_mode,
+                 float* midi_dev, float* bound_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---- decode ------------------------------------------------------------------------------------- */
+
+/* Replaces: MIDIExtractionInference.postprocess (inference/me_infer.py:78-97) or, with quantized != 0,
+ * QuantizedMIDIExtractionInference.postprocess (inference/me_quant_infer.py:22-38), i.e.
+ * decode_bounds_to_alignment + decode_gaussian_blurred_probs|argmax + decode_note_sequence
+ * (utils/infer_utils.py:9-76), per clip.
+ * probs_dev [total_frames, outdim], bounds_dev [total_frames], row_mask_dev optional (NULL = all ones).
+ * Outputs (device): clip b's notes are written at rows frame_offsets[b] ... frame_offsets[b]+n_notes[b]-1
+ * of note_midi_dev (fp32), note_dur_dev (int64, in FRAMES; the caller multiplies by hop/sr in float64 as
+ * me_infer.py:95 does) and note_rest_dev (uint8); n_notes_dev int32 [B].
+ * Optional per-frame intermediates (may be NULL): frame2item_dev int64 [total_frames],
+ * values_dev fp32 [total_frames] (quantized: the clipped argmax as fp32), rest_dev uint8 [total_frames].
+ * scratch_dev: some_decode_scratch_bytes(total_frames) bytes. */
+size_t some_decode_scratch_bytes(const SomeHandle* h, int64_t total_frames);
+int some_decode(SomeHandle* h, const float* probs_dev, const float* bounds_dev, const uint8_t* row_mask_dev,
+                const int32_t* frame_offsets_dev, int32_t B, int64_t total_frames, int32_t quantized,
+                float* note_midi_dev, int64_t* note_dur_dev, uint8_t* note_rest_dev, int32_t* n_notes_dev,
+                int64_t* frame2item_dev, float* values_dev, uint8_t* rest_dev,
+                void* scratch_dev, size_t scratch_bytes, void* stream);
+
+/* ---- single-operator entry points (kernel-level parity tests and micro-benchmarks) ------------------ */
+
+#define SOME_EPI_NONE 0       /* C = A W^T                                                          */
+#define SOME_EPI_BIAS 1       /* C = act(A W^T + b), act: 0 none / 1 sigmoid; optional row mask      */
+#define SOME_EPI_BIAS_SILU 2  /* C = silu(A W^T + b)                       (Gconform.py:30-31)       */
+#define SOME_EPI_BIAS_RES 3   /* C = res + alpha (A W^T + b)               (Gconform.py:57,60-62)    */
+#define SOME_EPI_GLU 4        /* C = (a + ba) sigmoid(g + bg), W rows packed 32 a | 32 gate          */
+#define SOME_EPI_GLU_RES 5    /* C = res + GLU(...), optional row mask     (Gconform.py:82-87)       */
+
+/* One nn.Linear (+ fused epilogue) on the f32 matrix pipe.  A [M,lda], W [N,K] (K contiguous), C [M,ldc].
+ * For the GLU epilogues N counts the packed rows (2 x output width) and C gets N/2 columns. */
+int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t lda, const float* W_dev,
+                 const float* bias_dev, const float* res_dev, int32_t ldr, float* C_dev, int32_t ldc,
+                 int32_t M, int32_t N, int32_t K, float alpha, int32_t act, const uint8_t* row_mask_dev,
+                 void* stream);
+/* nn.LayerNorm(512), eps 1e-5 (Gconform.py:49-53): y = LN(x) * gamma + beta, rows of 512. */
+int some_op_layernorm(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                      float* y_dev, int32_t M, void* stream);
+/* Unmasked per-clip attention, 8 heads x 64, scale 1/8 (base_attention.py:34-44): qkv [M,1536] -> out [M,512]. */
+int some_op_attention(SomeHandle* h, const float* qkv_dev, const int32_t* frame_offsets_dev, int32_t B,
+                      int32_t max_frames, float* out_dev, void* stream);
+/* Depthwise k=31 conv (taps [31,512], BatchNorm already folded) + bias + SiLU, per-clip zero padding
+ * (base_conv.py:66-68): x [M,512] -> y [M,512]. */
+int some_op_dwconv_silu(SomeHandle* h, const float* x_dev, const float* taps_dev, const float* bias_dev,
+                        const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, float* y_dev, void* stream);
+
+/* ---- per-kernel timing (measurement only; off by default) ----------------------------------------- */
+
+typedef struct SomeKernelStat {
+    char name[48];          /* kernel family, e.g. "gemm_bias_silu[512->2048]"                         */
+    int64_t launches;
+    double total_ms;        /* sum of hipEventElapsedTime over the launches since the last reset       */
+    double flops;           /* algorithmic FLOPs summed over those launches (0 for byte-bound kernels) */
+    double bytes;           /* algorithmic HBM bytes summed over those launches                        */
+} SomeKernelStat;
+
+/* on != 0: bracket every kernel launch of subsequent calls with hipEvents on the launch stream. */
+int some_profile_enable(SomeHandle* h, int32_t on);
+/* Synchronises the recorded events, accumulates and returns up to max_stats entries; resets the log. */
+int some_profile_collect(SomeHandle* h, SomeKernelStat* stats, int32_t max_stats, int32_t* n_stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOME_AMD_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of libsome_amd.so - the only door between the Python host side and the HIP kernels.
+
+The library is built in-tree by ``python -m some_amd.build`` (or ``__graft_entry__.build()``).  There is NO
+fallback: if the shared object is missing or a call fails, the Python layer raises.
+"""
+import ctypes as C
+import pathlib
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _HERE / 'libsome_amd.so'
+
+SOME_OK = 0
+SOME_EINVAL, SOME_EKEY, SOME_ESHAPE, SOME_EHIP, SOME_ESTATE, SOME_ENOMEM = -1, -2, -3, -4, -5, -6
+HEAD_LOGITS, HEAD_SIGMOID, HEAD_SOFTMAX = 0, 1, 2
+EPI_NONE, EPI_BIAS, EPI_BIAS_SILU, EPI_BIAS_RES, EPI_GLU, EPI_GLU_RES = range(6)
+
+
+class SomeConfig(C.Structure):
+    _fields_ = [
+        ('lay', C.c_int32), ('dim', C.c_int32), ('heads', C.c_int32), ('head_dim', C.c_int32),
+        ('kernel_size', C.c_int32), ('indim', C.c_int32), ('outdim', C.c_int32),
+        ('sample_rate', C.c_int32), ('hop_size', C.c_int32), ('win_size', C.c_int32),
+        ('fmin', C.c_float), ('fmax', C.c_float),
+        ('midi_min', C.c_double), ('midi_max', C.c_double),
+        ('midi_deviation', C.c_double), ('rest_threshold', C.c_double),
+    ]
+
+
+class SomeTensorDesc(C.Structure):
+    _fields_ = [('name', C.c_char_p), ('data', C.c_void_p), ('dtype', C.c_int32), ('ndim', C.c_int32),
+                ('shape', C.c_int64 * 4)]
+
+
+class SomeKernelStat(C.Structure):
+    _fields_ = [('name', C.c_char * 48), ('launches', C.c_int64), ('total_ms', C.c_double),
+                ('flops', C.c_double), ('bytes', C.c_double)]
+
+
+# every symbol include/some_amd.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    'some_create': (C.c_int, [C.POINTER(SomeConfig), C.POINTER(_P)]),
+    'some_destroy': (None, [_P]),
+    'some_last_error': (C.c_char_p, [_P]),
+    'some_version': (C.c_char_p, []),
+    'some_arena_bytes': (C.c_size_t, [_P]),
+    'some_pack_weights': (C.c_int, [_P, C.POINTER(SomeTensorDesc), C.c_int32, _P]),
+    'some_attach_arena': (C.c_int, [_P, _P, C.c_size_t]),
+    'some_mel_filterbank': (C.c_int, [_P, _P]),
+    'some_logmel': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
+    'some_workspace_bytes': (C.c_size_t, [_P, C.c_int64, C.c_int32]),
+    'some_forward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_size_t, _P]),
+    'some_decode_scratch_bytes': (C.c_size_t, [_P, C.c_int64]),
+    'some_decode': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    'some_op_gemm': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32,
+                               C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P]),
+    'some_op_layernorm': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P]),
+    'some_op_attention': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
+    'some_op_dwconv_silu': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
+    'some_profile_enable': (C.c_int, [_P, C.c_int32]),
+    'some_profile_collect': (C.c_int, [_P, C.POINTER(SomeKernelStat), C.c_int32, C.POINTER(C.c_int32)]),
+}
+
+_lib = None
+
+
+class SomeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'libsome_amd error {code}: {msg}')
+        self.code = code
+
+
+def load():
+    """Load (once) and return the ctypes library with typed signatures.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: the HIP extension has not been built. Run `python -m some_amd.build` '
+            f'(needs hipcc, ROCm >= 7.0). There is no CPU / PyTorch fallback for the hot path.')
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)     # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(handle, rc):
+    if rc != SOME_OK:
+        msg = load().some_last_error(handle)
+        raise SomeError(rc, msg.decode('utf8', 'replace') if msg else '')

@@ -1,0 +1,73 @@
+"""Build libsome_amd.so (HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+No torch / pybind involvement: the library is a plain C-ABI shared object (include/some_amd.h) loaded with
+ctypes (some_amd/_lib.py).  hipcc cross-compiles without a GPU, so this also runs in the build container.
+
+    python -m some_amd.build [--force]
+"""
+import concurrent.futures
+import os
+import pathlib
+import shutil
+import subprocess
+import sys
+
+HERE = pathlib.Path(__file__).resolve().parent
+CSRC = HERE / 'csrc'
+OBJ = CSRC / 'build'
+LIB = HERE / 'libsome_amd.so'
+SOURCES = ['api.hip', 'gemm.hip', 'rowops.hip', 'attention.hip', 'dwconv.hip', 'logmel.hip', 'decode.hip']
+HEADERS = [CSRC / 'internal.h', CSRC / 'fft_core.h', HERE.parent / 'include' / 'some_amd.h']
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found (need ROCm >= 7.0 to build libsome_amd.so)')
+    return exe
+
+
+def _stale(target: pathlib.Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(pathlib.Path(d).stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
+    hipcc = _hipcc()
+    OBJ.mkdir(parents=True, exist_ok=True)
+    jobs = []
+    for src in SOURCES:
+        s, o = CSRC / src, OBJ / (src + '.o')
+        if force or _stale(o, [s] + HEADERS):
+            jobs.append((s, o))
+
+    def compile_one(job):
+        s, o = job
+        cmd = [hipcc] + FLAGS + ['-c', str(s), '-o', str(o)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {s.name}:\n{r.stdout}\n{r.stderr}')
+        return s.name, r.stderr
+
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for name, err in ex.map(compile_one, jobs):
+                if verbose:
+                    print(f'[some_amd.build] compiled {name}' + (f'\n{err}' if err.strip() else ''))
+    objs = [OBJ / (s + '.o') for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', str(LIB)] + [str(o) for o in objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+        if verbose:
+            print(f'[some_amd.build] linked {LIB}')
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,640 @@
+// C ABI of libsome_amd.so (include/some_amd.h): handle lifecycle, weight packing, and the launch sequences
+// that replace the reference's Python-level op chains.  Host code only; kernels live in the sibling files.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+
+#include "internal.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int fail(SomeHandle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+int fail_hip(SomeHandle* h, hipError_t e, const char* what) {
+    return fail(h, SOME_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(h, expr)                                             \
+    do {                                                             \
+        hipError_t _e = (expr);                                      \
+        if (_e != hipSuccess) return fail_hip((h), _e, #expr);       \
+    } while (0)
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- arena layout ------------------------------------------------------------------------------------
+struct Cursor {
+    size_t pos = 0;
+    size_t take(size_t n) { size_t p = pos; pos = align_up(pos + n, 64); return p; }   // 256-byte aligned
+};
+
+void build_layout(const SomeConfig& c, ArenaLayout& L) {
+    Cursor cur;
+    for (int g = 0; g < kStreams; ++g) { L.in_w[g] = cur.take((size_t)kDim * c.indim); L.in_b[g] = cur.take(kDim); }
+    L.out_w = cur.take((size_t)c.outdim * kDim);
+    L.out_b = cur.take(c.outdim);
+    L.cut_w = cur.take(kDim);
+    L.cut_b = cur.take(1);
+    L.blocks.resize((size_t)(c.lay + 1) * 2);
+    for (auto& b : L.blocks) {
+        for (int i = 0; i < 5; ++i) { b.ln_g[i] = cur.take(kDim); b.ln_b[i] = cur.take(kDim); }
+        for (int f = 0; f < 2; ++f) {
+            b.ffn_w1[f] = cur.take((size_t)kFfn * kDim); b.ffn_b1[f] = cur.take(kFfn);
+            b.ffn_w2[f] = cur.take((size_t)kDim * kFfn); b.ffn_b2[f] = cur.take(kDim);
+        }
+        b.wqkv = cur.take((size_t)3 * kDim * kDim);
+        b.wo = cur.take((size_t)kDim * kDim); b.bo = cur.take(kDim);
+        b.pw1_w = cur.take((size_t)2 * kDim * kDim); b.pw1_b = cur.take(2 * kDim);
+        b.dw_w = cur.take((size_t)kConvK * kDim); b.dw_b = cur.take(kDim);
+        b.pw2_w = cur.take((size_t)kDim * kDim); b.pw2_b = cur.take(kDim);
+    }
+    L.glu_w.resize((size_t)c.lay * 2);
+    L.glu_b.resize((size_t)c.lay * 2);
+    for (size_t i = 0; i < L.glu_w.size(); ++i) { L.glu_w[i] = cur.take((size_t)2 * kDim * kDim); L.glu_b[i] = cur.take(2 * kDim); }
+    L.total_floats = cur.pos;
+}
+
+// ---- mel filterbank (librosa.filters.mel, htk=True, norm='slaney'; call site spec.py:22-28) ----------
+double hz_to_mel(double f) { return 2595.0 * std::log10(1.0 + f / 700.0); }
+double mel_to_hz(double m) { return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0); }
+
+void mel_basis(const SomeConfig& c, std::vector<float>& out) {
+    const int n_bins = 1 + c.win_size / 2, n_mels = kMels;
+    const double fmax = c.fmax > 0 ? (double)c.fmax : c.sample_rate / 2.0;
+    std::vector<double> fftf(n_bins), melf(n_mels + 2);
+    const double fstep = (c.sample_rate / 2.0) / (n_bins - 1);
+    for (int i = 0; i < n_bins; ++i) fftf[i] = i * fstep;
+    fftf[n_bins - 1] = c.sample_rate / 2.0;
+    const double m0 = hz_to_mel(c.fmin), m1 = hz_to_mel(fmax);
+    const double mstep = (m1 - m0) / (n_mels + 1);
+    for (int i = 0; i < n_mels + 2; ++i) melf[i] = mel_to_hz(i == n_mels + 1 ? m1 : m0 + i * mstep);
+    out.assign((size_t)n_mels * n_bins, 0.f);
+    for (int i = 0; i < n_mels; ++i) {
+        const double fd0 = melf[i + 1] - melf[i], fd1 = melf[i + 2] - melf[i + 1];
+        const double enorm = 2.0 / (melf[i + 2] - melf[i]);
+        for (int j = 0; j < n_bins; ++j) {
+            const double lower = -(melf[i] - fftf[j]) / fd0;
+            const double upper = (melf[i + 2] - fftf[j]) / fd1;
+            const double w = std::max(0.0, std::min(lower, upper)) * enorm;
+            out[(size_t)i * n_bins + j] = (float)w;
+        }
+    }
+}
+
+int ensure_mel_tables(SomeHandle* h) {
+    if (h->mel_blob) return SOME_OK;
+    const int n_bins = 1 + kWin / 2;
+    std::vector<float> basis;
+    mel_basis(h->cfg, basis);
+    std::vector<int32_t> start(kMels), len(kMels), off(kMels);
+    std::vector<float> packed;
+    int kmax = 0;
+    for (int m = 0; m < kMels; ++m) {
+        int first = -1, last = -1;
+        for (int j = 0; j < n_bins; ++j)
+            if (basis[(size_t)m * n_bins + j] != 0.f) { if (first < 0) first = j; last = j; }
+        if (first < 0) { first = 0; last = -1; }
+        start[m] = first; len[m] = last - first + 1; off[m] = (int32_t)packed.size();
+        for (int j = first; j <= last; ++j) packed.push_back(basis[(size_t)m * n_bins + j]);
+        kmax = std::max(kmax, last);
+    }
+    std::vector<float> window(kWin), tw(2 * 2048);
+    for (int n = 0; n < kWin; ++n) window[n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / kWin));   // periodic Hann
+    for (int k = 0; k < 2048; ++k) {
+        const double ang = -2.0 * M_PI * k / 2048.0;
+        tw[2 * k] = (float)std::cos(ang);
+        tw[2 * k + 1] = (float)std::sin(ang);
+    }
+    // one blob: window | twiddle | mel_w | start | len | off
+    const size_t o_win = 0, o_tw = o_win + kWin * 4, o_w = o_tw + tw.size() * 4;
+    const size_t o_st = align_up(o_w + packed.size() * 4, 16), o_len = o_st + kMels * 4, o_off = o_len + kMels * 4;
+    const size_t total = o_off + kMels * 4;
+    std::vector<char> host(total, 0);
+    memcpy(host.data() + o_win, window.data(), kWin * 4);
+    memcpy(host.data() + o_tw, tw.data(), tw.size() * 4);
+    memcpy(host.data() + o_w, packed.data(), packed.size() * 4);
+    memcpy(host.data() + o_st, start.data(), kMels * 4);
+    memcpy(host.data() + o_len, len.data(), kMels * 4);
+    memcpy(host.data() + o_off, off.data(), kMels * 4);
+    void* dev = nullptr;
+    HIP_TRY(h, hipMalloc(&dev, total));
+    hipError_t e = hipMemcpy(dev, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(dev); return fail_hip(h, e, "hipMemcpy(mel tables)"); }
+    char* d = static_cast<char*>(dev);
+    h->mel_blob = dev;
+    h->mel.window = reinterpret_cast<float*>(d + o_win);
+    h->mel.twiddle = reinterpret_cast<float*>(d + o_tw);
+    h->mel.mel_w = reinterpret_cast<float*>(d + o_w);
+    h->mel.mel_start = reinterpret_cast<int32_t*>(d + o_st);
+    h->mel.mel_len = reinterpret_cast<int32_t*>(d + o_len);
+    h->mel.mel_off = reinterpret_cast<int32_t*>(d + o_off);
+    h->mel.kmax = std::min(kmax, 1024);
+    return SOME_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------------
+struct Scope {
+    SomeHandle* h; hipStream_t s; ProfRecord rec; bool on;
+    Scope(SomeHandle* h_, hipStream_t s_, const char* name, double flops, double bytes) : h(h_), s(s_), on(h_->profiling) {
+        if (!on) return;
+        rec.name = name; rec.flops = flops; rec.bytes = bytes;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!h->event_pool.empty()) { e = h->event_pool.back(); h->event_pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        rec.e0 = get(); rec.e1 = get();
+        (void)hipEventRecord(rec.e0, s);
+    }
+    ~Scope() {
+        if (!on) return;
+        (void)hipEventRecord(rec.e1, s);
+        h->prof.push_back(rec);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* some_version(void) { return "some_amd 0.1 gfx950 (f32 MFMA conformer, HIP)"; }
+
+const char* some_last_error(const SomeHandle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int some_create(const SomeConfig* cfg, SomeHandle** out) {
+    if (!cfg || !out) return fail(nullptr, SOME_EINVAL, "some_create: null argument");
+    char msg[256];
+#define REQUIRE(cond, ...)                                                                   \
+    if (!(cond)) { snprintf(msg, sizeof msg, __VA_ARGS__); return fail(nullptr, SOME_EINVAL, msg); }
+    REQUIRE(cfg->lay >= 0 && cfg->lay <= 64, "unsupported lay=%d", cfg->lay);
+    REQUIRE(cfg->dim == kDim, "unsupported dim=%d (compiled for %d)", cfg->dim, kDim);
+    REQUIRE(cfg->heads == kHeads && cfg->head_dim == kHeadDim, "unsupported attention %dx%d (compiled for %dx%d)",
+            cfg->heads, cfg->head_dim, kHeads, kHeadDim);
+    REQUIRE(cfg->kernel_size == kConvK, "unsupported kernel_size=%d (compiled for %d)", cfg->kernel_size, kConvK);
+    REQUIRE(cfg->indim > 0 && cfg->indim % 4 == 0 && cfg->indim <= 1024, "unsupported units_dim=%d (need a multiple of 4)", cfg->indim);
+    REQUIRE(cfg->outdim >= 2 && cfg->outdim <= 192, "unsupported midi_num_bins=%d", cfg->outdim);
+    REQUIRE(cfg->win_size == kWin && cfg->hop_size == kHop, "unsupported win/hop %d/%d (compiled for %d/%d)",
+            cfg->win_size, cfg->hop_size, kWin, kHop);
+    REQUIRE(cfg->indim == kMels, "front end is compiled for %d mel bands, got units_dim=%d", kMels, cfg->indim);
+    REQUIRE(cfg->sample_rate > 0 && cfg->fmin >= 0, "bad sample_rate/fmin");
+#undef REQUIRE
+    SomeHandle* h = new SomeHandle();
+    h->cfg = *cfg;
+    build_layout(h->cfg, h->lay);
+    *out = h;
+    return SOME_OK;
+}
+
+void some_destroy(SomeHandle* h) {
+    if (!h) return;
+    if (h->mel_blob) (void)hipFree(h->mel_blob);
+    for (auto& r : h->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : h->event_pool) (void)hipEventDestroy(e);
+    delete h;
+}
+
+size_t some_arena_bytes(const SomeHandle* h) { return h ? h->lay.total_floats * sizeof(float) : 0; }
+
+int some_mel_filterbank(const SomeHandle* h, float* basis_host) {
+    if (!h || !basis_host) return SOME_EINVAL;
+    std::vector<float> b;
+    mel_basis(h->cfg, b);
+    memcpy(basis_host, b.data(), b.size() * sizeof(float));
+    return SOME_OK;
+}
+
+int some_pack_weights(SomeHandle* h, const SomeTensorDesc* tensors, int32_t n, float* arena) {
+    if (!h) return SOME_EINVAL;
+    if (!tensors || !arena || n < 0) return fail(h, SOME_EINVAL, "some_pack_weights: null argument");
+    const SomeConfig& c = h->cfg;
+    std::map<std::string, const SomeTensorDesc*> have;
+    for (int i = 0; i < n; ++i) have[tensors[i].name] = &tensors[i];
+    std::set<std::string> used;
+    std::string missing, bad_shape;
+    auto get = [&](const std::string& name, std::initializer_list<int64_t> shape) -> const float* {
+        auto it = have.find(name);
+        if (it == have.end()) { if (missing.size() < 400) missing += " " + name; return nullptr; }
+        used.insert(name);
+        const SomeTensorDesc* t = it->second;
+        bool ok = t->dtype == 0 && t->ndim == (int)shape.size();
+        int d = 0;
+        for (int64_t s : shape) { if (ok && t->shape[d] != s) ok = false; ++d; }
+        if (!ok) { if (bad_shape.size() < 400) bad_shape += " " + name; return nullptr; }
+        return static_cast<const float*>(t->data);
+    };
+    std::fill(arena, arena + h->lay.total_floats, 0.f);
+    auto copy = [&](size_t off, const float* src, size_t cnt) { if (src) memcpy(arena + off, src, cnt * sizeof(float)); };
+    // GLU-producing GEMMs: packed row p <- source row (p%64 < 32 ? a-row : gate-row) so that one wave's two
+    // 32-column MFMA tiles hold an output column and its gate (gemm.hip, EPI_GLU)
+    auto copy_glu = [&](size_t w_off, size_t b_off, const float* w, const float* b) {
+        if (!w || !b) return;
+        for (int p = 0; p < 2 * kDim; ++p) {
+            const int c64 = p / 64, wi = p % 64;
+            const int src = wi < 32 ? c64 * 32 + wi : kDim + c64 * 32 + (wi - 32);
+            memcpy(arena + w_off + (size_t)p * kDim, w + (size_t)src * kDim, kDim * sizeof(float));
+            arena[b_off + p] = b[src];
+        }
+    };
+    const int64_t D = kDim, F = kFfn, K = kConvK;
+    const ArenaLayout& L = h->lay;
+    copy(L.in_w[0], get("model.inln.weight", {D, c.indim}), (size_t)D * c.indim);
+    copy(L.in_b[0], get("model.inln.bias", {D}), D);
+    copy(L.in_w[1], get("model.inln1.weight", {D, c.indim}), (size_t)D * c.indim);
+    copy(L.in_b[1], get("model.inln1.bias", {D}), D);
+    copy(L.out_w, get("model.outln.weight", {c.outdim, D}), (size_t)c.outdim * D);
+    copy(L.out_b, get("model.outln.bias", {c.outdim}), c.outdim);
+    copy(L.cut_w, get("model.cutheard.weight", {1, D}), D);
+    copy(L.cut_b, get("model.cutheard.bias", {1}), 1);
+    for (int layer = 0; layer <= c.lay; ++layer) {
+        for (int g = 0; g < kStreams; ++g) {
+            const std::string p = (layer < c.lay ? "model.cf_lay." + std::to_string(layer) : std::string("model")) +
+                                  (g == 0 ? ".att1." : ".att2.");
+            const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
+            for (int i = 0; i < 5; ++i) {
+                copy(b.ln_g[i], get(p + "norm" + std::to_string(i + 1) + ".weight", {D}), D);
+                copy(b.ln_b[i], get(p + "norm" + std::to_string(i + 1) + ".bias", {D}), D);
+            }
+            for (int f = 0; f < 2; ++f) {
+                const std::string q = p + (f == 0 ? "ffn1." : "ffn2.");
+                copy(b.ffn_w1[f], get(q + "ln1.weight", {F, D}), (size_t)F * D);
+                copy(b.ffn_b1[f], get(q + "ln1.bias", {F}), F);
+                copy(b.ffn_w2[f], get(q + "ln2.weight", {D, F}), (size_t)D * F);
+                copy(b.ffn_b2[f], get(q + "ln2.bias", {D}), D);
+            }
+            copy(b.wqkv, get(p + "att.to_q.weight", {D, D}), (size_t)D * D);                 // rows 0..511   = q
+            copy(b.wqkv + (size_t)D * D, get(p + "att.to_kv.weight", {2 * D, D}), (size_t)2 * D * D);   // k | v
+            copy(b.wo, get(p + "att.to_out.0.weight", {D, D}), (size_t)D * D);
+            copy(b.bo, get(p + "att.to_out.0.bias", {D}), D);
+            copy_glu(b.pw1_w, b.pw1_b, get(p + "conv.pointwise_conv1.weight", {2 * D, D, 1}),
+                     get(p + "conv.pointwise_conv1.bias", {2 * D}));
+            const float* dw = get(p + "conv.depthwise_conv.weight", {D, 1, K});
+            const float* db = get(p + "conv.depthwise_conv.bias", {D});
+            const float* bn_w = get(p + "conv.norm.weight", {D});
+            const float* bn_b = get(p + "conv.norm.bias", {D});
+            const float* bn_m = get(p + "conv.norm.running_mean", {D});
+            const float* bn_v = get(p + "conv.norm.running_var", {D});
+            if (have.count(p + "conv.norm.num_batches_tracked")) used.insert(p + "conv.norm.num_batches_tracked");
+            if (dw && db && bn_w && bn_b && bn_m && bn_v) {
+                for (int ch = 0; ch < kDim; ++ch) {          // BatchNorm1d eval fold, eps 1e-5 (base_conv.py:52,66)
+                    const double scale = (double)bn_w[ch] / std::sqrt((double)bn_v[ch] + 1e-5);
+                    for (int j = 0; j < kConvK; ++j)
+                        arena[b.dw_w + (size_t)j * kDim + ch] = (float)((double)dw[(size_t)ch * kConvK + j] * scale);
+                    arena[b.dw_b + ch] = (float)(((double)db[ch] - (double)bn_m[ch]) * scale + (double)bn_b[ch]);
+                }
+            }
+            copy(b.pw2_w, get(p + "conv.pointwise_conv2.weight", {D, D, 1}), (size_t)D * D);
+            copy(b.pw2_b, get(p + "conv.pointwise_conv2.bias", {D}), D);
+        }
+        if (layer < c.lay) {
+            for (int k = 0; k < 2; ++k) {
+                const std::string p = "model.cf_lay." + std::to_string(layer) + (k == 0 ? ".glu1.0." : ".glu2.0.");
+                copy_glu(L.glu_w[(size_t)layer * 2 + k], L.glu_b[(size_t)layer * 2 + k],
+                         get(p + "weight", {2 * D, D}), get(p + "bias", {2 * D}));
+            }
+        }
+    }
+    if (!missing.empty()) return fail(h, SOME_EKEY, "Missing key(s) in state_dict:" + missing);
+    std::string unexpected;
+    for (auto& kv : have)
+        if (!used.count(kv.first) && unexpected.size() < 400) unexpected += " " + kv.first;
+    if (!unexpected.empty()) return fail(h, SOME_EKEY, "Unexpected key(s) in state_dict:" + unexpected);
+    if (!bad_shape.empty()) return fail(h, SOME_ESHAPE, "size mismatch for:" + bad_shape);
+    return SOME_OK;
+}
+
+int some_attach_arena(SomeHandle* h, const float* arena_dev, size_t bytes) {
+    if (!h) return SOME_EINVAL;
+    if (!arena_dev || bytes < some_arena_bytes(h)) return fail(h, SOME_EINVAL, "some_attach_arena: buffer too small");
+    if (reinterpret_cast<uintptr_t>(arena_dev) & 255) return fail(h, SOME_EINVAL, "some_attach_arena: arena must be 256-byte aligned");
+    h->arena = arena_dev;
+    return SOME_OK;
+}
+
+int some_logmel(SomeHandle* h, const float* audio_dev, const int64_t* sample_offsets_dev,
+                const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, float* units_dev, void* stream) {
+    if (!h) return SOME_EINVAL;
+    if (B < 0 || max_frames < 0) return fail(h, SOME_EINVAL, "some_logmel: negative size");
+    if (B == 0 || max_frames == 0) return SOME_OK;
+    if (!audio_dev || !sample_offsets_dev || !frame_offsets_dev || !units_dev) return fail(h, SOME_EINVAL, "some_logmel: null pointer");
+    if (B > 65535) return fail(h, SOME_EINVAL, "some_logmel: B > 65535");
+    int rc = ensure_mel_tables(h);
+    if (rc != SOME_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(h, s, "logmel", 0.0, 0.0);
+    HIP_TRY(h, launch_logmel(h->mel, audio_dev, sample_offsets_dev, frame_offsets_dev, B, max_frames, units_dev, s));
+    return SOME_OK;
+}
+
+size_t some_workspace_bytes(const SomeHandle* h, int64_t total_frames, int32_t B) {
+    (void)B;
+    if (!h || total_frames <= 0) return 0;
+    const size_t m = (size_t)total_frames;
+    // per stream: X 512 | H 512 | U 2048 | G 512 floats per frame
+    return kStreams * align_up(m * (size_t)(kDim * 3 + kFfn) * sizeof(float), 256) + 1024;
+}
+
+int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_offsets_dev, int32_t B,
+                 int64_t total_frames, int32_t max_frames, const uint8_t* row_mask_dev, int32_t head_mode,
+                 float* midi_dev, float* bound_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    if (!h->arena) return fail(h, SOME_ESTATE, "some_forward: no weights attached (call some_attach_arena first)");
+    if (B < 0 || total_frames < 0) return fail(h, SOME_EINVAL, "some_forward: negative size");
+    if (B == 0 || total_frames == 0) return SOME_OK;
+    if (total_frames > (int64_t)1 << 30) return fail(h, SOME_EINVAL, "some_forward: total_frames too large");
+    if (!units_dev || !frame_offsets_dev || !midi_dev || !bound_dev || !workspace_dev) return fail(h, SOME_EINVAL, "some_forward: null pointer");
+    if (head_mode < 0 || head_mode > 2) return fail(h, SOME_EINVAL, "some_forward: bad head_mode");
+    if (workspace_bytes < some_workspace_bytes(h, total_frames, B)) return fail(h, SOME_ENOMEM, "some_forward: workspace too small");
+    if (reinterpret_cast<uintptr_t>(workspace_dev) & 255) return fail(h, SOME_EINVAL, "some_forward: workspace must be 256-byte aligned");
+    if ((size_t)B * kHeads * kStreams > 0x7fffffffu / 64) return fail(h, SOME_EINVAL, "some_forward: B too large");
+
+    const SomeConfig& c = h->cfg;
+    const ArenaLayout& L = h->lay;
+    const float* W = h->arena;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int M = (int)total_frames;
+    const size_t m = (size_t)M;
+    const size_t per_stream = align_up(m * (size_t)(kDim * 3 + kFfn) * sizeof(float), 256) / sizeof(float);
+    float* ws = static_cast<float*>(workspace_dev);
+    float *X[2], *H[2], *U[2], *G[2];
+    for (int g = 0; g < kStreams; ++g) {
+        float* base = ws + g * per_stream;
+        X[g] = base; H[g] = X[g] + m * kDim; G[g] = H[g] + m * kDim; U[g] = G[g] + m * kDim;
+    }
+    const double Md = (double)M;
+    double sumT2 = 0.0;
+    if (h->profiling) {   // measurement only: exact attention FLOPs need the per-clip lengths
+        std::vector<int32_t> off((size_t)B + 1);
+        HIP_TRY(h, hipMemcpy(off.data(), frame_offsets_dev, off.size() * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) { const double t = off[b + 1] - off[b]; sumT2 += t * t; }
+    }
+
+    auto gemm = [&](const char* name, GemmEpi epi, GemmArgs& a, int n_out_total) -> int {
+        a.groups = kStreams; a.M = M;
+        const double flops = 2.0 * Md * a.K * n_out_total;
+        Scope sc(h, s, name, flops, 0.0);
+        hipError_t e = launch_gemm(epi, a, s);
+        if (e != hipSuccess) return fail_hip(h, e, name);
+        return SOME_OK;
+    };
+    auto ln = [&](int layer, int idx, float* const* src, float* const* dst) -> int {
+        LnArgs a{};
+        for (int g = 0; g < kStreams; ++g) {
+            const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
+            a.x[g] = src[g]; a.y[g] = dst[g]; a.gamma[g] = W + b.ln_g[idx]; a.beta[g] = W + b.ln_b[idx];
+        }
+        a.groups = kStreams; a.M = M;
+        Scope sc(h, s, "layernorm", 0.0, 2.0 * kStreams * Md * kDim * 4);
+        hipError_t e = launch_layernorm(a, s);
+        if (e != hipSuccess) return fail_hip(h, e, "layernorm");
+        return SOME_OK;
+    };
+    auto ffn = [&](int layer, int f) -> int {
+        GemmArgs a{};
+        for (int g = 0; g < kStreams; ++g) {
+            const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
+            a.g[g] = GemmGroup{H[g], W + b.ffn_w1[f], W + b.ffn_b1[f], nullptr, U[g], nullptr, kFfn, 0};
+        }
+        a.K = kDim; a.lda = kDim; a.ldc = kFfn;
+        int rc = gemm("gemm_bias_silu[512->2048]", EPI_BIAS_SILU, a, kStreams * kFfn);
+        if (rc) return rc;
+        GemmArgs d{};
+        for (int g = 0; g < kStreams; ++g) {
+            const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
+            d.g[g] = GemmGroup{U[g], W + b.ffn_w2[f], W + b.ffn_b2[f], X[g], X[g], nullptr, kDim, 0};
+        }
+        d.K = kFfn; d.lda = kFfn; d.ldc = kDim; d.ldr = kDim; d.alpha = 0.5f;
+        return gemm("gemm_bias_res[2048->512]", EPI_BIAS_RES, d, kStreams * kDim);
+    };
+
+    int rc;
+    {   // Gconform.py:124-127: the two input projections (+ masked_fill on the midi stream)
+        GemmArgs a{};
+        for (int g = 0; g < kStreams; ++g)
+            a.g[g] = GemmGroup{units_dev, W + L.in_w[g], W + L.in_b[g], nullptr, X[g], g == 0 ? row_mask_dev : nullptr, kDim, 0};
+        a.K = c.indim; a.lda = c.indim; a.ldc = kDim;
+        if ((rc = gemm("gemm_bias[in->512]", EPI_BIAS, a, kStreams * kDim))) return rc;
+    }
+    for (int layer = 0; layer <= c.lay; ++layer) {
+        // ---- conform_blocke.forward (Gconform.py:56-63), both streams per launch
+        if ((rc = ln(layer, 0, X, H))) return rc;
+        if ((rc = ffn(layer, 0))) return rc;
+        if ((rc = ln(layer, 1, X, H))) return rc;
+        {
+            GemmArgs a{};
+            for (int g = 0; g < kStreams; ++g)
+                a.g[g] = GemmGroup{H[g], W + L.blocks[(size_t)layer * 2 + g].wqkv, nullptr, nullptr, U[g], nullptr, 3 * kDim, 0};
+            a.K = kDim; a.lda = kDim; a.ldc = 3 * kDim;
+            if ((rc = gemm("gemm[512->1536 qkv]", EPI_NONE, a, kStreams * 3 * kDim))) return rc;
+        }
+        {
+            AttnArgs a{};
+            for (int g = 0; g < kStreams; ++g) { a.qkv[g] = U[g]; a.out[g] = H[g]; }
+            a.frame_offsets = frame_offsets_dev; a.groups = kStreams; a.B = B; a.max_frames = max_frames;
+            Scope sc(h, s, "attention", 4.0 * kHeadDim * kHeads * kStreams * sumT2, 0.0);
+            HIP_TRY(h, launch_attention(a, s));
+        }
+        {
+            GemmArgs a{};
+            for (int g = 0; g < kStreams; ++g) {
+                const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
+                a.g[g] = GemmGroup{H[g], W + b.wo, W + b.bo, X[g], X[g], nullptr, kDim, 0};
+            }
+            a.K = kDim; a.lda = kDim; a.ldc = kDim; a.ldr = kDim; a.alpha = 1.0f;
+            if ((rc = gemm("gemm_bias_res[512->512]", EPI_BIAS_RES, a, kStreams * kDim))) return rc;
+        }
+        if ((rc = ln(layer, 2, X, H))) return rc;
+        {
+            GemmArgs a{};
+            for (int g = 0; g < kStreams; ++g) {
+                const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
+                a.g[g] = GemmGroup{H[g], W + b.pw1_w, W + b.pw1_b, nullptr, G[g], nullptr, 2 * kDim, 0};
+            }
+            a.K = kDim; a.lda = kDim; a.ldc = kDim;
+            if ((rc = gemm("gemm_glu[512->2x512]", EPI_GLU, a, kStreams * 2 * kDim))) return rc;
+        }
+        {
+            DwArgs a{};
+            for (int g = 0; g < kStreams; ++g) {
+                const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
+                a.x[g] = G[g]; a.y[g] = H[g]; a.w[g] = W + b.dw_w; a.b[g] = W + b.dw_b;
+            }
+            a.frame_offsets = frame_offsets_dev; a.groups = kStreams; a.B = B; a.max_frames = max_frames;
+            Scope sc(h, s, "dwconv_bn_silu", 0.0, 2.0 * kStreams * Md * kDim * 4);
+            HIP_TRY(h, launch_dwconv(a, s));
+        }
+        {
+            GemmArgs a{};
+            for (int g = 0; g < kStreams; ++g) {
+                const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
+                a.g[g] = GemmGroup{H[g], W + b.pw2_w, W + b.pw2_b, X[g], X[g], nullptr, kDim, 0};
+            }
+            a.K = kDim; a.lda = kDim; a.ldc = kDim; a.ldr = kDim; a.alpha = 1.0f;
+            if ((rc = gemm("gemm_bias_res[512->512]", EPI_BIAS_RES, a, kStreams * kDim))) return rc;
+        }
+        if ((rc = ln(layer, 3, X, H))) return rc;
+        if ((rc = ffn(layer, 1))) return rc;
+        if ((rc = ln(layer, 4, X, H))) return rc;      // block output y = H
+        if (layer < c.lay) {
+            // Gcf.forward (Gconform.py:82-87): midi' = y0 + GLU(glu2(y1)), bound' = y1 + GLU(glu1(y0));
+            // then masked_fill on the midi stream (Gconform.py:131-132)
+            GemmArgs a{};
+            a.g[0] = GemmGroup{H[1], W + L.glu_w[(size_t)layer * 2 + 1], W + L.glu_b[(size_t)layer * 2 + 1], H[0], X[0], row_mask_dev, 2 * kDim, 0};
+            a.g[1] = GemmGroup{H[0], W + L.glu_w[(size_t)layer * 2 + 0], W + L.glu_b[(size_t)layer * 2 + 0], H[1], X[1], nullptr, 2 * kDim, 0};
+            a.K = kDim; a.lda = kDim; a.ldc = kDim; a.ldr = kDim;
+            if ((rc = gemm("gemm_glu_res[512->2x512 gate]", EPI_GLU_RES, a, kStreams * 2 * kDim))) return rc;
+        }
+    }
+    {   // heads (Gconform.py:135-138, Gmidi_conform.py:33-37)
+        GemmArgs a{};
+        a.g[0] = GemmGroup{H[0], W + L.out_w, W + L.out_b, nullptr, midi_dev, nullptr, c.outdim, head_mode == SOME_HEAD_SIGMOID ? 1 : 0};
+        a.g[1] = GemmGroup{H[1], W + L.cut_w, W + L.cut_b, nullptr, bound_dev, nullptr, 1, 1};
+        a.K = kDim; a.lda = kDim; a.ldc = 0;   // per-group ldc below
+        // the two heads have different widths: run them as two launches of one group each
+        GemmArgs a0 = a; a0.g[0] = a.g[0]; a0.groups = 1; a0.M = M; a0.ldc = c.outdim;
+        {
+            Scope sc(h, s, "gemm_bias[512->outdim]", 2.0 * Md * kDim * c.outdim, 0.0);
+            HIP_TRY(h, launch_gemm(EPI_BIAS, a0, s));
+        }
+        GemmArgs a1 = a; a1.g[0] = a.g[1]; a1.groups = 1; a1.M = M; a1.ldc = 1;
+        {
+            Scope sc(h, s, "gemm_bias[512->1]", 2.0 * Md * kDim, 0.0);
+            HIP_TRY(h, launch_gemm(EPI_BIAS, a1, s));
+        }
+        if (head_mode == SOME_HEAD_SOFTMAX) {
+            Scope sc(h, s, "row_softmax", 0.0, 2.0 * Md * c.outdim * 4);
+            HIP_TRY(h, launch_row_softmax(midi_dev, M, c.outdim, s));
+        }
+    }
+    return SOME_OK;
+}
+
+size_t some_decode_scratch_bytes(const SomeHandle* h, int64_t total_frames) {
+    if (!h || total_frames <= 0) return 0;
+    return decode_scratch_bytes(total_frames);
+}
+
+int some_decode(SomeHandle* h, const float* probs_dev, const float* bounds_dev, const uint8_t* row_mask_dev,
+                const int32_t* frame_offsets_dev, int32_t B, int64_t total_frames, int32_t quantized,
+                float* note_midi_dev, int64_t* note_dur_dev, uint8_t* note_rest_dev, int32_t* n_notes_dev,
+                int64_t* frame2item_dev, float* values_dev, uint8_t* rest_dev,
+                void* scratch_dev, size_t scratch_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    if (B < 0 || total_frames < 0) return fail(h, SOME_EINVAL, "some_decode: negative size");
+    if (B == 0 || total_frames == 0) return SOME_OK;
+    if (!probs_dev || !bounds_dev || !frame_offsets_dev || !note_midi_dev || !note_dur_dev || !note_rest_dev ||
+        !n_notes_dev || !scratch_dev)
+        return fail(h, SOME_EINVAL, "some_decode: null pointer");
+    if (scratch_bytes < decode_scratch_bytes(total_frames)) return fail(h, SOME_ENOMEM, "some_decode: scratch too small");
+    if (quantized && h->cfg.outdim != 129) return fail(h, SOME_EINVAL, "some_decode: quantized decode expects 129 bins (rest = 128)");
+    DecodeArgs a{};
+    a.probs = probs_dev; a.bounds = bounds_dev; a.mask = row_mask_dev; a.frame_offsets = frame_offsets_dev;
+    a.B = B; a.total_frames = total_frames; a.nbins = h->cfg.outdim; a.quantized = quantized ? 1 : 0;
+    a.vmin = h->cfg.midi_min; a.vmax = h->cfg.midi_max; a.deviation = h->cfg.midi_deviation; a.threshold = h->cfg.rest_threshold;
+    a.note_midi = note_midi_dev; a.note_dur = note_dur_dev; a.note_rest = note_rest_dev; a.n_notes = n_notes_dev;
+    a.frame2item = frame2item_dev; a.values = values_dev; a.rest = rest_dev; a.scratch = scratch_dev;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(h, s, "decode", 0.0, (double)total_frames * (4.0 * (h->cfg.outdim + 1) + 13.0));
+    HIP_TRY(h, launch_decode(a, s));
+    return SOME_OK;
+}
+
+int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t lda, const float* W_dev,
+                 const float* bias_dev, const float* res_dev, int32_t ldr, float* C_dev, int32_t ldc,
+                 int32_t M, int32_t N, int32_t K, float alpha, int32_t act, const uint8_t* row_mask_dev, void* stream) {
+    if (!h) return SOME_EINVAL;
+    if (epilogue < 0 || epilogue > 5 || M < 0 || N <= 0 || K <= 0 || !A_dev || !W_dev || !C_dev)
+        return fail(h, SOME_EINVAL, "some_op_gemm: bad argument");
+    if (epilogue != EPI_NONE && !bias_dev) return fail(h, SOME_EINVAL, "some_op_gemm: epilogue needs a bias");
+    if ((epilogue == EPI_BIAS_RES || epilogue == EPI_GLU_RES) && !res_dev) return fail(h, SOME_EINVAL, "some_op_gemm: epilogue needs a residual");
+    if ((epilogue == EPI_GLU || epilogue == EPI_GLU_RES) && (N % 64)) return fail(h, SOME_EINVAL, "some_op_gemm: GLU epilogue needs N % 64 == 0");
+    GemmArgs a{};
+    a.g[0] = GemmGroup{A_dev, W_dev, bias_dev, res_dev, C_dev, row_mask_dev, N, act};
+    a.groups = 1; a.M = M; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.alpha = alpha;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(h, s, "op_gemm", 2.0 * M * (double)N * K, 0.0);
+    HIP_TRY(h, launch_gemm(static_cast<GemmEpi>(epilogue), a, s));
+    return SOME_OK;
+}
+
+int some_op_layernorm(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                      float* y_dev, int32_t M, void* stream) {
+    if (!h) return SOME_EINVAL;
+    if (M < 0 || !x_dev || !gamma_dev || !beta_dev || !y_dev) return fail(h, SOME_EINVAL, "some_op_layernorm: bad argument");
+    LnArgs a{};
+    a.x[0] = x_dev; a.y[0] = y_dev; a.gamma[0] = gamma_dev; a.beta[0] = beta_dev; a.groups = 1; a.M = M;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(h, s, "op_layernorm", 0.0, 2.0 * M * kDim * 4.0);
+    HIP_TRY(h, launch_layernorm(a, s));
+    return SOME_OK;
+}
+
+int some_op_attention(SomeHandle* h, const float* qkv_dev, const int32_t* frame_offsets_dev, int32_t B,
+                      int32_t max_frames, float* out_dev, void* stream) {
+    if (!h) return SOME_EINVAL;
+    if (B < 0 || max_frames < 0 || !qkv_dev || !frame_offsets_dev || !out_dev) return fail(h, SOME_EINVAL, "some_op_attention: bad argument");
+    AttnArgs a{};
+    a.qkv[0] = qkv_dev; a.out[0] = out_dev; a.frame_offsets = frame_offsets_dev; a.groups = 1; a.B = B; a.max_frames = max_frames;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(h, s, "op_attention", 0.0, 0.0);
+    HIP_TRY(h, launch_attention(a, s));
+    return SOME_OK;
+}
+
+int some_op_dwconv_silu(SomeHandle* h, const float* x_dev, const float* taps_dev, const float* bias_dev,
+                        const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, float* y_dev, void* stream) {
+    if (!h) return SOME_EINVAL;
+    if (B < 0 || max_frames < 0 || !x_dev || !taps_dev || !bias_dev || !frame_offsets_dev || !y_dev)
+        return fail(h, SOME_EINVAL, "some_op_dwconv_silu: bad argument");
+    DwArgs a{};
+    a.x[0] = x_dev; a.y[0] = y_dev; a.w[0] = taps_dev; a.b[0] = bias_dev;
+    a.frame_offsets = frame_offsets_dev; a.groups = 1; a.B = B; a.max_frames = max_frames;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(h, s, "op_dwconv_silu", 0.0, 0.0);
+    HIP_TRY(h, launch_dwconv(a, s));
+    return SOME_OK;
+}
+
+int some_profile_enable(SomeHandle* h, int32_t on) {
+    if (!h) return SOME_EINVAL;
+    h->profiling = on != 0;
+    return SOME_OK;
+}
+
+int some_profile_collect(SomeHandle* h, SomeKernelStat* stats, int32_t max_stats, int32_t* n_stats) {
+    if (!h || !stats || !n_stats || max_stats < 0) return SOME_EINVAL;
+    std::vector<SomeKernelStat> acc;
+    std::map<std::string, size_t> index;
+    for (auto& r : h->prof) {
+        hipError_t e = hipEventSynchronize(r.e1);
+        if (e != hipSuccess) return fail_hip(h, e, "hipEventSynchronize");
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (e != hipSuccess) return fail_hip(h, e, "hipEventElapsedTime");
+        auto it = index.find(r.name);
+        if (it == index.end()) {
+            SomeKernelStat st{};
+            snprintf(st.name, sizeof st.name, "%s", r.name.c_str());
+            index[r.name] = acc.size();
+            acc.push_back(st);
+            it = index.find(r.name);
+        }
+        SomeKernelStat& st = acc[it->second];
+        st.launches += 1; st.total_ms += ms; st.flops += r.flops; st.bytes += r.bytes;
+        h->event_pool.push_back(r.e0);
+        h->event_pool.push_back(r.e1);
+    }
+    h->prof.clear();
+    const int32_t n = std::min<int32_t>((int32_t)acc.size(), max_stats);
+    for (int32_t i = 0; i < n; ++i) stats[i] = acc[i];
+    *n_stats = n;
+    return SOME_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// Internal declarations shared by the HIP translation units of libsome_amd.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/some_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Compiled shapes (validated in some_create): the reference's configs all use them
+// (configs/midi_conformer.yaml:22-33, configs/base.yaml:11-15).
+constexpr int kDim = 512;
+constexpr int kHeads = 8;
+constexpr int kHeadDim = 64;
+constexpr int kFfn = 2048;
+constexpr int kConvK = 31;
+constexpr int kWin = 2048;
+constexpr int kHop = 512;
+constexpr int kMels = 80;
+constexpr int kStreams = 2;   // 0 = midi stream (att1 / x), 1 = bound stream (att2 / x1)
+
+// ---- GEMM -----------------------------------------------------------------------------------------
+enum GemmEpi { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_SILU = 2, EPI_BIAS_RES = 3, EPI_GLU = 4, EPI_GLU_RES = 5 };
+
+struct GemmGroup {
+    const float* A;        // [M, lda]
+    const float* W;        // [N, K] row-major (K contiguous); GLU epilogues: rows interleaved 32 a / 32 gate
+    const float* bias;     // [N] (same interleave) or nullptr
+    const float* res;      // residual [M, ldr] or nullptr
+    float* C;              // [M, ldc]
+    const uint8_t* mask;   // optional row mask (0 -> output row := 0)
+    int N;                 // number of W rows for this group
+    int act;               // EPI_BIAS only: 0 none, 1 sigmoid
+};
+
+struct GemmArgs {
+    GemmGroup g[kStreams];
+    int groups;
+    int M, K;
+    int lda, ldc, ldr;
+    float alpha;           // EPI_BIAS_RES: C = res + alpha * (acc + bias)
+    int n_tiles;           // filled by launch_gemm
+};
+
+hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
+
+// ---- row ops --------------------------------------------------------------------------------------
+// y[g][m][:] = LayerNorm(x[g][m][:]) * gamma[g] + beta[g], eps 1e-5, rows of 512.
+struct LnArgs {
+    const float* x[kStreams];
+    float* y[kStreams];
+    const float* gamma[kStreams];
+    const float* beta[kStreams];
+    int groups;
+    int M;
+};
+hipError_t launch_layernorm(const LnArgs& a, hipStream_t s);
+// in-place softmax over rows of width n (head_mode SOFTMAX)
+hipError_t launch_row_softmax(float* x, int64_t rows, int n, hipStream_t s);
+
+// ---- attention ------------------------------------------------------------------------------------
+// qkv[g]: [M, 1536] (q | k | v, each 8 heads x 64); out[g]: [M, 512]; per clip, unmasked, scale 1/8.
+struct AttnArgs {
+    const float* qkv[kStreams];
+    float* out[kStreams];
+    const int32_t* frame_offsets;  // device [B+1]
+    int groups, B, max_frames;
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+// ---- depthwise conv + folded BN + SiLU ------------------------------------------------------------
+struct DwArgs {
+    const float* x[kStreams];      // [M, 512] (GLU output)
+    float* y[kStreams];            // [M, 512]
+    const float* w[kStreams];      // [31, 512] folded
+    const float* b[kStreams];      // [512] folded
+    const int32_t* frame_offsets;
+    int groups, B, max_frames;
+};
+hipError_t launch_dwconv(const DwArgs& a, hipStream_t s);
+
+// ---- front end ------------------------------------------------------------------------------------
+struct LogmelTables {
+    float* window;       // [2048] periodic Hann
+    float* twiddle;      // [1024] complex (cos, -sin)(2*pi*k/1024) interleaved + [1024] post-process table
+    float* mel_w;        // packed non-zero filter weights
+    int32_t* mel_start;  // [80] first bin of each band
+    int32_t* mel_len;    // [80] number of bins
+    int32_t* mel_off;    // [80] offset into mel_w
+    int kmax;            // highest FFT bin any band touches
+};
+hipError_t launch_logmel(const LogmelTables& t, const float* audio, const int64_t* sample_offsets,
+                         const int32_t* frame_offsets, int B, int max_frames, float* units, hipStream_t s);
+
+// ---- decode ---------------------------------------------------------------------------------------
+struct DecodeArgs {
+    const float* probs; const float* bounds; const uint8_t* mask;
+    const int32_t* frame_offsets; int B; int64_t total_frames; int nbins; int quantized;
+    double vmin, vmax, deviation, threshold;
+    float* note_midi; int64_t* note_dur; uint8_t* note_rest; int32_t* n_notes;
+    int64_t* frame2item; float* values; uint8_t* rest;
+    void* scratch;
+};
+size_t decode_scratch_bytes(int64_t total_frames);
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t s);
+
+// ---- profiling ------------------------------------------------------------------------------------
+struct ProfRecord { std::string name; hipEvent_t e0, e1; double flops, bytes; };
+
+// ---- arena layout ---------------------------------------------------------------------------------
+struct BlockOff {           // offsets in floats into the arena
+    size_t ln_g[5], ln_b[5];
+    size_t ffn_w1[2], ffn_b1[2], ffn_w2[2], ffn_b2[2];
+    size_t wqkv, wo, bo;
+    size_t pw1_w, pw1_b, dw_w, dw_b, pw2_w, pw2_b;
+};
+
+struct ArenaLayout {
+    size_t in_w[kStreams], in_b[kStreams];
+    size_t out_w, out_b, cut_w, cut_b;
+    std::vector<BlockOff> blocks;       // index: (layer * 2 + stream), layer == lay -> final att1/att2
+    std::vector<size_t> glu_w, glu_b;   // index: layer * 2 + (0: glu1, 1: glu2)
+    size_t total_floats;
+};
+
+struct SomeHandle {
+    SomeConfig cfg;
+    ArenaLayout lay;
+    const float* arena = nullptr;
+    LogmelTables mel{};
+    void* mel_blob = nullptr;
+    std::string err;
+    bool profiling = false;
+    std::vector<ProfRecord> prof;
+    std::vector<hipEvent_t> event_pool;
+};

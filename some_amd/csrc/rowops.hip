@@ -1,0 +1,103 @@
+// Row-wise HBM-bound kernels: LayerNorm(512) and the head softmax.
+//
+// LayerNorm replaces nn.LayerNorm(dim) x5 per conformer block (modules/conform/Gconform.py:49-53, 56-63;
+// eps 1e-5, biased variance).  One 64-lane wave owns one 512-float row: two coalesced 16-byte loads per
+// lane, two wavefront butterfly reductions (mean, then centred second moment - the two-pass form keeps
+// fp32 cancellation out), one coalesced store.  Algorithmic traffic: 4 KiB per row (read + write).
+//
+// Softmax replaces F.softmax(midi, dim=2) (modules/model/Gmidi_conform.py:36-37) on the [M, outdim] head.
+#include "internal.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave_in_grid = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * 256) >> 6;
+    const int g = blockIdx.y;
+    const float* __restrict__ x = a.x[g];
+    float* __restrict__ y = a.y[g];
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.gamma[g] + lane * 4);
+    const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.gamma[g] + 256 + lane * 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.beta[g] + lane * 4);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.beta[g] + 256 + lane * 4);
+    for (int m = wave_in_grid; m < a.M; m += n_waves) {
+        const float* row = x + (size_t)m * kDim;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(row + lane * 4);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 256 + lane * 4);
+        float s = (v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3]);
+        const float mean = wave_sum(s) * (1.0f / kDim);
+        v0 -= mean;
+        v1 -= mean;
+        float q = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]) +
+                  (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
+        const float var = wave_sum(q) * (1.0f / kDim);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        f32x4 o0 = v0 * rstd * g0 + b0;
+        f32x4 o1 = v1 * rstd * g1 + b1;
+        float* out = y + (size_t)m * kDim;
+        *reinterpret_cast<f32x4*>(out + lane * 4) = o0;
+        *reinterpret_cast<f32x4*>(out + 256 + lane * 4) = o1;
+    }
+}
+
+// one wave per row, n <= 256 (129 in the reference's quantised config)
+__global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ x, int64_t rows, int n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_in_grid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t m = wave_in_grid; m < rows; m += n_waves) {
+        float* row = x + m * n;
+        float v[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < n ? row[c] : -INFINITY;
+            mx = fmaxf(mx, v[i]);
+        }
+        mx = wave_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = expf(v[i] - mx);
+            s += v[i];
+        }
+        s = wave_sum(s);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            if (c < n) row[c] = v[i] / s;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_layernorm(const LnArgs& a, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    int blocks = (a.M + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(blocks, a.groups), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_softmax(float* x, int64_t rows, int n, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (n > 256) return hipErrorInvalidValue;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(row_softmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, rows, n);
+    return hipGetLastError();
+}

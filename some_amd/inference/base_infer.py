@@ -1,0 +1,59 @@
+"""``BaseInference`` - constructor, attributes and method names of reference inference/base_infer.py:13-53."""
+import pathlib
+from collections import OrderedDict
+from typing import Dict, List
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..utils import build_object_from_class_name
+
+
+class BaseInference:
+    def __init__(self, config: dict, model_path: pathlib.Path, device=None):
+        if device is None:
+            device = 'cuda' if torch.cuda.is_available() else 'cpu'    # base_infer.py:15-16
+        if torch.device(device).type != 'cuda':
+            raise RuntimeError(
+                "some_amd needs an AMD GPU (PyTorch-ROCm device 'cuda'); got device "
+                f"'{device}'. The hot path has no CPU fallback - use the reference implementation on CPU.")
+        self.config = config
+        self.model_path = model_path
+        self.device = device
+        self.timestep = self.config['hop_size'] / self.config['audio_sample_rate']
+        self.model: torch.nn.Module = self.build_model()
+
+    def build_model(self) -> nn.Module:
+        """base_infer.py:23-35: build ``model_cls``, load ``ckpt['state_dict']`` entries under ``model.``,
+        strict."""
+        model: nn.Module = build_object_from_class_name(
+            self.config['model_cls'], nn.Module, config=self.config
+        ).eval().to(self.device)
+        state_dict = torch.load(self.model_path, map_location='cpu')['state_dict']
+        prefix_in_ckpt = 'model'
+        state_dict = OrderedDict({
+            k[len(prefix_in_ckpt) + 1:]: v
+            for k, v in state_dict.items() if k.startswith(f'{prefix_in_ckpt}.')
+        })
+        model.load_state_dict(state_dict, strict=True)
+        print(f'| load \'{prefix_in_ckpt}\' from \'{self.model_path}\'.')
+        return model
+
+    def preprocess(self, waveform: np.ndarray) -> Dict[str, torch.Tensor]:
+        raise NotImplementedError()
+
+    def forward_model(self, sample: Dict[str, torch.Tensor]):
+        raise NotImplementedError()
+
+    def postprocess(self, results: Dict[str, torch.Tensor]) -> List[Dict[str, np.ndarray]]:
+        raise NotImplementedError()
+
+    def infer(self, waveforms: List[np.ndarray]) -> List[Dict[str, np.ndarray]]:
+        """Reference semantics (base_infer.py:46-53): one result dict per waveform, each processed on its own.
+        Subclasses batch the clips on the device; the per-clip results are identical because every kernel
+        treats the clips of a packed batch independently."""
+        results = []
+        for w in waveforms:
+            results.append(self.postprocess(self.forward_model(self.preprocess(w))))
+        return results
