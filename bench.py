@@ -46,6 +46,7 @@ def main():
     ap.add_argument('--lay', type=int, default=None, help='override lay (debug only; invalidates the metric)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--no-latency', action='store_true', help='skip the B=1 p50 latency leg')
     ap.add_argument('--cpu-clips', type=int, default=2, help='clips in the bounded CPU-baseline sample')
     args = ap.parse_args()
 
@@ -171,7 +172,7 @@ def main():
         one = ClipBatch.from_sample_counts([len(clips[0])], eng.hop, device)
         a1 = torch.from_numpy(clips[0]).to(device)
         lat = []
-        for i in range(8):
+        for i in range(0 if args.no_latency else 8):
             torch.cuda.synchronize(device)
             t1 = time.perf_counter()
             u = eng.logmel(a1, one)
@@ -179,7 +180,8 @@ def main():
             eng.decode(p, b, one, quantized=quant)
             torch.cuda.synchronize(device)
             lat.append(time.perf_counter() - t1)
-        result['p50_clip_latency_ms'] = round(1e3 * float(np.median(lat[2:])), 3)
+        if lat:
+            result['p50_clip_latency_ms'] = round(1e3 * float(np.median(lat[2:])), 3)
 
         # ---- CPU baseline: the oracle (port of the reference CPU path), bounded sample, rank 0, N = 1 ---
         if world == 1 and not args.no_cpu_baseline:

@@ -75,6 +75,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: libsome_amd.so must bind to the SAME HIP runtime (libamdhip64.so.7) that PyTorch-ROCm
+    # bundles and initialises, because every device pointer it receives comes from torch's allocator.  A
+    # process that dlopens the library before torch would pull in /opt/rocm's copy as a second runtime.
+    import torch  # noqa: F401
     if not LIB_PATH.exists():
         raise RuntimeError(
             f'{LIB_PATH} is missing: the HIP extension has not been built. Run `python -m some_amd.build` '

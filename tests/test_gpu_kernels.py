@@ -67,7 +67,8 @@ def test_gemm_plain_and_bias(eng, M, N, K):
     out = _gemm(eng, _lib.EPI_BIAS, A, W, bias=b)
     assert (out - (ref + b)).abs().max().item() < 2e-6 * scale * max(1, K // 256)
     out = _gemm(eng, _lib.EPI_BIAS, A, W, bias=b, act=1)
-    assert (out - torch.sigmoid(ref + b)).abs().max().item() < 1e-5
+    # |d sigmoid| <= |d x| / 4
+    assert (out - torch.sigmoid(ref + b)).abs().max().item() < 0.25 * 2e-6 * scale * max(1, K // 256) + 2e-6
 
 
 def test_gemm_epilogues(eng):
