@@ -1,0 +1,127 @@
+#!/usr/bin/env python
+"""``python batch_infer.py --dataset DIR --model CKPT [--round_midi] [--csv OUT] [--overwrite]`` - the
+reference's DiffSinger-dataset command (batch_infer.py:137-226) on the HIP hot path.
+
+Single process: same behaviour as the reference, but the chunks of MANY rows are packed into each device batch.
+Multi-GPU: launch with ``python -m torch.distributed.run --nproc-per-node 8 batch_infer.py ...``; rows are
+sharded across the ranks (largest first, round-robin), rank 0 packs the weights and broadcasts them once with
+RCCL, every rank works on its own rows with no cross-GPU dependence, rank 0 gathers and writes the CSV."""
+import pathlib
+from concurrent.futures import ThreadPoolExecutor
+from csv import DictReader, DictWriter
+from typing import Dict, List
+
+import click
+
+from infer import load_inference
+from some_amd import batch_logic, sharding
+from some_amd.utils.audio import load_wav
+from utils.slicer2 import Slicer
+
+CSV_FIELDS = ['name', 'ph_seq', 'ph_dur', 'ph_num', 'note_seq', 'note_dur']
+
+
+def model_init(model_path):
+    """batch_infer.py:21-34."""
+    return load_inference(pathlib.Path(model_path))
+
+
+def load_and_slice(audio_path, config):
+    """batch_infer.py:50-53 (host side of one row): decode + silence slicing."""
+    waveform, _ = load_wav(audio_path, sr=config['audio_sample_rate'], mono=True)
+    return Slicer(sr=config['audio_sample_rate'], max_sil_kept=1000).slice(waveform)
+
+
+def infer(wav, infer_ins, config):
+    """batch_infer.py:49-81 for one file: absolute-time note list."""
+    chunks = load_and_slice(pathlib.Path(wav), config)
+    midis = infer_ins.infer([c['waveform'] for c in chunks])
+    return batch_logic.notes_from_segments([c['offset'] for c in chunks], midis)
+
+
+def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, infer_ins, config,
+                 round_midi: bool, max_batch_frames: int = 131072, io_threads: int = 8) -> Dict[int, tuple]:
+    """Rows ``indices`` of the CSV -> {row index: (note_seq, note_dur)}.  WAV decode + slicing run in a thread
+    pool ahead of the GPU; chunks of consecutive rows share packed device batches."""
+    hop = config['hop_size']
+    out: Dict[int, tuple] = {}
+    jobs = []
+    for i in indices:
+        audio_path = data_path / 'wavs' / f"{rows[i]['name']}.wav"
+        if not audio_path.exists():
+            print(f'WARNING: audio file does not exist: \'{audio_path}\'')          # batch_infer.py:166-168
+            continue
+        jobs.append((i, audio_path))
+
+    def flush(group):
+        waves = [c['waveform'] for _, chunks in group for c in chunks]
+        results = infer_ins.infer(waves)
+        pos = 0
+        for i, chunks in group:
+            segs = results[pos:pos + len(chunks)]
+            pos += len(chunks)
+            notes = batch_logic.notes_from_segments([c['offset'] for c in chunks], segs)
+            out[i] = batch_logic.align_row(notes, rows[i]['ph_dur'], rows[i]['ph_num'], round_midi)
+
+    with ThreadPoolExecutor(max_workers=io_threads) as pool:
+        futures = [(i, pool.submit(load_and_slice, p, config)) for i, p in jobs]
+        group, frames = [], 0
+        for i, fut in futures:
+            chunks = fut.result()
+            t = sum(1 + c['waveform'].shape[-1] // hop for c in chunks)
+            if group and frames + t > max_batch_frames:
+                flush(group)
+                group, frames = [], 0
+            group.append((i, chunks))
+            frames += t
+        if group:
+            flush(group)
+    return out
+
+
+@click.command(help='Batch inference on existing DiffSinger dataset.')
+@click.option(
+    '--dataset', required=True, metavar='RAW_DATA_DIR',
+    help='Path to the dataset directory. Equivalent to \'raw_data_dir\' in DiffSinger configuration files.'
+)
+@click.option('--model', required=True, metavar='CKPT_PATH', help='Path to the model checkpoint (*.ckpt)')
+@click.option('--round_midi', is_flag=True, help='Round MIDI values to integers')
+@click.option(
+    '--csv', required=False, metavar='CSV_PATH',
+    help='Path to the output transcriptions.csv file (default to the same file in the dataset)'
+)
+@click.option('--overwrite', is_flag=True, help='Overwrite the existing transcriptions.csv file')
+def batch_infer(dataset, model, round_midi, csv, overwrite):
+    data_path = pathlib.Path(dataset)
+    model_path = pathlib.Path(model)
+    csv_path = pathlib.Path(csv) if csv is not None else data_path / 'transcriptions.csv'
+    if csv_path.exists() and not overwrite:
+        raise FileExistsError(f'The CSV path \'{csv_path}\' already exists. Please re-try with --overwrite option.')
+    dist = sharding.init_distributed()
+    rank, _, world = sharding.dist_env()
+    infer_ins, config = model_init(model_path)
+
+    with open(data_path / 'transcriptions.csv', 'r', encoding='utf8', newline='') as f:
+        csv_data: List[dict] = list(DictReader(f))
+
+    sizes = []
+    for row in csv_data:
+        p = data_path / 'wavs' / f"{row['name']}.wav"
+        sizes.append(p.stat().st_size if p.exists() else 0)
+    mine = sorted(sharding.partition(sizes, rank, world))
+    done = process_rows(csv_data, mine, data_path, infer_ins, config, round_midi)
+    merged = sharding.gather_to_rank0(sorted(done.items()))
+    if rank == 0:
+        for i, (seq, dur) in merged:
+            csv_data[i]['note_seq'], csv_data[i]['note_dur'] = seq, dur
+        with open(csv_path, 'w', encoding='utf8', newline='') as f:
+            writer = DictWriter(f, fieldnames=CSV_FIELDS)
+            writer.writeheader()
+            writer.writerows(csv_data)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    batch_infer()

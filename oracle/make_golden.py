@@ -292,6 +292,32 @@ def gen_batch_infer_fns():
     print('batch_infer_fns.json')
 
 
+def gen_batch_csv():
+    """The reference's whole batch_infer command (batch_infer.py:149-226) on a miniature dataset, with the
+    model replaced by tests/dataset_util.FakeInference and librosa.load by a WAV reader: pins the CSV text."""
+    import tempfile
+    sys.path.append(str(REPO / 'tests'))
+    import dataset_util
+    from some_amd.utils.audio import load_wav
+    for name in ('inference', 'utils', 'utils.config_utils', 'utils.slicer2'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules['inference'].BaseInference = object
+    sys.modules['utils.config_utils'].print_config = lambda c: None
+    sys.modules['utils.slicer2'].Slicer = ref_slicer2.Slicer
+    librosa.load = lambda path, sr, mono: load_wav(path, sr=sr, mono=mono)
+    bi = _load_file('ref_batch_infer2', REF / 'batch_infer.py')
+    cfg = get_config('midi_conformer')
+    bi.model_init = lambda p: (dataset_util.FakeInference(), cfg)
+    with tempfile.TemporaryDirectory() as d:
+        d = pathlib.Path(d)
+        dataset_util.build_dataset(d)
+        for tag, rm in (('round', True), ('full', False)):
+            out = d / f'out_{tag}.csv'
+            bi.batch_infer.callback(dataset=str(d), model=str(d / 'm.ckpt'), round_midi=rm, csv=str(out), overwrite=True)
+            (OUT / f'batch_csv_{tag}.csv').write_bytes(out.read_bytes())
+    print('batch_csv_*.csv')
+
+
 def gen_e2e():
     """waveform -> notes through the reference's own front end, model and decoder (B=1, CPU)."""
     out = {}
@@ -336,4 +362,5 @@ if __name__ == '__main__':
     gen_slicer()
     gen_midi_msgs()
     gen_batch_infer_fns()
+    gen_batch_csv()
     gen_e2e()

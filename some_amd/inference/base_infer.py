@@ -30,15 +30,29 @@ class BaseInference:
         model: nn.Module = build_object_from_class_name(
             self.config['model_cls'], nn.Module, config=self.config
         ).eval().to(self.device)
-        state_dict = torch.load(self.model_path, map_location='cpu')['state_dict']
         prefix_in_ckpt = 'model'
-        state_dict = OrderedDict({
+        import torch.distributed as dist
+        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if sharded and hasattr(model, 'load_packed_arena'):
+            # one process per GPU: rank 0 reads + packs the checkpoint, then ONE broadcast of the flat fp32
+            # arena (RCCL over xGMI); the other ranks never touch the file
+            arena = torch.empty(model.engine.arena_numel, dtype=torch.float32, device=self.device)
+            if dist.get_rank() == 0:
+                arena.copy_(model.engine.pack_state_dict(self._read_state_dict(prefix_in_ckpt)))
+            dist.broadcast(arena, src=0)
+            model.load_packed_arena(arena)
+        else:
+            model.load_state_dict(self._read_state_dict(prefix_in_ckpt), strict=True)
+        if not sharded or dist.get_rank() == 0:
+            print(f'| load \'{prefix_in_ckpt}\' from \'{self.model_path}\'.')
+        return model
+
+    def _read_state_dict(self, prefix_in_ckpt: str):
+        state_dict = torch.load(self.model_path, map_location='cpu')['state_dict']
+        return OrderedDict({
             k[len(prefix_in_ckpt) + 1:]: v
             for k, v in state_dict.items() if k.startswith(f'{prefix_in_ckpt}.')
         })
-        model.load_state_dict(state_dict, strict=True)
-        print(f'| load \'{prefix_in_ckpt}\' from \'{self.model_path}\'.')
-        return model
 
     def preprocess(self, waveform: np.ndarray) -> Dict[str, torch.Tensor]:
         raise NotImplementedError()

@@ -56,6 +56,12 @@ class midi_conforms(nn.Module):
             self._ensure_engine().attach_arena(self._host_arena.to(self._device))
         return torch.nn.modules.module._IncompatibleKeys([], [])
 
+    def load_packed_arena(self, arena_dev: torch.Tensor):
+        """Attach an already packed device arena (what the sharded path receives from the rank-0 broadcast)."""
+        self._host_arena = None
+        self._device = arena_dev.device
+        self._ensure_engine().attach_arena(arena_dev)
+
     # ---- the operator ------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, x, f0=None, mask=None, softmax=False, sig=False):

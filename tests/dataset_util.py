@@ -1,0 +1,60 @@
+"""Deterministic miniature DiffSinger-style dataset + a deterministic fake inference object.  Shared by
+oracle/make_golden.py (which drives the REFERENCE's batch_infer.py with it) and the tests (which drive ours),
+so that the CSV text can be compared byte for byte without a GPU."""
+import csv
+import pathlib
+
+import numpy as np
+
+from some_amd import synth
+from some_amd.utils.audio import save_wav
+
+HOP, SR = 512, 44100
+
+
+class FakeInference:
+    """``infer(waveforms)`` -> canned note dicts that depend only on each waveform's length."""
+    timestep = HOP / SR
+
+    def infer(self, waveforms):
+        out = []
+        for w in waveforms:
+            t = 1 + int(w.shape[-1]) // HOP
+            rng = np.random.default_rng(t)
+            durs = []
+            left = t
+            while left > 0:
+                d = int(min(left, rng.integers(3, 60)))
+                durs.append(d)
+                left -= d
+            n = len(durs)
+            out.append({
+                'note_midi': rng.uniform(45, 80, n).astype(np.float32),
+                'note_dur': np.asarray(durs, dtype=np.int64) * self.timestep,
+                'note_rest': rng.uniform(0, 1, n) < 0.2,
+            })
+        return out
+
+
+def build_dataset(root: pathlib.Path, n_rows: int = 5, extra_missing_row: bool = True):
+    """wavs/clip_XX.wav (int16 PCM, with silences so the Slicer cuts) + transcriptions.csv."""
+    (root / 'wavs').mkdir(parents=True, exist_ok=True)
+    rows = []
+    for i in range(n_rows):
+        secs = 6.0 + 2.5 * i
+        y = synth.synth_clip(200 + i, secs, SR, silence_every=3.1 + 0.7 * i)
+        save_wav(root / 'wavs' / f'clip_{i:02d}.wav', y, SR)
+        rng = np.random.default_rng(300 + i)
+        n_words = int(rng.integers(5, 11))
+        ph_num = rng.integers(1, 4, n_words)
+        raw = rng.uniform(0.2, 1.0, int(ph_num.sum()))
+        ph_dur = raw / raw.sum() * (secs - 0.3)
+        rows.append({'name': f'clip_{i:02d}', 'ph_seq': ' '.join(['a'] * int(ph_num.sum())),
+                     'ph_dur': ' '.join(f'{x:.6f}' for x in ph_dur), 'ph_num': ' '.join(str(int(x)) for x in ph_num)})
+    if extra_missing_row:
+        rows.insert(2, {'name': 'missing_clip', 'ph_seq': 'a b', 'ph_dur': '0.5 0.5', 'ph_num': '2'})
+    with open(root / 'transcriptions.csv', 'w', encoding='utf8', newline='') as f:
+        w = csv.DictWriter(f, fieldnames=['name', 'ph_seq', 'ph_dur', 'ph_num'])
+        w.writeheader()
+        w.writerows(rows)
+    return rows

@@ -1,0 +1,73 @@
+"""The C-ABI shared library loads and exports every symbol include/some_amd.h declares; host-only entry
+points (weight packing, mel basis, argument validation) behave.  No compute calls: runs without a GPU."""
+import ctypes as C
+import pathlib
+import re
+
+import numpy as np
+import pytest
+
+from some_amd import _lib, synth
+from some_amd.configs import get_config
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    header = (ROOT / 'include' / 'some_amd.h').read_text()
+    declared = set(re.findall(r'\b(some_[a-z_0-9]+)\s*\(', header))
+    lib = _lib.load()
+    assert declared, 'no declarations parsed'
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} declared in include/some_amd.h but not exported'
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    assert b'gfx950' in lib.some_version()
+
+
+def test_create_validates_configuration():
+    lib = _lib.load()
+    from some_amd.engine import make_some_config
+    cfg = get_config('midi_conformer')
+    cfg['midi_extractor_args']['dim'] = 256
+    h = C.c_void_p()
+    rc = lib.some_create(C.byref(make_some_config(cfg)), C.byref(h))
+    assert rc == _lib.SOME_EINVAL and b'dim=256' in lib.some_last_error(None)
+
+
+def test_pack_weights_layout_and_strictness():
+    from some_amd.engine import Engine
+    import torch
+    cfg = get_config('midi_conformer', lay=1)
+    eng = Engine(cfg, host_only=True)
+    sd = synth.synth_state_dict(cfg, 3)
+    arena = eng.pack_state_dict(sd).numpy()
+    assert arena.shape[0] == eng.arena_numel
+    # first tensor of the arena is inln.weight verbatim
+    np.testing.assert_array_equal(arena[:512 * 80].reshape(512, 80), sd['model.inln.weight'])
+    total = sum(int(np.prod(v.shape)) for k, v in sd.items() if not k.endswith('num_batches_tracked'))
+    # BN (4 x 512 per block) is folded away; padding only adds zeros
+    assert np.count_nonzero(arena) <= total and np.count_nonzero(arena) >= total - 4 * 4 * 512 - 100
+    # the folded depthwise taps: w' = w * gamma / sqrt(var + eps), stored [31, 512]
+    p = 'model.cf_lay.0.att1.conv.'
+    scale = sd[p + 'norm.weight'].astype(np.float64) / np.sqrt(sd[p + 'norm.running_var'].astype(np.float64) + 1e-5)
+    taps = (sd[p + 'depthwise_conv.weight'][:, 0, :].astype(np.float64) * scale[:, None]).T.astype(np.float32)
+    flat = taps.reshape(-1)
+    idx = np.flatnonzero(arena == flat[0])
+    assert any(np.array_equal(arena[i:i + flat.size], flat) for i in idx)
+    for mutate, pattern in [(lambda d: d.pop('model.att2.norm5.weight'), 'Missing key'),
+                            (lambda d: d.update({'model.bogus': np.zeros(2, np.float32)}), 'Unexpected key'),
+                            (lambda d: d.update({'model.cutheard.weight': np.zeros((2, 512), np.float32)}), 'size mismatch')]:
+        bad = dict(sd)
+        mutate(bad)
+        with pytest.raises(_lib.SomeError, match=pattern):
+            eng.pack_state_dict(bad)
+
+
+def test_forward_requires_weights_and_gpu_pointers():
+    lib = _lib.load()
+    from some_amd.engine import Engine
+    eng = Engine(get_config('midi_conformer', lay=1), host_only=True)
+    rc = lib.some_forward(eng.handle, None, None, 1, 10, 10, None, 0, None, None, None, 0, None)
+    assert rc == _lib.SOME_ESTATE and b'attach' in lib.some_last_error(eng.handle)
+    assert lib.some_workspace_bytes(eng.handle, 1000, 1) >= 2 * 1000 * (512 * 3 + 2048) * 4
+    assert lib.some_decode_scratch_bytes(eng.handle, 1000) >= 1000 * 13

@@ -33,3 +33,90 @@ def test_slicer_matches_reference(golden_dir, name):
     if rms_ref.size:
         rms = get_rms(y=w, frame_length=3528, hop_length=882).squeeze(0)
         np.testing.assert_array_equal(rms.astype(np.float32), rms_ref)   # bit-identical RMS
+
+
+# ---- batch_infer host logic (reference batch_infer.py:37-134) -----------------------------------------
+def test_batch_logic_functions_match_reference(golden_dir):
+    import copy
+    from some_amd import batch_logic as bl
+    g = json.loads((golden_dir / 'batch_infer_fns.json').read_text())
+    for midi, want in g['calc_seq']:
+        assert bl.calc_seq(midi, False) == want
+        assert bl.calc_seq(midi, True) == 'rest'
+    for c in g['cases']:
+        words = bl.get_word_durs(c['ph_dur'], c['ph_num'])
+        assert [list(w) for w in words] == c['words']
+        for n in c['notes']:
+            assert bl.calc_seq(n['_midi'], n['_rest']) == n['note_seq']
+        aligned = bl.midi_align(copy.deepcopy(c['notes']), words)
+        assert aligned == c['aligned']
+        for w, want in zip(words, c['per_word']):
+            assert bl.get_max_overlap_midi(w, aligned) == want['max']
+            got = [s['note_seq'] + '@' + repr(s['start_time']) for s in bl.get_all_overlap_midis(w, aligned)]
+            assert got == want['all']
+
+
+@pytest.mark.parametrize('tag,round_midi', [('round', True), ('full', False)])
+def test_batch_infer_csv_text_matches_reference(golden_dir, tmp_path, tag, round_midi, monkeypatch):
+    """Our batch_infer command with the model stubbed out == the reference's command with the same stub,
+    byte for byte (CSV order, skipped missing wav, rounding, rest filling)."""
+    import batch_infer as bi
+    import dataset_util
+    from some_amd.configs import get_config
+    dataset_util.build_dataset(tmp_path)
+    monkeypatch.setattr(bi, 'model_init', lambda p: (dataset_util.FakeInference(), get_config('midi_conformer')))
+    out = tmp_path / f'out_{tag}.csv'
+    bi.batch_infer.callback(dataset=str(tmp_path), model=str(tmp_path / 'm.ckpt'), round_midi=round_midi, csv=str(out), overwrite=True)
+    assert out.read_bytes() == (golden_dir / f'batch_csv_{tag}.csv').read_bytes()
+    with pytest.raises(FileExistsError):
+        bi.batch_infer.callback(dataset=str(tmp_path), model=str(tmp_path / 'm.ckpt'), round_midi=round_midi, csv=str(out), overwrite=False)
+
+
+def test_midi_file_messages_and_bytes(golden_dir):
+    from some_amd.utils.infer_utils import build_midi_file
+    g = json.loads((golden_dir / 'midi_msgs.json').read_text())
+    for c in g.values():
+        segs = [{'note_midi': np.array(s['note_midi'], np.float32), 'note_dur': np.array(s['note_dur'], np.float64),
+                 'note_rest': np.array(s['note_rest'], bool)} for s in c['segments']]
+        mf = build_midi_file(c['offsets'], segs, tempo=c['tempo'])
+        got = [[m.type, getattr(m, 'note', -1), int(m.time), int(getattr(m, 'tempo', -1))] for m in mf.tracks[0]]
+        assert got == c['messages']
+        raw = mf.to_bytes()
+        assert raw[:14] == b'MThd' + bytes([0, 0, 0, 6, 0, 1, 0, 1, 0x01, 0xE0])       # type 1, 1 track, 480 tpb
+        assert raw[14:18] == b'MTrk' and int.from_bytes(raw[18:22], 'big') == len(raw) - 22
+        assert raw[-3:] == bytes([0xFF, 0x2F, 0x00])                                   # end_of_track
+        assert raw[22:29] == bytes([0x00, 0xFF, 0x51, 0x03]) + int(round(60e6 / c['tempo'])).to_bytes(3, 'big')
+
+
+def test_smf_variable_length_quantity():
+    from some_amd.utils.smf import _vlq
+    assert _vlq(0) == [0] and _vlq(0x7F) == [0x7F] and _vlq(0x80) == [0x81, 0x00]
+    assert _vlq(0x3FFF) == [0xFF, 0x7F] and _vlq(0x4000) == [0x81, 0x80, 0x00] and _vlq(480 * 8) == [0x9E, 0x00]
+
+
+def test_wav_roundtrip_and_rate_check(tmp_path):
+    from some_amd.utils.audio import load_wav, save_wav
+    y = synth.synth_clip(1, 0.2)
+    save_wav(tmp_path / 'a.wav', y, 44100)
+    z, sr = load_wav(tmp_path / 'a.wav', 44100)
+    assert sr == 44100 and z.dtype == np.float32 and np.abs(z - y).max() <= 1 / 32768 + 1e-7
+    with pytest.raises(NotImplementedError):
+        load_wav(tmp_path / 'a.wav', 16000)
+
+
+def test_config_inheritance(tmp_path, monkeypatch):
+    from some_amd.utils.config_utils import read_full_config
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / 'configs').mkdir()
+    (tmp_path / 'configs/base.yaml').write_text('a: 1\nargs: {x: 1, y: 2}\n')
+    (tmp_path / 'configs/mid.yaml').write_text('base_config: configs/base.yaml\nb: 2\nargs: {y: 3}\n')
+    (tmp_path / 'configs/top.yaml').write_text('base_config:\n  - configs/mid.yaml\nc: 3\n')
+    cfg = read_full_config(tmp_path / 'configs/top.yaml')
+    assert cfg == {'a': 1, 'b': 2, 'c': 3, 'args': {'x': 1, 'y': 3}}
+
+
+def test_cpu_device_is_refused(tmp_path):
+    import inference
+    from some_amd.configs import get_config
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        inference.MIDIExtractionInference(config=get_config('midi_conformer', lay=1), model_path=tmp_path / 'x.ckpt', device='cpu')
