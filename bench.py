@@ -44,6 +44,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='clips per GPU per step')
     ap.add_argument('--seconds', type=float, default=30.0, help='clip length')
     ap.add_argument('--lay', type=int, default=None, help='override lay (debug only; invalidates the metric)')
+    ap.add_argument('--precision', default=None, choices=['f32', 'f16x3'], help='GEMM arithmetic (default: library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-latency', action='store_true', help='skip the B=1 p50 latency leg')
@@ -72,9 +73,12 @@ def main():
         dist.init_process_group('nccl', device_id=device)      # "nccl" is RCCL on ROCm
 
     cfg = get_config(args.config, lay=args.lay) if args.lay is not None else get_config(args.config)
+    if args.precision:
+        cfg['some_amd_precision'] = args.precision
     quant = cfg['task_cls'].endswith('QuantizedMIDIExtractionTask')
     lay, outdim = cfg['midi_extractor_args']['lay'], cfg['midi_num_bins']
     eng = Engine(cfg, device=device)
+    precision_name = {v: k for k, v in __import__('some_amd.engine', fromlist=['PRECISIONS']).PRECISIONS.items()}[eng.c_config.precision]
 
     # ---- weights: rank 0 packs, RCCL broadcast of the flat fp32 arena over xGMI -------------------------
     sd = None
@@ -130,10 +134,12 @@ def main():
         'metric': 'audio-seconds/s (x real-time), SOME inference hot path (log-mel + conformer + decode)',
         'value': round(value, 2), 'unit': 'audio-s/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': 'f32' if precision_name == 'f32' else 'f32-equivalent (3-term split f16 MFMA, f32 accumulate)',
+        'data': 'synthetic',
         'config': {'workload': f'configs/{args.config}.yaml inference, batch of {args.batch} x {args.seconds:g} s '
                                f'44.1 kHz mono clips per GPU (lay {lay}, {outdim} bins, T={T} frames/clip), random-init weights',
                    'clips_per_gpu': args.batch, 'clip_seconds': args.seconds, 'frames_per_clip': T,
+                   'gemm_precision': precision_name,
                    'parallelism': f'utterance-sharded x{world}, RCCL weight broadcast, no data-path collective'},
         'model_tflops': round(step_flops * world / (ms_per_step * 1e-3) / 1e12, 2),
         'notes_decoded_last_step': n_notes,

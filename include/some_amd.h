@@ -57,7 +57,13 @@ typedef struct SomeConfig {
     double midi_max;        /* midi_max                       (127)     */
     double midi_deviation;  /* midi_prob_deviation            (1.0)     */
     double rest_threshold;  /* rest_threshold                 (0.1)     */
+    int32_t precision;      /* SOME_PRECISION_* : arithmetic of the dense GEMMs (library knob, not a reference key) */
+    int32_t reserved;
 } SomeConfig;
+
+#define SOME_PRECISION_F32 0    /* exact fp32 on the f32 matrix pipe (v_mfma_f32_32x32x2_f32)                      */
+#define SOME_PRECISION_F16X3 1  /* fp32-equivalent 3-term split on the f16 matrix pipe: x = hi + lo (two f16),      */
+                                /* a*b = ah*bh + ah*bl + al*bh, fp32 accumulate; needs |GEMM inputs| < 65504        */
 
 /* One entry of a PyTorch state_dict, host memory, contiguous, as produced by
  * torch.load(ckpt)['state_dict'] after the 'model.' prefix strip (inference/base_infer.py:27-32). */
@@ -159,20 +165,26 @@ int some_decode(SomeHandle* h, const float* probs_dev, const float* bounds_dev, 
 
 /* One nn.Linear (+ fused epilogue) on the f32 matrix pipe.  A [M,lda], W [N,K] (K contiguous), C [M,ldc].
  * For the GLU epilogues N counts the packed rows (2 x output width) and C gets N/2 columns. */
+#define SOME_GEMM_SPLIT_IN 1    /* A and W are in SPLIT32 format -> 3-term split-f16 kernel (K % 32 == 0)            */
+#define SOME_GEMM_SPLIT_OUT 2   /* C written in SPLIT32 format (SOME_EPI_BIAS_SILU only)                            */
+#define SOME_GEMM_TILE(t) (((t) & 3) << 8)   /* split kernel tile: 0 = 128x128, 1 = 256x128, 2 = 256x256            */
 int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t lda, const float* W_dev,
                  const float* bias_dev, const float* res_dev, int32_t ldr, float* C_dev, int32_t ldc,
                  int32_t M, int32_t N, int32_t K, float alpha, int32_t act, const uint8_t* row_mask_dev,
-                 void* stream);
+                 int32_t flags, void* stream);
+/* fp32 rows [rows, K] -> SPLIT32 format (per 32-element k-block: 32 f16 hi | 32 f16 lo; same byte size). */
+int some_op_split_rows(SomeHandle* h, const float* x_dev, float* out_dev, int64_t rows, int32_t K, void* stream);
 /* nn.LayerNorm(512), eps 1e-5 (Gconform.py:49-53): y = LN(x) * gamma + beta, rows of 512. */
 int some_op_layernorm(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
-                      float* y_dev, int32_t M, void* stream);
+                      float* y_dev, float* y_split_dev, int32_t M, void* stream);   /* either output may be NULL */
 /* Unmasked per-clip attention, 8 heads x 64, scale 1/8 (base_attention.py:34-44): qkv [M,1536] -> out [M,512]. */
 int some_op_attention(SomeHandle* h, const float* qkv_dev, const int32_t* frame_offsets_dev, int32_t B,
-                      int32_t max_frames, float* out_dev, void* stream);
+                      int32_t max_frames, float* out_dev, int32_t out_split, void* stream);
 /* Depthwise k=31 conv (taps [31,512], BatchNorm already folded) + bias + SiLU, per-clip zero padding
  * (base_conv.py:66-68): x [M,512] -> y [M,512]. */
 int some_op_dwconv_silu(SomeHandle* h, const float* x_dev, const float* taps_dev, const float* bias_dev,
-                        const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, float* y_dev, void* stream);
+                        const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, float* y_dev,
+                        int32_t out_split, void* stream);
 
 /* ---- per-kernel timing (measurement only; off by default) ----------------------------------------- */
 

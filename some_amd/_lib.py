@@ -13,6 +13,8 @@ SOME_OK = 0
 SOME_EINVAL, SOME_EKEY, SOME_ESHAPE, SOME_EHIP, SOME_ESTATE, SOME_ENOMEM = -1, -2, -3, -4, -5, -6
 HEAD_LOGITS, HEAD_SIGMOID, HEAD_SOFTMAX = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_SILU, EPI_BIAS_RES, EPI_GLU, EPI_GLU_RES = range(6)
+PRECISION_F32, PRECISION_F16X3 = 0, 1
+GEMM_SPLIT_IN, GEMM_SPLIT_OUT = 1, 2
 
 
 class SomeConfig(C.Structure):
@@ -23,6 +25,7 @@ class SomeConfig(C.Structure):
         ('fmin', C.c_float), ('fmax', C.c_float),
         ('midi_min', C.c_double), ('midi_max', C.c_double),
         ('midi_deviation', C.c_double), ('rest_threshold', C.c_double),
+        ('precision', C.c_int32), ('reserved', C.c_int32),
     ]
 
 
@@ -53,10 +56,11 @@ SYMBOLS = {
     'some_decode_scratch_bytes': (C.c_size_t, [_P, C.c_int64]),
     'some_decode': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     'some_op_gemm': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32,
-                               C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P]),
-    'some_op_layernorm': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P]),
-    'some_op_attention': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
-    'some_op_dwconv_silu': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
+                               C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, C.c_int32, _P]),
+    'some_op_split_rows': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
+    'some_op_layernorm': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    'some_op_attention': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
+    'some_op_dwconv_silu': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     'some_profile_enable': (C.c_int, [_P, C.c_int32]),
     'some_profile_collect': (C.c_int, [_P, C.POINTER(SomeKernelStat), C.c_int32, C.POINTER(C.c_int32)]),
 }

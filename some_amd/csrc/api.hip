@@ -8,6 +8,7 @@
 #include <set>
 
 #include "internal.h"
+#include "split.h"
 
 namespace {
 
@@ -164,7 +165,7 @@ struct Scope {
 
 extern "C" {
 
-const char* some_version(void) { return "some_amd 0.1 gfx950 (f32 MFMA conformer, HIP)"; }
+const char* some_version(void) { return "some_amd 0.2 gfx950 (f32 / split-f16 MFMA conformer, HIP)"; }
 
 const char* some_last_error(const SomeHandle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -185,8 +186,13 @@ int some_create(const SomeConfig* cfg, SomeHandle** out) {
     REQUIRE(cfg->indim == kMels, "front end is compiled for %d mel bands, got units_dim=%d", kMels, cfg->indim);
     REQUIRE(cfg->sample_rate > 0 && cfg->fmin >= 0, "bad sample_rate/fmin");
 #undef REQUIRE
+    if (cfg->precision != SOME_PRECISION_F32 && cfg->precision != SOME_PRECISION_F16X3)
+        return fail(nullptr, SOME_EINVAL, "unsupported precision (0 = f32, 1 = f16x3)");
     SomeHandle* h = new SomeHandle();
     h->cfg = *cfg;
+    h->precision = cfg->precision;
+    h->tile = -1;                                    // -1: pick per launch from the grid size
+    if (const char* t = getenv("SOME_AMD_TILE")) h->tile = atoi(t);
     build_layout(h->cfg, h->lay);
     *out = h;
     return SOME_OK;
@@ -300,6 +306,27 @@ int some_pack_weights(SomeHandle* h, const SomeTensorDesc* tensors, int32_t n, f
             }
         }
     }
+    if (h->precision == SOME_PRECISION_F16X3) {
+        // every GEMM weight except the K = units_dim input projections -> SPLIT32 in place (same byte size)
+        auto to_split = [&](size_t off, size_t rows, size_t K) {
+            half_t tmp[64];
+            for (size_t i = 0; i < rows * (K / 32); ++i) {
+                float* blk = arena + off + i * 32;
+                for (int j = 0; j < 32; ++j) split_f16(blk[j], tmp[j], tmp[32 + j]);
+                memcpy(blk, tmp, 128);
+            }
+        };
+        to_split(L.out_w, (size_t)c.outdim, kDim);
+        to_split(L.cut_w, 1, kDim);
+        for (const BlockOff& b : L.blocks) {
+            for (int f = 0; f < 2; ++f) { to_split(b.ffn_w1[f], kFfn, kDim); to_split(b.ffn_w2[f], kDim, kFfn); }
+            to_split(b.wqkv, 3 * kDim, kDim);
+            to_split(b.wo, kDim, kDim);
+            to_split(b.pw1_w, 2 * kDim, kDim);
+            to_split(b.pw2_w, kDim, kDim);
+        }
+        for (size_t off : L.glu_w) to_split(off, 2 * kDim, kDim);
+    }
     if (!missing.empty()) return fail(h, SOME_EKEY, "Missing key(s) in state_dict:" + missing);
     std::string unexpected;
     for (auto& kv : have)
@@ -375,19 +402,34 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
         for (int b = 0; b < B; ++b) { const double t = off[b + 1] - off[b]; sumT2 += t * t; }
     }
 
-    auto gemm = [&](const char* name, GemmEpi epi, GemmArgs& a, int n_out_total) -> int {
+    const bool f16x3 = h->precision == SOME_PRECISION_F16X3;
+    auto pick_tile = [&](int n_max) -> int {
+        if (h->tile >= 0) return h->tile;
+        auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((n_max + bn - 1) / bn) * kStreams; };
+        if (blocks(256, 256) >= 512) return 2;       // >= 2 waves of workgroups over 256 CUs
+        if (blocks(256, 128) >= 512) return 1;
+        return 0;
+    };
+    auto launch_any = [&](GemmEpi epi, GemmArgs& a, bool out_split, int n_max) -> hipError_t {
+        if (f16x3) return launch_gemm_f16x3(epi, a, out_split, pick_tile(n_max), s);
+        return launch_gemm(epi, a, s);
+    };
+    auto gemm = [&](const char* name, GemmEpi epi, GemmArgs& a, int n_out_total, bool out_split = false) -> int {
         a.groups = kStreams; a.M = M;
         const double flops = 2.0 * Md * a.K * n_out_total;
         Scope sc(h, s, name, flops, 0.0);
-        hipError_t e = launch_gemm(epi, a, s);
+        hipError_t e = launch_any(epi, a, out_split, n_out_total / kStreams);
         if (e != hipSuccess) return fail_hip(h, e, name);
         return SOME_OK;
     };
-    auto ln = [&](int layer, int idx, float* const* src, float* const* dst) -> int {
+    // f32 mode: dst gets fp32.  f16x3 mode: dst gets SPLIT32 (GEMM operand) and, if dst32 != null, an fp32 copy too.
+    auto ln = [&](int layer, int idx, float* const* src, float* const* dst, float* const* dst32 = nullptr) -> int {
         LnArgs a{};
         for (int g = 0; g < kStreams; ++g) {
             const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
-            a.x[g] = src[g]; a.y[g] = dst[g]; a.gamma[g] = W + b.ln_g[idx]; a.beta[g] = W + b.ln_b[idx];
+            a.x[g] = src[g]; a.gamma[g] = W + b.ln_g[idx]; a.beta[g] = W + b.ln_b[idx];
+            if (f16x3) { a.ys[g] = dst[g]; a.y[g] = dst32 ? dst32[g] : nullptr; }
+            else { a.y[g] = dst[g]; a.ys[g] = nullptr; }
         }
         a.groups = kStreams; a.M = M;
         Scope sc(h, s, "layernorm", 0.0, 2.0 * kStreams * Md * kDim * 4);
@@ -402,7 +444,7 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
             a.g[g] = GemmGroup{H[g], W + b.ffn_w1[f], W + b.ffn_b1[f], nullptr, U[g], nullptr, kFfn, 0};
         }
         a.K = kDim; a.lda = kDim; a.ldc = kFfn;
-        int rc = gemm("gemm_bias_silu[512->2048]", EPI_BIAS_SILU, a, kStreams * kFfn);
+        int rc = gemm("gemm_bias_silu[512->2048]", EPI_BIAS_SILU, a, kStreams * kFfn, /*out_split=*/f16x3);
         if (rc) return rc;
         GemmArgs d{};
         for (int g = 0; g < kStreams; ++g) {
@@ -418,8 +460,11 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
         GemmArgs a{};
         for (int g = 0; g < kStreams; ++g)
             a.g[g] = GemmGroup{units_dev, W + L.in_w[g], W + L.in_b[g], nullptr, X[g], g == 0 ? row_mask_dev : nullptr, kDim, 0};
-        a.K = c.indim; a.lda = c.indim; a.ldc = kDim;
-        if ((rc = gemm("gemm_bias[in->512]", EPI_BIAS, a, kStreams * kDim))) return rc;
+        a.K = c.indim; a.lda = c.indim; a.ldc = kDim; a.groups = kStreams; a.M = M;
+        {   // K = units_dim (80) is not a multiple of 32 and the operand is raw fp32: always the exact-f32 kernel
+            Scope sc(h, s, "gemm_bias[in->512]", 2.0 * Md * c.indim * kStreams * kDim, 0.0);
+            HIP_TRY(h, launch_gemm(EPI_BIAS, a, s));
+        }
     }
     for (int layer = 0; layer <= c.lay; ++layer) {
         // ---- conform_blocke.forward (Gconform.py:56-63), both streams per launch
@@ -437,6 +482,7 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
             AttnArgs a{};
             for (int g = 0; g < kStreams; ++g) { a.qkv[g] = U[g]; a.out[g] = H[g]; }
             a.frame_offsets = frame_offsets_dev; a.groups = kStreams; a.B = B; a.max_frames = max_frames;
+            a.out_split = f16x3 ? 1 : 0;
             Scope sc(h, s, "attention", 4.0 * kHeadDim * kHeads * kStreams * sumT2, 0.0);
             HIP_TRY(h, launch_attention(a, s));
         }
@@ -466,6 +512,7 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
                 a.x[g] = G[g]; a.y[g] = H[g]; a.w[g] = W + b.dw_w; a.b[g] = W + b.dw_b;
             }
             a.frame_offsets = frame_offsets_dev; a.groups = kStreams; a.B = B; a.max_frames = max_frames;
+            a.out_split = f16x3 ? 1 : 0;
             Scope sc(h, s, "dwconv_bn_silu", 0.0, 2.0 * kStreams * Md * kDim * 4);
             HIP_TRY(h, launch_dwconv(a, s));
         }
@@ -480,13 +527,17 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
         }
         if ((rc = ln(layer, 3, X, H))) return rc;
         if ((rc = ffn(layer, 1))) return rc;
-        if ((rc = ln(layer, 4, X, H))) return rc;      // block output y = H
+        // block output y: f32 mode keeps it in H; f16x3 mode needs it twice - SPLIT32 in H as the next GEMM's
+        // operand and fp32 in X (in place) as the exact residual of the cross gate
+        if ((rc = ln(layer, 4, X, H, X))) return rc;
         if (layer < c.lay) {
             // Gcf.forward (Gconform.py:82-87): midi' = y0 + GLU(glu2(y1)), bound' = y1 + GLU(glu1(y0));
             // then masked_fill on the midi stream (Gconform.py:131-132)
             GemmArgs a{};
-            a.g[0] = GemmGroup{H[1], W + L.glu_w[(size_t)layer * 2 + 1], W + L.glu_b[(size_t)layer * 2 + 1], H[0], X[0], row_mask_dev, 2 * kDim, 0};
-            a.g[1] = GemmGroup{H[0], W + L.glu_w[(size_t)layer * 2 + 0], W + L.glu_b[(size_t)layer * 2 + 0], H[1], X[1], nullptr, 2 * kDim, 0};
+            const float* res0 = f16x3 ? X[0] : H[0];
+            const float* res1 = f16x3 ? X[1] : H[1];
+            a.g[0] = GemmGroup{H[1], W + L.glu_w[(size_t)layer * 2 + 1], W + L.glu_b[(size_t)layer * 2 + 1], res0, X[0], row_mask_dev, 2 * kDim, 0};
+            a.g[1] = GemmGroup{H[0], W + L.glu_w[(size_t)layer * 2 + 0], W + L.glu_b[(size_t)layer * 2 + 0], res1, X[1], nullptr, 2 * kDim, 0};
             a.K = kDim; a.lda = kDim; a.ldc = kDim; a.ldr = kDim;
             if ((rc = gemm("gemm_glu_res[512->2x512 gate]", EPI_GLU_RES, a, kStreams * 2 * kDim))) return rc;
         }
@@ -500,12 +551,12 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
         GemmArgs a0 = a; a0.g[0] = a.g[0]; a0.groups = 1; a0.M = M; a0.ldc = c.outdim;
         {
             Scope sc(h, s, "gemm_bias[512->outdim]", 2.0 * Md * kDim * c.outdim, 0.0);
-            HIP_TRY(h, launch_gemm(EPI_BIAS, a0, s));
+            HIP_TRY(h, f16x3 ? launch_gemm_f16x3(EPI_BIAS, a0, false, 0, s) : launch_gemm(EPI_BIAS, a0, s));
         }
         GemmArgs a1 = a; a1.g[0] = a.g[1]; a1.groups = 1; a1.M = M; a1.ldc = 1;
         {
             Scope sc(h, s, "gemm_bias[512->1]", 2.0 * Md * kDim, 0.0);
-            HIP_TRY(h, launch_gemm(EPI_BIAS, a1, s));
+            HIP_TRY(h, f16x3 ? launch_gemm_f16x3(EPI_BIAS, a1, false, 0, s) : launch_gemm(EPI_BIAS, a1, s));
         }
         if (head_mode == SOME_HEAD_SOFTMAX) {
             Scope sc(h, s, "row_softmax", 0.0, 2.0 * Md * c.outdim * 4);
@@ -547,7 +598,8 @@ int some_decode(SomeHandle* h, const float* probs_dev, const float* bounds_dev, 
 
 int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t lda, const float* W_dev,
                  const float* bias_dev, const float* res_dev, int32_t ldr, float* C_dev, int32_t ldc,
-                 int32_t M, int32_t N, int32_t K, float alpha, int32_t act, const uint8_t* row_mask_dev, void* stream) {
+                 int32_t M, int32_t N, int32_t K, float alpha, int32_t act, const uint8_t* row_mask_dev, int32_t flags,
+                 void* stream) {
     if (!h) return SOME_EINVAL;
     if (epilogue < 0 || epilogue > 5 || M < 0 || N <= 0 || K <= 0 || !A_dev || !W_dev || !C_dev)
         return fail(h, SOME_EINVAL, "some_op_gemm: bad argument");
@@ -559,16 +611,28 @@ int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t ld
     a.groups = 1; a.M = M; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.alpha = alpha;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(h, s, "op_gemm", 2.0 * M * (double)N * K, 0.0);
-    HIP_TRY(h, launch_gemm(static_cast<GemmEpi>(epilogue), a, s));
+    if (flags & SOME_GEMM_SPLIT_IN) {
+        if ((K & 31) || (lda & 31)) return fail(h, SOME_EINVAL, "some_op_gemm: SPLIT32 operands need K % 32 == 0 and lda % 32 == 0");
+        HIP_TRY(h, launch_gemm_f16x3(static_cast<GemmEpi>(epilogue), a, (flags & SOME_GEMM_SPLIT_OUT) != 0, (flags >> 8) & 3, s));
+    } else {
+        HIP_TRY(h, launch_gemm(static_cast<GemmEpi>(epilogue), a, s));
+    }
+    return SOME_OK;
+}
+
+int some_op_split_rows(SomeHandle* h, const float* x_dev, float* out_dev, int64_t rows, int32_t K, void* stream) {
+    if (!h) return SOME_EINVAL;
+    if (rows < 0 || K <= 0 || (K & 31) || !x_dev || !out_dev) return fail(h, SOME_EINVAL, "some_op_split_rows: bad argument (K % 32 == 0)");
+    HIP_TRY(h, launch_split_rows(x_dev, out_dev, rows, K, static_cast<hipStream_t>(stream)));
     return SOME_OK;
 }
 
 int some_op_layernorm(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
-                      float* y_dev, int32_t M, void* stream) {
+                      float* y_dev, float* y_split_dev, int32_t M, void* stream) {
     if (!h) return SOME_EINVAL;
-    if (M < 0 || !x_dev || !gamma_dev || !beta_dev || !y_dev) return fail(h, SOME_EINVAL, "some_op_layernorm: bad argument");
+    if (M < 0 || !x_dev || !gamma_dev || !beta_dev || (!y_dev && !y_split_dev)) return fail(h, SOME_EINVAL, "some_op_layernorm: bad argument");
     LnArgs a{};
-    a.x[0] = x_dev; a.y[0] = y_dev; a.gamma[0] = gamma_dev; a.beta[0] = beta_dev; a.groups = 1; a.M = M;
+    a.x[0] = x_dev; a.y[0] = y_dev; a.ys[0] = y_split_dev; a.gamma[0] = gamma_dev; a.beta[0] = beta_dev; a.groups = 1; a.M = M;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(h, s, "op_layernorm", 0.0, 2.0 * M * kDim * 4.0);
     HIP_TRY(h, launch_layernorm(a, s));
@@ -576,11 +640,12 @@ int some_op_layernorm(SomeHandle* h, const float* x_dev, const float* gamma_dev,
 }
 
 int some_op_attention(SomeHandle* h, const float* qkv_dev, const int32_t* frame_offsets_dev, int32_t B,
-                      int32_t max_frames, float* out_dev, void* stream) {
+                      int32_t max_frames, float* out_dev, int32_t out_split, void* stream) {
     if (!h) return SOME_EINVAL;
     if (B < 0 || max_frames < 0 || !qkv_dev || !frame_offsets_dev || !out_dev) return fail(h, SOME_EINVAL, "some_op_attention: bad argument");
     AttnArgs a{};
     a.qkv[0] = qkv_dev; a.out[0] = out_dev; a.frame_offsets = frame_offsets_dev; a.groups = 1; a.B = B; a.max_frames = max_frames;
+    a.out_split = out_split ? 1 : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(h, s, "op_attention", 0.0, 0.0);
     HIP_TRY(h, launch_attention(a, s));
@@ -588,13 +653,15 @@ int some_op_attention(SomeHandle* h, const float* qkv_dev, const int32_t* frame_
 }
 
 int some_op_dwconv_silu(SomeHandle* h, const float* x_dev, const float* taps_dev, const float* bias_dev,
-                        const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, float* y_dev, void* stream) {
+                        const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, float* y_dev, int32_t out_split,
+                        void* stream) {
     if (!h) return SOME_EINVAL;
     if (B < 0 || max_frames < 0 || !x_dev || !taps_dev || !bias_dev || !frame_offsets_dev || !y_dev)
         return fail(h, SOME_EINVAL, "some_op_dwconv_silu: bad argument");
     DwArgs a{};
     a.x[0] = x_dev; a.y[0] = y_dev; a.w[0] = taps_dev; a.b[0] = bias_dev;
     a.frame_offsets = frame_offsets_dev; a.groups = 1; a.B = B; a.max_frames = max_frames;
+    a.out_split = out_split ? 1 : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(h, s, "op_dwconv_silu", 0.0, 0.0);
     HIP_TRY(h, launch_dwconv(a, s));

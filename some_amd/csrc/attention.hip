@@ -22,6 +22,7 @@
 // LDS: K tile [64][68] (row pad 4 floats -> conflict-free ds_read_b128 down a column of keys),
 //      V tile [64][64]; 2 stages = 67,584 B -> 2 workgroups / CU.
 #include "internal.h"
+#include "split.h"
 
 namespace {
 
@@ -199,9 +200,20 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, int nqb) 
     for (int p = 0; p < 8; ++p) {
         const int ql = orow + 4 * p;
         const int q = q0 + wave * 32 + ql;
-        if (q < T)
-            *reinterpret_cast<f32x4*>(og + (size_t)q * kDim + ocol) =
-                *reinterpret_cast<const f32x4*>(patch + ql * LDK + ocol);
+        if (q < T) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(patch + ql * LDK + ocol);
+            if (a.out_split) {   // SPLIT32 row of 512: head h covers k-blocks 2h, 2h+1; 8 lanes per k-block
+                half4 hh, ll;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { half_t h, l; split_f16(v[i], h, l); hh[i] = h; ll[i] = l; }
+                char* row = reinterpret_cast<char*>(a.out[g]) + ((size_t)(f0 + q) * kDim + head * kHeadDim) * 4 +
+                            (ocol >> 5) * 128 + (ocol & 31) * 2;
+                *reinterpret_cast<half4*>(row) = hh;
+                *reinterpret_cast<half4*>(row + 64) = ll;
+            } else {
+                *reinterpret_cast<f32x4*>(og + (size_t)q * kDim + ocol) = v;
+            }
+        }
     }
 }
 

@@ -10,6 +10,7 @@
 // window down 128 frames, 8 outputs per step (31 FMAs each), so every input is loaded from memory once per
 // block (+ a 30-frame halo shared with the neighbouring block through L2).
 #include "internal.h"
+#include "split.h"
 
 namespace {
 
@@ -53,7 +54,20 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
 #pragma unroll
             for (int j = 0; j < kConvK; ++j) acc = fmaf(w[j], win[o + j], acc);
             const float v = acc / (1.0f + __expf(-acc));
-            if (t0 + o < t_end) y[(size_t)(t0 + o) * kDim] = v;
+            if (a.out_split) {   // SPLIT32: lane pairs pack two hi (even lane) / two lo (odd lane) halves per dword
+                half_t h, l;
+                split_f16(v, h, l);
+                const uint32_t mine = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
+                const uint32_t other = __shfl_xor(mine, 1, 64);
+                const int odd = threadIdx.x & 1;
+                const uint32_t word = odd ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
+                if (t0 + o < t_end) {
+                    char* row = reinterpret_cast<char*>(a.y[g]) + (size_t)(f0 + t0 + o) * kDim * 4 + (c >> 5) * 128;
+                    *reinterpret_cast<uint32_t*>(row + (odd ? 64 + ((c & 31) - 1) * 2 : (c & 31) * 2)) = word;
+                }
+            } else if (t0 + o < t_end) {
+                y[(size_t)(t0 + o) * kDim] = v;
+            }
         }
 #pragma unroll
         for (int i = 0; i < kConvK - 1; ++i) win[i] = win[i + G];

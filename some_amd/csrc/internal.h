@@ -46,18 +46,23 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
+// 3-term split-f16 path (gemm_f16x3.hip): A and W in SPLIT32 format (split.h); out_split: C written in SPLIT32
+// (EPI_BIAS_SILU only); tile: 0 = 128x128, 1 = 256x128, 2 = 256x256.
+hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a, bool out_split, int tile, hipStream_t s);
 
 // ---- row ops --------------------------------------------------------------------------------------
 // y[g][m][:] = LayerNorm(x[g][m][:]) * gamma[g] + beta[g], eps 1e-5, rows of 512.
 struct LnArgs {
     const float* x[kStreams];
-    float* y[kStreams];
+    float* y[kStreams];            // fp32 output (may be nullptr)
+    float* ys[kStreams];           // SPLIT32 output (may be nullptr)
     const float* gamma[kStreams];
     const float* beta[kStreams];
     int groups;
     int M;
 };
 hipError_t launch_layernorm(const LnArgs& a, hipStream_t s);
+hipError_t launch_split_rows(const float* x, float* out, int64_t rows, int K, hipStream_t s);
 // in-place softmax over rows of width n (head_mode SOFTMAX)
 hipError_t launch_row_softmax(float* x, int64_t rows, int n, hipStream_t s);
 
@@ -68,6 +73,7 @@ struct AttnArgs {
     float* out[kStreams];
     const int32_t* frame_offsets;  // device [B+1]
     int groups, B, max_frames;
+    int out_split;                 // 1: write `out` in SPLIT32 format
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -79,6 +85,7 @@ struct DwArgs {
     const float* b[kStreams];      // [512] folded
     const int32_t* frame_offsets;
     int groups, B, max_frames;
+    int out_split;                 // 1: write `y` in SPLIT32 format
 };
 hipError_t launch_dwconv(const DwArgs& a, hipStream_t s);
 
@@ -134,6 +141,8 @@ struct SomeHandle {
     void* mel_blob = nullptr;
     std::string err;
     bool profiling = false;
+    int precision = 0;          // SOME_PRECISION_*
+    int tile = 2;               // f16x3 GEMM tile selector (tuning knob)
     std::vector<ProfRecord> prof;
     std::vector<hipEvent_t> event_pool;
 };

@@ -7,6 +7,7 @@
 //
 // Softmax replaces F.softmax(midi, dim=2) (modules/model/Gmidi_conform.py:36-37) on the [M, outdim] head.
 #include "internal.h"
+#include "split.h"
 
 namespace {
 
@@ -28,6 +29,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     const int g = blockIdx.y;
     const float* __restrict__ x = a.x[g];
     float* __restrict__ y = a.y[g];
+    char* __restrict__ ys = reinterpret_cast<char*>(a.ys[g]);
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.gamma[g] + lane * 4);
     const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.gamma[g] + 256 + lane * 4);
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.beta[g] + lane * 4);
@@ -46,9 +48,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
         f32x4 o0 = v0 * rstd * g0 + b0;
         f32x4 o1 = v1 * rstd * g1 + b1;
-        float* out = y + (size_t)m * kDim;
-        *reinterpret_cast<f32x4*>(out + lane * 4) = o0;
-        *reinterpret_cast<f32x4*>(out + 256 + lane * 4) = o1;
+        if (y != nullptr) {
+            float* out = y + (size_t)m * kDim;
+            *reinterpret_cast<f32x4*>(out + lane * 4) = o0;
+            *reinterpret_cast<f32x4*>(out + 256 + lane * 4) = o1;
+        }
+        if (ys != nullptr) {     // SPLIT32: k-block = 8 lanes; 4 hi halves (8 B) + 4 lo halves (8 B) per lane
+            half4 h0, l0, h1, l1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                half_t h, l;
+                split_f16(o0[i], h, l); h0[i] = h; l0[i] = l;
+                split_f16(o1[i], h, l); h1[i] = h; l1[i] = l;
+            }
+            char* row = ys + (size_t)m * kDim * 4 + (lane >> 3) * 128 + (lane & 7) * 8;
+            *reinterpret_cast<half4*>(row) = h0;
+            *reinterpret_cast<half4*>(row + 64) = l0;
+            *reinterpret_cast<half4*>(row + 1024) = h1;
+            *reinterpret_cast<half4*>(row + 1024 + 64) = l1;
+        }
     }
 }
 
@@ -83,7 +101,32 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ x,
     }
 }
 
+// fp32 rows -> SPLIT32 (split.h): one thread per 4 consecutive elements
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, char* __restrict__ out, int64_t n4, int k4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / k4;
+        const int c = (int)(i % k4) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        half4 hh, ll;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { half_t h, l; split_f16(v[j], h, l); hh[j] = h; ll[j] = l; }
+        char* p = out + row * (int64_t)k4 * 16 + (c >> 5) * 128 + (c & 31) * 2;
+        *reinterpret_cast<half4*>(p) = hh;
+        *reinterpret_cast<half4*>(p + 64) = ll;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_split_rows(const float* x, float* out, int64_t rows, int K, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (K & 31) return hipErrorInvalidValue;
+    const int64_t n4 = rows * (K / 4);
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, reinterpret_cast<char*>(out), n4, K / 4);
+    return hipGetLastError();
+}
 
 hipError_t launch_layernorm(const LnArgs& a, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;

@@ -35,7 +35,22 @@ def make_some_config(config: dict) -> _lib.SomeConfig:
     c.midi_max = float(config.get('midi_max', 127))
     c.midi_deviation = float(config.get('midi_prob_deviation', 1.0))
     c.rest_threshold = float(config.get('rest_threshold', 0.1))
+    c.precision = resolve_precision(config)
     return c
+
+
+PRECISIONS = {'f32': _lib.PRECISION_F32, 'f16x3': _lib.PRECISION_F16X3}
+DEFAULT_PRECISION = 'f16x3'
+
+
+def resolve_precision(config: dict) -> int:
+    """GEMM arithmetic: config key ``some_amd_precision`` > env ``SOME_AMD_PRECISION`` > default.
+    'f32' = exact fp32 MFMA; 'f16x3' = fp32-equivalent 3-term split on the f16 matrix pipe."""
+    import os
+    name = config.get('some_amd_precision') or os.environ.get('SOME_AMD_PRECISION') or DEFAULT_PRECISION
+    if name not in PRECISIONS:
+        raise ValueError(f"unknown some_amd precision '{name}' (choose from {sorted(PRECISIONS)})")
+    return PRECISIONS[name]
 
 
 class ClipBatch:

@@ -25,17 +25,36 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _gemm(eng, epi, A, W, bias=None, res=None, alpha=1.0, act=0, mask=None, n_out=None):
+def _split(eng, x):
+    """fp32 [R, K] -> SPLIT32 bytes (same shape / dtype container)."""
+    from some_amd import _lib
+    out = torch.empty_like(x)
+    _lib.check(eng.handle, eng.lib.some_op_split_rows(eng.handle, _p(x), _p(out), x.shape[0], x.shape[1], _stream()))
+    return out
+
+
+def _unsplit(t):
+    """SPLIT32 container [R, K] -> fp32 values hi + lo (host-side decode for checking split outputs)."""
+    r, k = t.shape
+    h = t.contiguous().view(torch.float16).view(r, k // 32, 2, 32).float()
+    return (h[:, :, 0] + h[:, :, 1]).reshape(r, k)
+
+
+def _gemm(eng, epi, A, W, bias=None, res=None, alpha=1.0, act=0, mask=None, n_out=None, split=False, tile=0, out_split=False):
     from some_amd import _lib
     M, K = A.shape
     N = W.shape[0]
     n_out = N if n_out is None else n_out
     Cm = torch.full((M, n_out), float('nan'), device='cuda')
+    flags = 0
+    if split:
+        A, W = _split(eng, A.contiguous()), _split(eng, W.contiguous())
+        flags = _lib.GEMM_SPLIT_IN | (tile << 8) | (_lib.GEMM_SPLIT_OUT if out_split else 0)
     _lib.check(eng.handle, eng.lib.some_op_gemm(
         eng.handle, epi, _p(A), A.stride(0), _p(W), _p(bias), _p(res), 0 if res is None else res.stride(0),
-        _p(Cm), n_out, M, N, K, alpha, act, _p(mask), _stream()))
+        _p(Cm), n_out, M, N, K, alpha, act, _p(mask), flags, _stream()))
     torch.cuda.synchronize()
-    return Cm
+    return _unsplit(Cm) if out_split else Cm
 
 
 def _interleave_glu(w):
@@ -89,7 +108,7 @@ def test_gemm_epilogues(eng):
     Xc = X.clone()
     from some_amd import _lib as L
     L.check(eng.handle, eng.lib.some_op_gemm(eng.handle, L.EPI_BIAS_RES, _p(out), 2048, _p(W2), _p(b2), _p(Xc), 512,
-                                             _p(Xc), 512, M, 512, 2048, 0.5, 0, None, _stream()))
+                                             _p(Xc), 512, M, 512, 2048, 0.5, 0, None, 0, _stream()))
     torch.cuda.synchronize()
     assert (Xc - want).abs().max().item() < 3e-5
     # GLU (conv pointwise 1) and GLU + residual + mask (cross gate)
@@ -114,10 +133,13 @@ def test_layernorm(eng, M):
     gamma = torch.randn(512, device='cuda', generator=g)
     beta = torch.randn(512, device='cuda', generator=g)
     y = torch.empty_like(x)
-    _lib.check(eng.handle, eng.lib.some_op_layernorm(eng.handle, _p(x), _p(gamma), _p(beta), _p(y), M, _stream()))
+    ys = torch.empty_like(x)
+    _lib.check(eng.handle, eng.lib.some_op_layernorm(eng.handle, _p(x), _p(gamma), _p(beta), _p(y), _p(ys), M, _stream()))
     torch.cuda.synchronize()
     ref = F.layer_norm(x.double(), (512,), gamma.double(), beta.double(), eps=1e-5).float()
     assert (y - ref).abs().max().item() < 5e-6
+    # SPLIT32 twin: hi + lo reproduces the fp32 output to 2^-21 relative
+    assert ((_unsplit(ys) - y).abs() <= y.abs() * 2.0 ** -20 + 1e-7).all()
 
 
 @pytest.mark.parametrize('lens', [[64], [1], [33], [130, 257], [128, 1, 300, 65], [862]])
@@ -131,9 +153,13 @@ def test_attention(eng, lens):
     qkv[:, :512] *= 2.0        # sharper softmax
     out = torch.full((M, 512), float('nan'), device='cuda')
     _lib.check(eng.handle, eng.lib.some_op_attention(eng.handle, _p(qkv), _p(batch.frame_offsets_dev), batch.B,
-                                                     batch.max_frames, _p(out), _stream()))
+                                                     batch.max_frames, _p(out), 0, _stream()))
+    outs = torch.empty_like(out)
+    _lib.check(eng.handle, eng.lib.some_op_attention(eng.handle, _p(qkv), _p(batch.frame_offsets_dev), batch.B,
+                                                     batch.max_frames, _p(outs), 1, _stream()))
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
+    assert ((_unsplit(outs) - out).abs() <= out.abs() * 2.0 ** -20 + 1e-7).all()
     for b, t in enumerate(lens):
         s = int(batch.frame_offsets[b])
         x = qkv[s:s + t].double()
@@ -154,7 +180,7 @@ def test_attention_online_softmax_rescale(eng):
     qkv[250, 512:576] = 4.0      # key 250 (4th tile) dominates query 7 of head 0
     batch = ClipBatch([t], 'cuda')
     out = torch.empty(t, 512, device='cuda')
-    _lib.check(eng.handle, eng.lib.some_op_attention(eng.handle, _p(qkv), _p(batch.frame_offsets_dev), 1, t, _p(out), _stream()))
+    _lib.check(eng.handle, eng.lib.some_op_attention(eng.handle, _p(qkv), _p(batch.frame_offsets_dev), 1, t, _p(out), 0, _stream()))
     torch.cuda.synchronize()
     x = qkv.double()
     q, k, v = (x[:, i * 512:(i + 1) * 512].reshape(t, 8, 64).transpose(0, 1) for i in range(3))
@@ -175,9 +201,76 @@ def test_dwconv_silu(eng, lens):
     taps = w[:, 0, :].t().contiguous()          # [31, 512]
     y = torch.full((M, 512), float('nan'), device='cuda')
     _lib.check(eng.handle, eng.lib.some_op_dwconv_silu(eng.handle, _p(x), _p(taps), _p(bias), _p(batch.frame_offsets_dev),
-                                                       batch.B, batch.max_frames, _p(y), _stream()))
+                                                       batch.B, batch.max_frames, _p(y), 0, _stream()))
+    ys = torch.empty_like(y)
+    _lib.check(eng.handle, eng.lib.some_op_dwconv_silu(eng.handle, _p(x), _p(taps), _p(bias), _p(batch.frame_offsets_dev),
+                                                       batch.B, batch.max_frames, _p(ys), 1, _stream()))
     torch.cuda.synchronize()
+    assert ((_unsplit(ys) - y).abs() <= y.abs() * 2.0 ** -20 + 1e-7).all()
     for b, t in enumerate(lens):
         s = int(batch.frame_offsets[b])
         ref = F.silu(F.conv1d(x[s:s + t].t()[None].double(), w.double(), bias.double(), padding=15, groups=512))[0].t().float()
         assert (y[s:s + t] - ref).abs().max().item() < 1e-5, (b, t)
+
+
+# ---- 3-term split-f16 GEMM (gemm_f16x3.hip) ----------------------------------------------------------
+@pytest.mark.parametrize('tile', [0, 1, 2])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 32), (300, 512, 512), (257, 1536, 512), (130, 512, 2048), (77, 129, 512), (64, 1, 512), (515, 2048, 512)])
+def test_gemm_f16x3_matches_fp64(eng, M, N, K, tile):
+    from some_amd import _lib
+    g = torch.Generator(device='cuda').manual_seed(M * 3 + N + tile)
+    A = torch.randn(M, K, device='cuda', generator=g)
+    W = torch.randn(N, K, device='cuda', generator=g) * (1 + torch.arange(N, device='cuda')[:, None] % 5) / 10
+    b = torch.randn(N, device='cuda', generator=g)
+    ref = _ref_mm(A, W)
+    scale = ref.abs().max().item() + 1.0
+    out = _gemm(eng, _lib.EPI_NONE, A, W, split=True, tile=tile)
+    assert torch.isfinite(out).all()
+    err = (out - ref).abs().max().item()
+    assert err < 4e-6 * scale * max(1, K // 256), err            # fp32-class accuracy from f16 MFMAs
+    out = _gemm(eng, _lib.EPI_BIAS, A, W, bias=b, split=True, tile=tile)
+    assert (out - (ref + b)).abs().max().item() < 4e-6 * scale * max(1, K // 256)
+
+
+def test_gemm_f16x3_small_magnitudes_need_f16_subnormals(eng):
+    """|x| ~ 1e-3: the lo halves are f16 subnormals; a pipe that flushed them would lose ~11 bits."""
+    from some_amd import _lib
+    g = torch.Generator(device='cuda').manual_seed(9)
+    A = torch.randn(200, 512, device='cuda', generator=g) * 1e-3
+    W = torch.randn(256, 512, device='cuda', generator=g) * 1e-2
+    ref = _ref_mm(A, W)
+    out = _gemm(eng, _lib.EPI_NONE, A, W, split=True, tile=0)
+    rel = ((out - ref).abs().max() / ref.abs().max()).item()
+    assert rel < 2e-5, rel
+
+
+@pytest.mark.parametrize('tile', [0, 2])
+def test_gemm_f16x3_epilogues(eng, tile):
+    from some_amd import _lib as L
+    g = torch.Generator(device='cuda').manual_seed(50 + tile)
+    M, K = 333, 512
+    A = torch.randn(M, K, device='cuda', generator=g)
+    W = torch.randn(2048, K, device='cuda', generator=g) / 20
+    b = torch.randn(2048, device='cuda', generator=g)
+    ref = F.silu(_ref_mm(A, W) + b)
+    out = _gemm(eng, L.EPI_BIAS_SILU, A, W, bias=b, split=True, tile=tile)
+    assert (out - ref).abs().max().item() < 2e-5
+    out_s = _gemm(eng, L.EPI_BIAS_SILU, A, W, bias=b, split=True, tile=tile, out_split=True)     # SPLIT32 output
+    assert (out_s - ref).abs().max().item() < 2e-5
+    W2 = torch.randn(512, 2048, device='cuda', generator=g) / 40
+    b2 = torch.randn(512, device='cuda', generator=g)
+    X = torch.randn(M, 512, device='cuda', generator=g)
+    want = X + 0.5 * (_ref_mm(out, W2) + b2)
+    got = _gemm(eng, L.EPI_BIAS_RES, out, W2, bias=b2, res=X, alpha=0.5, split=True, tile=tile)
+    assert (got - want).abs().max().item() < 3e-5
+    Wg = torch.randn(1024, K, device='cuda', generator=g) / 20
+    bg = torch.randn(1024, device='cuda', generator=g)
+    y = _ref_mm(A, Wg) + bg
+    glu = y[:, :512] * torch.sigmoid(y[:, 512:])
+    bgi = _interleave_glu(bg[:, None])[:, 0].contiguous()
+    out = _gemm(eng, L.EPI_GLU, A, _interleave_glu(Wg), bias=bgi, n_out=512, split=True, tile=tile)
+    assert (out - glu).abs().max().item() < 2e-5
+    R = torch.randn(M, 512, device='cuda', generator=g)
+    mask = (torch.rand(M, device='cuda', generator=g) > 0.2).to(torch.uint8)
+    out = _gemm(eng, L.EPI_GLU_RES, A, _interleave_glu(Wg), bias=bgi, res=R, mask=mask, n_out=512, split=True, tile=tile)
+    assert (out - (R + glu) * mask[:, None]).abs().max().item() < 2e-5

@@ -75,13 +75,14 @@ def test_mel_spectrogram_module_signature(golden_dir):
 MODEL_CASES = ['conf_lay8', 'conf_lay2_b2', 'quant_lay3', 'two_head_lay1_mask', 'conf_lay1_t1', 'conf_lay1_t33']
 
 
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
 @pytest.mark.parametrize('name', MODEL_CASES)
-def test_model_forward_golden(golden_dir, name):
+def test_model_forward_golden(golden_dir, name, precision):
     """midi_conforms.forward through the nn.Module-compatible operator vs the reference's outputs."""
     from some_amd.modules.model.Gmidi_conform import midi_conforms
     meta = json.loads((golden_dir / 'model.json').read_text())[name]
     g = np.load(golden_dir / 'model.npz')
-    cfg = get_config(meta['config'], lay=meta['lay'])
+    cfg = get_config(meta['config'], lay=meta['lay'], some_amd_precision=precision)
     model = midi_conforms(cfg).eval().to('cuda')
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.synth_state_dict(cfg, meta['seed']).items()}, strict=True)
     x = torch.from_numpy(g[name + '.units']).cuda()
@@ -93,7 +94,7 @@ def test_model_forward_golden(golden_dir, name):
     err_l = np.abs(logits.cpu().numpy() - g[name + '.logits']).max()
     err_p = np.abs(probs.cpu().numpy() - g[name + '.probs']).max()
     err_b = np.abs(bounds.cpu().numpy() - g[name + '.bounds']).max()
-    print(f'{name}: max|dlogit|={err_l:.3e} max|dprob|={err_p:.3e} max|dbound|={err_b:.3e}')
+    print(f'{name} [{precision}]: max|dlogit|={err_l:.3e} max|dprob|={err_p:.3e} max|dbound|={err_b:.3e}')
     assert err_l < LOGIT_TOL and err_p < LOGIT_TOL and err_b < LOGIT_TOL
 
 
@@ -112,6 +113,24 @@ def test_model_strict_loading_errors():
     bad = dict(sd, **{'model.outln.weight': torch.zeros(127, 512)})
     with pytest.raises(RuntimeError, match='size mismatch'):
         model.load_state_dict(bad, strict=True)
+
+
+def test_forward_f16x3_large_ragged_batch_vs_f32(engines):
+    """Both GEMM arithmetic modes on a batch large enough to use the 256x256 / 256x128 tiles."""
+    from some_amd import _lib
+    from some_amd.engine import ClipBatch, Engine
+    cfg3 = get_config('midi_conformer', lay=2, some_amd_precision='f16x3')
+    e3 = Engine(cfg3, device='cuda')
+    e3.load_state_dict(synth.synth_state_dict(cfg3, 77))
+    e1 = engines('midi_conformer', 2, 77)
+    rng = np.random.default_rng(8)
+    lens = [2584] * 20 + [1000, 333, 64, 1]
+    units = torch.from_numpy((rng.standard_normal((sum(lens), 80)) * 2 - 4).astype(np.float32)).cuda()
+    batch = ClipBatch(lens, 'cuda')
+    m1, b1 = e1.forward(units, batch, head_mode=_lib.HEAD_SIGMOID)
+    m3, b3 = e3.forward(units, batch, head_mode=_lib.HEAD_SIGMOID)
+    print('f16x3 vs f32: max|dprob|', float((m1 - m3).abs().max()), 'max|dbound|', float((b1 - b3).abs().max()))
+    assert float((m1 - m3).abs().max()) < 2e-5 and float((b1 - b3).abs().max()) < 2e-5
 
 
 def test_forward_varlen_batch_equals_single_clips(engines):
