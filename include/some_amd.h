@@ -180,6 +180,12 @@ int some_op_layernorm(SomeHandle* h, const float* x_dev, const float* gamma_dev,
 /* Unmasked per-clip attention, 8 heads x 64, scale 1/8 (base_attention.py:34-44): qkv [M,1536] -> out [M,512]. */
 int some_op_attention(SomeHandle* h, const float* qkv_dev, const int32_t* frame_offsets_dev, int32_t B,
                       int32_t max_frames, float* out_dev, int32_t out_split, void* stream);
+/* Split-f16 pair: QKV projection (h [M,512] SPLIT32 x Wqkv [1536,512] SPLIT32) writing Q | K SPLIT32 planes and V
+ * transposed, followed by the split-f16 flash attention (attention_f16x3.hip); out [M,512] SPLIT32.
+ * workspace: >= M*4096 + 2048 * roundup(M, 256) bytes. */
+int some_op_qkv_attention_f16x3(SomeHandle* h, const float* h_split_dev, const float* wqkv_split_dev,
+                                const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, int32_t M,
+                                float* out_split_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 /* Depthwise k=31 conv (taps [31,512], BatchNorm already folded) + bias + SiLU, per-clip zero padding
  * (base_conv.py:66-68): x [M,512] -> y [M,512]. */
 int some_op_dwconv_silu(SomeHandle* h, const float* x_dev, const float* taps_dev, const float* bias_dev,

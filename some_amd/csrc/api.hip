@@ -28,6 +28,7 @@ int fail_hip(SomeHandle* h, hipError_t e, const char* what) {
     } while (0)
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+constexpr size_t kWsSlack = 1 << 20;   // per stream: room for the V^T row padding (ldv - M < 256 frames x 2 KiB)
 
 // ---- arena layout ------------------------------------------------------------------------------------
 struct Cursor {
@@ -364,7 +365,7 @@ size_t some_workspace_bytes(const SomeHandle* h, int64_t total_frames, int32_t B
     if (!h || total_frames <= 0) return 0;
     const size_t m = (size_t)total_frames;
     // per stream: X 512 | H 512 | U 2048 | G 512 floats per frame
-    return kStreams * align_up(m * (size_t)(kDim * 3 + kFfn) * sizeof(float), 256) + 1024;
+    return kStreams * (align_up(m * (size_t)(kDim * 3 + kFfn) * sizeof(float), 256) + kWsSlack) + 1024;
 }
 
 int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_offsets_dev, int32_t B,
@@ -387,7 +388,7 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = (int)total_frames;
     const size_t m = (size_t)M;
-    const size_t per_stream = align_up(m * (size_t)(kDim * 3 + kFfn) * sizeof(float), 256) / sizeof(float);
+    const size_t per_stream = (align_up(m * (size_t)(kDim * 3 + kFfn) * sizeof(float), 256) + kWsSlack) / sizeof(float);
     float* ws = static_cast<float*>(workspace_dev);
     float *X[2], *H[2], *U[2], *G[2];
     for (int g = 0; g < kStreams; ++g) {
@@ -471,18 +472,35 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
         if ((rc = ln(layer, 0, X, H))) return rc;
         if ((rc = ffn(layer, 0))) return rc;
         if ((rc = ln(layer, 1, X, H))) return rc;
-        {
+        if (f16x3) {
+            // QKV projection writes Q | K as SPLIT32 planes and V transposed; split-f16 attention consumes them
+            const int ldv = vt_ld(M);
+            GemmArgs a{};
+            Attn3Args t{};
+            for (int g = 0; g < kStreams; ++g) {
+                float* qp = U[g];
+                float* kp = U[g] + m * kDim;
+                void* vt = U[g] + 2 * m * kDim;
+                a.g[g] = GemmGroup{H[g], W + L.blocks[(size_t)layer * 2 + g].wqkv, nullptr, nullptr, qp, nullptr, 3 * kDim, 0, kp, vt, ldv};
+                t.q[g] = qp; t.k[g] = kp; t.vt[g] = vt; t.out[g] = H[g];
+            }
+            a.K = kDim; a.lda = kDim; a.ldc = kDim;
+            if ((rc = gemm("gemm[512->1536 qkv]", EPI_QKV, a, kStreams * 3 * kDim))) return rc;
+            t.frame_offsets = frame_offsets_dev; t.groups = kStreams; t.B = B; t.max_frames = max_frames; t.M = M; t.ldv = ldv;
+            Scope sc(h, s, "attention", 4.0 * kHeadDim * kHeads * kStreams * sumT2, 0.0);
+            HIP_TRY(h, launch_attention_f16x3(t, s));
+        } else {
             GemmArgs a{};
             for (int g = 0; g < kStreams; ++g)
                 a.g[g] = GemmGroup{H[g], W + L.blocks[(size_t)layer * 2 + g].wqkv, nullptr, nullptr, U[g], nullptr, 3 * kDim, 0};
             a.K = kDim; a.lda = kDim; a.ldc = 3 * kDim;
             if ((rc = gemm("gemm[512->1536 qkv]", EPI_NONE, a, kStreams * 3 * kDim))) return rc;
         }
-        {
+        if (!f16x3) {
             AttnArgs a{};
             for (int g = 0; g < kStreams; ++g) { a.qkv[g] = U[g]; a.out[g] = H[g]; }
             a.frame_offsets = frame_offsets_dev; a.groups = kStreams; a.B = B; a.max_frames = max_frames;
-            a.out_split = f16x3 ? 1 : 0;
+            a.out_split = 0;
             Scope sc(h, s, "attention", 4.0 * kHeadDim * kHeads * kStreams * sumT2, 0.0);
             HIP_TRY(h, launch_attention(a, s));
         }
@@ -649,6 +667,30 @@ int some_op_attention(SomeHandle* h, const float* qkv_dev, const int32_t* frame_
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(h, s, "op_attention", 0.0, 0.0);
     HIP_TRY(h, launch_attention(a, s));
+    return SOME_OK;
+}
+
+int some_op_qkv_attention_f16x3(SomeHandle* h, const float* h_split_dev, const float* wqkv_split_dev,
+                                const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, int32_t M,
+                                float* out_split_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    if (B < 0 || M < 0 || !h_split_dev || !wqkv_split_dev || !frame_offsets_dev || !out_split_dev || !workspace_dev)
+        return fail(h, SOME_EINVAL, "some_op_qkv_attention_f16x3: bad argument");
+    const int ldv = vt_ld(M);
+    const size_t need = (size_t)M * kDim * 4 * 2 + (size_t)2 * kDim * ldv * 2;
+    if (workspace_bytes < need) return fail(h, SOME_ENOMEM, "some_op_qkv_attention_f16x3: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* qp = static_cast<float*>(workspace_dev);
+    float* kp = qp + (size_t)M * kDim;
+    void* vt = kp + (size_t)M * kDim;
+    GemmArgs a{};
+    a.g[0] = GemmGroup{h_split_dev, wqkv_split_dev, nullptr, nullptr, qp, nullptr, 3 * kDim, 0, kp, vt, ldv};
+    a.groups = 1; a.M = M; a.K = kDim; a.lda = kDim; a.ldc = kDim;
+    HIP_TRY(h, launch_gemm_f16x3(EPI_QKV, a, false, h->tile >= 0 ? h->tile : 0, s));
+    Attn3Args t{};
+    t.q[0] = qp; t.k[0] = kp; t.vt[0] = vt; t.out[0] = out_split_dev;
+    t.frame_offsets = frame_offsets_dev; t.groups = 1; t.B = B; t.max_frames = max_frames; t.M = M; t.ldv = ldv;
+    HIP_TRY(h, launch_attention_f16x3(t, s));
     return SOME_OK;
 }
 

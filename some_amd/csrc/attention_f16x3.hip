@@ -1,0 +1,253 @@
+// fp32-equivalent flash attention on the f16 matrix pipe (3-term split, v_mfma_f32_32x32x16_f16).
+//
+// Same operator as attention.hip (F.scaled_dot_product_attention, 8 heads x 64, per clip, unmasked;
+// modules/attention/base_attention.py:34-44) and the same register-only online softmax built on the transposed
+// products  S^T = K Q^T  and  O^T = V^T P^T  (a lane owns one query; P^T in the MFMA C/D layout IS the B operand
+// of the second product).  What changes is the arithmetic of the two products:
+//     s = kh*qh + kh*ql + kl*qh,      o += vh*ph + vh*pl + vl*ph          (x = xh + xl, two f16 halves, fp32 acc)
+// 48 MFMAs of 32 cycles per 64-key tile instead of 128 of 64 cycles.
+//
+// Operands arrive pre-split from the QKV projection's epilogue (gemm_f16x3.hip, EPI_QKV):
+//   Q, K : [M, 512] SPLIT32 rows (split.h) - a head's 64 dims are 256 contiguous bytes (2 k-blocks of hi|lo);
+//   V^T  : hi and lo f16 planes [512, ldv] with the FRAME index contiguous, so a (d, 8-key) operand fragment
+//          is two ds_read_b64 and no transposition happens in this kernel.
+// Key tiles are aligned in GLOBAL frame coordinates (64 gt .. 64 gt + 63), which keeps every 16-byte V^T chunk
+// aligned however the clips are packed; keys outside the clip get score -inf (their data is another clip's
+// finite values or the zero padding the GEMM wrote, so 0 * v stays 0).
+// The softmax scale 64^-0.5 * log2(e) is folded into the exp2 argument: p = exp2(fma(s, c, -m)).
+#include "internal.h"
+#include "split.h"
+
+namespace {
+
+constexpr int QB = 128;
+constexpr int KT = 64;
+constexpr int LDR = 68;                         // LDS row (dwords): 64 data + 4 pad
+constexpr int K_DW = KT * LDR;                  // K tile: [64 keys][hi|lo hi|lo]
+constexpr int V_DW = kHeadDim * LDR;            // V^T tile: [64 d][64 keys hi | 64 keys lo]
+constexpr int STAGE = K_DW + V_DW;
+constexpr size_t LDS_BYTES = 2 * STAGE * sizeof(float);
+
+__device__ __forceinline__ float exp2_(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ void split8(const f32x16& p, int base, half8& h, half8& l) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const half_t hh = (half_t)p[base + i];
+        h[i] = hh;
+        l[i] = (half_t)(p[base + i] - (float)hh);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int slot = jj / nqb, qb = jj % nqb;
+    const int unit = slot * 8 + xcd;
+    const int hg = unit % (kHeads * a.groups), b = unit / (kHeads * a.groups);
+    if (b >= a.B) return;
+    const int head = hg % kHeads, g = hg / kHeads;
+    const int f0 = a.frame_offsets[b];
+    const int T = a.frame_offsets[b + 1] - f0;
+    const int q0 = qb * QB;
+    if (q0 >= T) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const char* __restrict__ Qp = reinterpret_cast<const char*>(a.q[g]) + head * 256;     // row stride 2048 B
+    const char* __restrict__ Kp = reinterpret_cast<const char*>(a.k[g]) + head * 256;
+    const char* __restrict__ Vh = reinterpret_cast<const char*>(a.vt[g]) + (size_t)head * kHeadDim * a.ldv * 2;
+    const char* __restrict__ Vl = Vh + (size_t)kDim * a.ldv * 2;
+
+    // ---- Q fragments (B operand of S^T): slab s covers d = 16 s .. 16 s + 15; lane half kg holds 8 of them
+    half8 qh[4], ql[4];
+    {
+        const int q = q0 + wave * 32 + l31;
+        const bool qv = q < T;
+        const char* row = Qp + (size_t)(f0 + (qv ? q : 0)) * 2048;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int off = (s >> 1) * 128 + (s & 1) * 32 + kg * 16;
+            qh[s] = *reinterpret_cast<const half8*>(row + off);
+            ql[s] = *reinterpret_cast<const half8*>(row + off + 64);
+            if (!qv) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { qh[s][i] = (half_t)0; ql[s][i] = (half_t)0; }
+            }
+        }
+    }
+
+    // ---- staging: K tile 64 rows x 16 chunks, V^T tile 64 rows x (8 hi + 8 lo) chunks; 4 + 4 per thread
+    const int srow = tid >> 4, sc = tid & 15;       // rows srow + 16 p, chunk sc
+    const int gt0 = f0 / KT, gt1 = (f0 + T - 1) / KT;
+    f32x4 rk[4], rv[4];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int gt) {
+        const int g0 = gt * KT;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = srow + 16 * p;
+            const int key = g0 + row;
+            rk[p] = key < a.M ? *reinterpret_cast<const f32x4*>(Kp + (size_t)key * 2048 + sc * 16) : zero4;
+            const char* vsrc = (sc < 8 ? Vh : Vl) + ((size_t)row * a.ldv + g0) * 2 + (sc & 7) * 16;
+            rv[p] = *reinterpret_cast<const f32x4*>(vsrc);
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* Ks = lds + buf * STAGE;
+        float* Vs = Ks + K_DW;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<f32x4*>(Ks + (srow + 16 * p) * LDR + sc * 4) = rk[p];
+            *reinterpret_cast<f32x4*>(Vs + (srow + 16 * p) * LDR + sc * 4) = rv[p];
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = 0.125f * 1.4426950408889634f;       // head_dim^-0.5 * log2(e)
+
+    gload(gt0);
+    lstore(0);
+    __syncthreads();
+
+    for (int gt = gt0; gt <= gt1; ++gt) {
+        const int buf = (gt - gt0) & 1;
+        if (gt < gt1) gload(gt + 1);
+        const float* Ks = lds + buf * STAGE;
+        const float* Vs = Ks + K_DW;
+
+        // ---- S^T = K Q^T (raw, unscaled) for the two 32-key sub-tiles
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        const float* kp = Ks + l31 * LDR + kg * 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int off = (s >> 1) * 32 + (s & 1) * 8;
+            const half8 kh0 = *reinterpret_cast<const half8*>(kp + off);
+            const half8 kl0 = *reinterpret_cast<const half8*>(kp + off + 16);
+            const half8 kh1 = *reinterpret_cast<const half8*>(kp + 32 * LDR + off);
+            const half8 kl1 = *reinterpret_cast<const half8*>(kp + 32 * LDR + off + 16);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[s], s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[s], s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[s], s1, 0, 0, 0);
+        }
+        // keys outside [f0, f0 + T): first and last global tile only
+        const int gbase = gt * KT;
+        if (gbase < f0 || gbase + KT > f0 + T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k0 = gbase + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (k0 < f0 || k0 >= f0 + T) s0[r] = -INFINITY;
+                if (k0 + 32 < f0 || k0 + 32 >= f0 + T) s1[r] = -INFINITY;
+            }
+        }
+        // ---- online softmax (lane = query); scale folded into the exponent
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * c);
+        const float alpha = exp2_(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = exp2_(fmaf(s0[r], c, -m_new));
+            s1[r] = exp2_(fmaf(s1[r], c, -m_new));
+            psum += s0[r] + s1[r];
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+
+        // ---- O^T += V^T P^T.  P slab (sub, s'): registers r = 8 s' .. 8 s' + 7 of the sub-tile hold keys
+        //      16 s' + {0..3} + 4 kg and 16 s' + 8 + {0..3} + 4 kg  ->  two ds_read_b64 per V^T fragment
+        const float* vp = Vs + l31 * LDR + 2 * kg;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                half8 ph, pl;
+                split8(sub == 0 ? s0 : s1, 8 * sp, ph, pl);
+                const int kd = 16 * sub + 8 * sp;                     // dword offset of key 32 sub + 16 s'
+                half8 vh0, vl0, vh1, vl1;
+                {
+                    const half4 a0 = *reinterpret_cast<const half4*>(vp + kd);
+                    const half4 a1 = *reinterpret_cast<const half4*>(vp + kd + 4);
+                    const half4 b0 = *reinterpret_cast<const half4*>(vp + 32 + kd);
+                    const half4 b1 = *reinterpret_cast<const half4*>(vp + 32 + kd + 4);
+                    const half4 c0 = *reinterpret_cast<const half4*>(vp + 32 * LDR + kd);
+                    const half4 c1 = *reinterpret_cast<const half4*>(vp + 32 * LDR + kd + 4);
+                    const half4 d0 = *reinterpret_cast<const half4*>(vp + 32 * LDR + 32 + kd);
+                    const half4 d1 = *reinterpret_cast<const half4*>(vp + 32 * LDR + 32 + kd + 4);
+                    vh0 = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    vl0 = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    vh1 = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    vl1 = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl0, ph, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl1, ph, o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, pl, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, pl, o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, ph, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, ph, o1, 0, 0, 0);
+            }
+        }
+
+        if (gt < gt1) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise, transpose through LDS (wave-private 32 x 64 patch), SPLIT32 row stores
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    float* patch = lds + wave * (32 * LDR);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * kg;
+        patch[l31 * LDR + d] = o0[r] * inv;
+        patch[l31 * LDR + 32 + d] = o1[r] * inv;
+    }
+    __syncthreads();
+    const int orow = lane >> 4, ocol = (lane & 15) * 4;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int ql_ = orow + 4 * p;
+        const int q = q0 + wave * 32 + ql_;
+        if (q < T) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(patch + ql_ * LDR + ocol);
+            half4 hh, ll;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { half_t h, l; split_f16(v[i], h, l); hh[i] = h; ll[i] = l; }
+            char* row = reinterpret_cast<char*>(a.out[g]) + ((size_t)(f0 + q) * kDim + head * kHeadDim) * 4 +
+                        (ocol >> 5) * 128 + (ocol & 31) * 2;
+            *reinterpret_cast<half4*>(row) = hh;
+            *reinterpret_cast<half4*>(row + 64) = ll;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
+    if (a.B <= 0 || a.max_frames <= 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nqb = (a.max_frames + QB - 1) / QB;
+    const int units = a.B * kHeads * a.groups;
+    const int slots = (units + 7) / 8;
+    hipLaunchKernelGGL(attention3_kernel, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    return hipGetLastError();
+}

@@ -210,6 +210,7 @@ hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s) {
         case EPI_BIAS_RES: return launch_t<EPI_BIAS_RES>(a, s);
         case EPI_GLU: return launch_t<EPI_GLU>(a, s);
         case EPI_GLU_RES: return launch_t<EPI_GLU_RES>(a, s);
+        case EPI_QKV: break;   // split-f16 path only
     }
     return hipErrorInvalidValue;
 }

@@ -146,6 +146,51 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
                     }
                 }
         }
+    } else if constexpr (EPI == EPI_QKV) {
+        // N = 1536: columns [0,512) -> Q plane, [512,1024) -> K plane (both SPLIT32 rows of 512),
+        // [1024,1536) -> V^T f16 planes with the frame index contiguous (what attention_f16x3.hip stages)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int n = n0 + (wn * TN + jn) * 32 + l31;
+            const int region = n >> 9;                                  // uniform per 32-column tile
+            if (region < 2) {
+                char* plane = reinterpret_cast<char*>(region == 0 ? g.C : g.C2);
+                const int nn = n & 511;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        half_t h, l;
+                        split_f16(acc[i][jn][r], h, l);
+                        const uint32_t mine = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
+                        const uint32_t other = __shfl_xor(mine, 1, 64);
+                        const uint32_t word = (lane & 1) ? ((other >> 16) | (mine & 0xffff0000u))
+                                                         : ((mine & 0xffffu) | (other << 16));
+                        if (m < a.M) {
+                            char* rowp = plane + (size_t)m * 2048 + (size_t)((nn - l31) >> 5) * 128;
+                            *reinterpret_cast<uint32_t*>(rowp + ((lane & 1) ? 64 + (l31 - 1) * 2 : l31 * 2)) = word;
+                        }
+                    }
+            } else {
+                const int d = n - 1024;
+                char* vh = reinterpret_cast<char*>(g.C3) + (size_t)d * g.ldv * 2;
+                char* vl = vh + (size_t)kDim * g.ldv * 2;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int m = m0 + (wm * TM + i) * 32 + 8 * rq + 4 * hi;     // 4 consecutive frames
+                        half4 hh, ll;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { half_t h, l; split_f16(acc[i][jn][4 * rq + e], h, l); hh[e] = h; ll[e] = l; }
+                        if (m < g.ldv) {      // rows >= M carry exact zeros (zero-filled A rows, no bias): finite padding
+                            *reinterpret_cast<half4*>(vh + (size_t)m * 2) = hh;
+                            *reinterpret_cast<half4*>(vl + (size_t)m * 2) = ll;
+                        }
+                    }
+            }
+        }
     } else {
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
@@ -231,6 +276,10 @@ hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a, bool out_split, int
         case EPI_BIAS_RES: return launch_epi<EPI_BIAS_RES, false>(a, tile, s);
         case EPI_GLU: return launch_epi<EPI_GLU, false>(a, tile, s);
         case EPI_GLU_RES: return launch_epi<EPI_GLU_RES, false>(a, tile, s);
+        case EPI_QKV:
+            for (int g = 0; g < a.groups; ++g)
+                if (a.g[g].N != 3 * kDim || !a.g[g].C2 || !a.g[g].C3 || (a.g[g].ldv & 255) || a.g[g].ldv < a.M) return hipErrorInvalidValue;
+            return launch_epi<EPI_QKV, false>(a, tile, s);
     }
     return hipErrorInvalidValue;
 }

@@ -23,7 +23,8 @@ constexpr int kMels = 80;
 constexpr int kStreams = 2;   // 0 = midi stream (att1 / x), 1 = bound stream (att2 / x1)
 
 // ---- GEMM -----------------------------------------------------------------------------------------
-enum GemmEpi { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_SILU = 2, EPI_BIAS_RES = 3, EPI_GLU = 4, EPI_GLU_RES = 5 };
+enum GemmEpi { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_SILU = 2, EPI_BIAS_RES = 3, EPI_GLU = 4, EPI_GLU_RES = 5,
+               EPI_QKV = 6 /* f16x3 only: Q | K planes in SPLIT32, V transposed (attention_f16x3.hip) */ };
 
 struct GemmGroup {
     const float* A;        // [M, lda]
@@ -34,6 +35,9 @@ struct GemmGroup {
     const uint8_t* mask;   // optional row mask (0 -> output row := 0)
     int N;                 // number of W rows for this group
     int act;               // EPI_BIAS only: 0 none, 1 sigmoid
+    float* C2;             // EPI_QKV: K plane [M, 512] SPLIT32 (C is the Q plane)
+    void* C3;              // EPI_QKV: V^T f16 planes: hi [512, ldv] then lo [512, ldv]
+    int ldv;               // EPI_QKV: frames per V^T row (multiple of 256, >= M rounded up to the M tile)
 };
 
 struct GemmArgs {
@@ -76,6 +80,18 @@ struct AttnArgs {
     int out_split;                 // 1: write `out` in SPLIT32 format
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+// split-f16 attention (attention_f16x3.hip): operands as written by the EPI_QKV GEMM epilogue; out is SPLIT32.
+struct Attn3Args {
+    const float* q[kStreams];      // [M, 512] SPLIT32
+    const float* k[kStreams];      // [M, 512] SPLIT32
+    const void* vt[kStreams];      // f16 hi plane [512, ldv] followed by lo plane [512, ldv]
+    float* out[kStreams];          // [M, 512] SPLIT32
+    const int32_t* frame_offsets;
+    int groups, B, max_frames, M, ldv;
+};
+hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s);
+inline int vt_ld(int64_t M) { return (int)((M + 255) / 256 * 256); }
 
 // ---- depthwise conv + folded BN + SiLU ------------------------------------------------------------
 struct DwArgs {

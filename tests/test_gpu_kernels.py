@@ -274,3 +274,34 @@ def test_gemm_f16x3_epilogues(eng, tile):
     mask = (torch.rand(M, device='cuda', generator=g) > 0.2).to(torch.uint8)
     out = _gemm(eng, L.EPI_GLU_RES, A, _interleave_glu(Wg), bias=bgi, res=R, mask=mask, n_out=512, split=True, tile=tile)
     assert (out - (R + glu) * mask[:, None]).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('lens', [[64], [1], [33], [130, 257], [128, 1, 300, 65], [862], [2584, 100]])
+def test_qkv_attention_f16x3(eng, lens):
+    """Split-f16 QKV projection (Q | K SPLIT32 planes + transposed V) + split-f16 flash attention vs fp64."""
+    from some_amd import _lib
+    from some_amd.engine import ClipBatch
+    g = torch.Generator(device='cuda').manual_seed(100 + sum(lens))
+    batch = ClipBatch(lens, 'cuda')
+    M = batch.total_frames
+    h = torch.randn(M, 512, device='cuda', generator=g)
+    W = torch.randn(1536, 512, device='cuda', generator=g) / 512 ** 0.5
+    W[:512] *= 3.0                                           # sharper softmax
+    out = torch.full((M, 512), float('nan'), device='cuda')
+    ldv = (M + 255) // 256 * 256
+    ws = torch.empty(M * 4096 + 2048 * ldv, dtype=torch.uint8, device='cuda')
+    hs, Ws = _split(eng, h), _split(eng, W)          # keep alive: the library only borrows the pointers
+    _lib.check(eng.handle, eng.lib.some_op_qkv_attention_f16x3(
+        eng.handle, _p(hs), _p(Ws), _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M,
+        _p(out), _p(ws), ws.numel(), _stream()))
+    torch.cuda.synchronize()
+    got = _unsplit(out)
+    assert torch.isfinite(got).all()
+    qkv = h.double() @ W.double().t()
+    for b, t in enumerate(lens):
+        s = int(batch.frame_offsets[b])
+        x = qkv[s:s + t]
+        q, k, v = (x[:, i * 512:(i + 1) * 512].reshape(t, 8, 64).transpose(0, 1) for i in range(3))
+        ref = (torch.softmax(q @ k.transpose(1, 2) * 0.125, dim=-1) @ v).transpose(0, 1).reshape(t, 512).float()
+        err = (got[s:s + t] - ref).abs().max().item()
+        assert err < 1e-5, (b, t, err)

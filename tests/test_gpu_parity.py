@@ -122,7 +122,9 @@ def test_forward_f16x3_large_ragged_batch_vs_f32(engines):
     cfg3 = get_config('midi_conformer', lay=2, some_amd_precision='f16x3')
     e3 = Engine(cfg3, device='cuda')
     e3.load_state_dict(synth.synth_state_dict(cfg3, 77))
-    e1 = engines('midi_conformer', 2, 77)
+    cfg1 = get_config('midi_conformer', lay=2, some_amd_precision='f32')
+    e1 = Engine(cfg1, device='cuda')
+    e1.load_state_dict(synth.synth_state_dict(cfg1, 77))
     rng = np.random.default_rng(8)
     lens = [2584] * 20 + [1000, 333, 64, 1]
     units = torch.from_numpy((rng.standard_normal((sum(lens), 80)) * 2 - 4).astype(np.float32)).cuda()
