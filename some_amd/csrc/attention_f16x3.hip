@@ -109,13 +109,16 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
     float m_run = -INFINITY, l_run = 0.f;
     const float c = 0.125f * 1.4426950408889634f;       // head_dim^-0.5 * log2(e)
 
+    // one register set, written to LDS after the barrier and re-issued at once (see gemm_f16x3.hip)
     gload(gt0);
     lstore(0);
+    if (gt0 < gt1) gload(gt0 + 1);
     __syncthreads();
 
     for (int gt = gt0; gt <= gt1; ++gt) {
         const int buf = (gt - gt0) & 1;
-        if (gt < gt1) gload(gt + 1);
+        if (gt < gt1) lstore(buf ^ 1);
+        if (gt + 1 < gt1) gload(gt + 2);
         const float* Ks = lds + buf * STAGE;
         const float* Vs = Ks + K_DW;
 
@@ -201,7 +204,6 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
             }
         }
 
-        if (gt < gt1) lstore(buf ^ 1);
         __syncthreads();
     }
 

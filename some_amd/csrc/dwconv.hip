@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
                 half_t h, l;
                 split_f16(v, h, l);
                 const uint32_t mine = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
-                const uint32_t other = __shfl_xor(mine, 1, 64);
+                const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);   // lane ^ 1
                 const int odd = threadIdx.x & 1;
                 const uint32_t word = odd ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
                 if (t0 + o < t_end) {

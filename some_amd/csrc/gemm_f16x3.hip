@@ -20,7 +20,153 @@ namespace {
 
 constexpr int LDT = 36;      // LDS row in dwords: 16 (32 hi halves) + 16 (32 lo halves) + 4 pad
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// 1 / (1 + e^-x) with the hardware reciprocal (v_rcp_f32, 1 ulp): the IEEE divide costs ~10 VALU per element
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// Epilogue memory traffic goes through buffer descriptors (T8): one 32-bit VGPR offset per MFMA tile + a scalar
+// row offset per element instead of a 64-bit VGPR address each (the accumulators already hold 128 VGPRs), and
+// hardware bounds checking instead of exec masking - rows >= M lie past num_records (loads return 0, stores are
+// dropped), out-of-range columns are pushed there explicitly.
+constexpr uint32_t kOob = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes), 0x00020000);
+}
+__device__ __forceinline__ float ld32(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void st32(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, uint32_t bits) {
+    __builtin_amdgcn_raw_buffer_store_b32(bits, r, voff, soff, 0);
+}
+__device__ __forceinline__ uint32_t pack_split_pair(float v, int lane) {
+    // SPLIT32 output helper: lane pairs exchange halves so each lane stores one packed dword
+    // (even lane -> two hi halves, odd lane -> two lo halves)
+    half_t h, l;
+    split_f16(v, h, l);
+    const uint32_t mine = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
+    // lane ^ 1 exchange as a DPP quad permute [1,0,3,2] (no LDS round trip, unlike __shfl_xor's ds_bpermute)
+    const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);
+    return (lane & 1) ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, bool FULL>
+__device__ __forceinline__ void epilogue(const GemmArgs& a, const GemmGroup& g, f32x16 (&acc)[TM][TN], int m0, int n0,
+                                         int wm, int wn, int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    const uint32_t row_c = (uint32_t)a.ldc * 4u, row_r = (uint32_t)a.ldr * 4u;      // row pitches in bytes
+    auto rk = [](int r) { return (uint32_t)((r & 3) + 8 * (r >> 2)); };             // row of element r within its tile
+    auto row0 = [&](int i) { return m0 + (wm * TM + i) * 32 + 4 * hi; };
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(g.C, (size_t)a.M * row_c);
+    if constexpr (EPI == EPI_GLU || EPI == EPI_GLU_RES) {
+        static_assert(TN % 2 == 0, "GLU pairs adjacent 32-column tiles");
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc(g.res, (size_t)a.M * row_r);
+#pragma unroll
+        for (int jp = 0; jp < TN / 2; ++jp) {
+            const int np = n0 + (wn * TN + 2 * jp) * 32 + l31;        // packed column of the `a` half
+            const bool nv = FULL || np < g.N;
+            const int oc = (np - l31) / 2 + l31;                       // packed 64-block -> 32 outputs
+            const float ba = nv ? g.bias[np] : 0.f, bg = nv ? g.bias[np + 32] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const uint32_t vc = nv ? (uint32_t)row0(i) * row_c + (uint32_t)oc * 4u : kOob;
+                float rr[16];
+                if constexpr (EPI == EPI_GLU_RES) {
+                    const uint32_t vr = nv ? (uint32_t)row0(i) * row_r + (uint32_t)oc * 4u : kOob;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rr[r] = ld32(rres, vr, rk(r) * row_r);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = (acc[i][2 * jp][r] + ba) * sigmoidf_(acc[i][2 * jp + 1][r] + bg);
+                    if constexpr (EPI == EPI_GLU_RES) {
+                        v += rr[r];
+                        if (g.mask != nullptr) {
+                            const int m = row0(i) + (int)rk(r);
+                            if (m < a.M && g.mask[m] == 0) v = 0.f;
+                        }
+                    }
+                    st32(rc, vc, rk(r) * row_c, __builtin_bit_cast(uint32_t, v));
+                }
+            }
+        }
+    } else if constexpr (EPI == EPI_QKV) {
+        // N = 1536: columns [0,512) -> Q plane, [512,1024) -> K plane (both SPLIT32 rows of 512),
+        // [1024,1536) -> V^T f16 planes with the frame index contiguous (what attention_f16x3.hip stages)
+        const __amdgpu_buffer_rsrc_t rq = make_rsrc(g.C, (size_t)a.M * 2048);
+        const __amdgpu_buffer_rsrc_t rkp = make_rsrc(g.C2, (size_t)a.M * 2048);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int n = n0 + (wn * TN + jn) * 32 + l31;
+            const int region = n >> 9;                                  // uniform per 32-column tile
+            if (region < 2) {
+                const int nn = n & 511;
+                const uint32_t lane_off = (uint32_t)((nn - l31) >> 5) * 128u + ((lane & 1) ? 64u + (uint32_t)(l31 - 1) * 2u : (uint32_t)l31 * 2u);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const uint32_t vq = (uint32_t)row0(i) * 2048u + lane_off;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t word = pack_split_pair(acc[i][jn][r], lane);
+                        st32(region == 0 ? rq : rkp, vq, rk(r) * 2048u, word);
+                    }
+                }
+            } else {
+                const int d = n - 1024;
+                char* vh = reinterpret_cast<char*>(g.C3) + (size_t)d * g.ldv * 2;
+                char* vl = vh + (size_t)kDim * g.ldv * 2;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int rq4 = 0; rq4 < 4; ++rq4) {
+                        const int m = m0 + (wm * TM + i) * 32 + 8 * rq4 + 4 * hi;     // 4 consecutive frames
+                        half4 hh, ll;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { half_t h, l; split_f16(acc[i][jn][4 * rq4 + e], h, l); hh[e] = h; ll[e] = l; }
+                        if (FULL || m < g.ldv) {   // rows >= M carry exact zeros (zero-filled A rows, no bias): finite padding
+                            *reinterpret_cast<half4*>(vh + (size_t)m * 2) = hh;
+                            *reinterpret_cast<half4*>(vl + (size_t)m * 2) = ll;
+                        }
+                    }
+            }
+        }
+    } else {
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc(EPI == EPI_BIAS_RES ? (const void*)g.res : (const void*)g.C, (size_t)a.M * row_r);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int n = n0 + (wn * TN + jn) * 32 + l31;
+            const bool nv = FULL || n < g.N;
+            float bias = 0.f;
+            if constexpr (EPI != EPI_NONE) bias = nv ? g.bias[n] : 0.f;
+            const uint32_t split_off = (uint32_t)((n - l31) >> 5) * 128u + ((lane & 1) ? 64u + (uint32_t)(l31 - 1) * 2u : (uint32_t)l31 * 2u);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const uint32_t vc = nv ? (uint32_t)row0(i) * row_c + (OUT_SPLIT ? split_off : (uint32_t)n * 4u) : kOob;
+                float rr[16];
+                if constexpr (EPI == EPI_BIAS_RES) {
+                    const uint32_t vr = nv ? (uint32_t)row0(i) * row_r + (uint32_t)n * 4u : kOob;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rr[r] = ld32(rres, vr, rk(r) * row_r);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][jn][r] + bias;
+                    if constexpr (EPI == EPI_BIAS) {
+                        if (g.act == 1) v = sigmoidf_(v);
+                        if (g.mask != nullptr) {
+                            const int m = row0(i) + (int)rk(r);
+                            if (m < a.M && g.mask[m] == 0) v = 0.f;
+                        }
+                    } else if constexpr (EPI == EPI_BIAS_SILU) {
+                        v = v * sigmoidf_(v);
+                    } else if constexpr (EPI == EPI_BIAS_RES) {
+                        v = rr[r] + a.alpha * v;
+                    }
+                    if constexpr (OUT_SPLIT) st32(rc, vc, rk(r) * row_c, pack_split_pair(v, lane));
+                    else st32(rc, vc, rk(r) * row_c, __builtin_bit_cast(uint32_t, v));
+                }
+            }
+        }
+    }
+}
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs a) {
@@ -83,8 +229,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
 
+    // Pipeline (one register set, cdna guide T14 "write after the barrier"): at the top of iteration kt the
+    // registers hold k-block kt + 1 (loaded during iteration kt - 1, so its latency is already paid); they are
+    // written to the other LDS buffer, immediately re-issued for k-block kt + 2, and the MFMAs of block kt run
+    // while those loads fly.  One barrier per k-block; nothing waits on a just-issued load.
     gload(0);
     lstore(0);
+    if (nk > 1) gload(1);
     __syncthreads();
 
     const int a_off = (wm * TM * 32 + l31) * LDT + kg * 4;
@@ -92,7 +243,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        if (kt + 2 < nk) gload(kt + 2);
         const float* As = lds + buf * STAGE + a_off;
         const float* Ws = lds + buf * STAGE + w_off;
 #pragma unroll
@@ -108,129 +260,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
                 bh[jn] = *reinterpret_cast<const half8*>(Ws + jn * 32 * LDT + s * 8);
                 bl[jn] = *reinterpret_cast<const half8*>(Ws + jn * 32 * LDT + 16 + s * 8);
             }
+            // three sweeps over the accumulator tiles: consecutive MFMAs never share an accumulator
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int jn = 0; jn < TN; ++jn) {
+                for (int jn = 0; jn < TN; ++jn)
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jn], acc[i][jn], 0, 0, 0);
-                }
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-    const int hi = kg;
-    if constexpr (EPI == EPI_GLU || EPI == EPI_GLU_RES) {
-        static_assert(TN % 2 == 0, "GLU pairs adjacent 32-column tiles");
-#pragma unroll
-        for (int jp = 0; jp < TN / 2; ++jp) {
-            const int np = n0 + (wn * TN + 2 * jp) * 32 + l31;        // packed column of the `a` half
-            if (np >= g.N) continue;
-            const int oc = (np - l31) / 2 + l31;                       // output column: packed 64-block -> 32 outputs
-            const float ba = g.bias[np], bg = g.bias[np + 32];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (m < a.M) {
-                        float v = (acc[i][2 * jp][r] + ba) * sigmoidf_(acc[i][2 * jp + 1][r] + bg);
-                        if constexpr (EPI == EPI_GLU_RES) {
-                            v += g.res[(size_t)m * a.ldr + oc];
-                            if (g.mask != nullptr && g.mask[m] == 0) v = 0.f;
-                        }
-                        g.C[(size_t)m * a.ldc + oc] = v;
-                    }
-                }
-        }
-    } else if constexpr (EPI == EPI_QKV) {
-        // N = 1536: columns [0,512) -> Q plane, [512,1024) -> K plane (both SPLIT32 rows of 512),
-        // [1024,1536) -> V^T f16 planes with the frame index contiguous (what attention_f16x3.hip stages)
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
-            const int n = n0 + (wn * TN + jn) * 32 + l31;
-            const int region = n >> 9;                                  // uniform per 32-column tile
-            if (region < 2) {
-                char* plane = reinterpret_cast<char*>(region == 0 ? g.C : g.C2);
-                const int nn = n & 511;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        half_t h, l;
-                        split_f16(acc[i][jn][r], h, l);
-                        const uint32_t mine = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
-                        const uint32_t other = __shfl_xor(mine, 1, 64);
-                        const uint32_t word = (lane & 1) ? ((other >> 16) | (mine & 0xffff0000u))
-                                                         : ((mine & 0xffffu) | (other << 16));
-                        if (m < a.M) {
-                            char* rowp = plane + (size_t)m * 2048 + (size_t)((nn - l31) >> 5) * 128;
-                            *reinterpret_cast<uint32_t*>(rowp + ((lane & 1) ? 64 + (l31 - 1) * 2 : l31 * 2)) = word;
-                        }
-                    }
-            } else {
-                const int d = n - 1024;
-                char* vh = reinterpret_cast<char*>(g.C3) + (size_t)d * g.ldv * 2;
-                char* vl = vh + (size_t)kDim * g.ldv * 2;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const int m = m0 + (wm * TM + i) * 32 + 8 * rq + 4 * hi;     // 4 consecutive frames
-                        half4 hh, ll;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { half_t h, l; split_f16(acc[i][jn][4 * rq + e], h, l); hh[e] = h; ll[e] = l; }
-                        if (m < g.ldv) {      // rows >= M carry exact zeros (zero-filled A rows, no bias): finite padding
-                            *reinterpret_cast<half4*>(vh + (size_t)m * 2) = hh;
-                            *reinterpret_cast<half4*>(vl + (size_t)m * 2) = ll;
-                        }
-                    }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
-            const int n = n0 + (wn * TN + jn) * 32 + l31;
-            const bool nv = n < g.N;
-            float bias = 0.f;
-            if constexpr (EPI != EPI_NONE) bias = nv ? g.bias[n] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    float v = acc[i][jn][r] + bias;
-                    if constexpr (EPI == EPI_BIAS) {
-                        if (g.act == 1) v = sigmoidf_(v);
-                        if (g.mask != nullptr && m < a.M && g.mask[m] == 0) v = 0.f;
-                    } else if constexpr (EPI == EPI_BIAS_SILU) {
-                        v = v * sigmoidf_(v);
-                    } else if constexpr (EPI == EPI_BIAS_RES) {
-                        if (nv && m < a.M) v = g.res[(size_t)m * a.ldr + n] + a.alpha * v;
-                    }
-                    if constexpr (OUT_SPLIT) {
-                        // SPLIT32 output: this tile's 32 columns are one k-block of the consumer GEMM.  Lane pairs
-                        // exchange halves so each lane stores one packed dword: even lane -> two hi, odd -> two lo.
-                        half_t h, l;
-                        split_f16(v, h, l);
-                        const uint32_t mine = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
-                        const uint32_t other = __shfl_xor(mine, 1, 64);
-                        const uint32_t word = (lane & 1) ? ((other >> 16) | (mine & 0xffff0000u))
-                                                         : ((mine & 0xffffu) | (other << 16));
-                        if (nv && m < a.M) {
-                            char* rowp = reinterpret_cast<char*>(g.C) + (size_t)m * a.ldc * 4 + (size_t)((n - l31) >> 5) * 128;
-                            *reinterpret_cast<uint32_t*>(rowp + ((lane & 1) ? 64 + (l31 - 1) * 2 : l31 * 2)) = word;
-                        }
-                    } else {
-                        if (nv && m < a.M) g.C[(size_t)m * a.ldc + n] = v;
-                    }
-                }
-        }
-    }
+    // Interior workgroups take the unguarded path (no per-element exec masking).  Residual values are fetched one
+    // 32 x 32 MFMA tile (16 per lane) at a time BEFORE that tile's stores: C may alias res (in-place residual
+    // update), which otherwise forces the compiler into load -> wait -> store per element.
+    if (m0 + BM <= a.M && n0 + BN <= g.N)
+        epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, true>(a, g, acc, m0, n0, wm, wn, lane);
+    else
+        epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT>
