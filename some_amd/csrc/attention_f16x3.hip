@@ -25,17 +25,19 @@ constexpr int KT = 64;
 constexpr int LDR = 68;                         // LDS row (dwords): 64 data + 4 pad
 constexpr int K_DW = KT * LDR;                  // K tile: [64 keys][hi|lo hi|lo]
 constexpr int V_DW = kHeadDim * LDR;            // V^T tile: [64 d][64 keys hi | 64 keys lo]
-constexpr int STAGE = K_DW + V_DW;
-constexpr size_t LDS_BYTES = 2 * STAGE * sizeof(float);
+constexpr size_t LDS_BYTES = 2 * (K_DW + V_DW) * sizeof(float);
 
 __device__ __forceinline__ float exp2_(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// p = hi + lo with packed round-toward-zero converts (v_cvt_pkrtz_f16_f32: two values per instruction).  hi need
+// not be the NEAREST f16: lo = rtz_f16(p - hi) still leaves |p - hi - lo| < 2^-20 p, the same class as split_f16.
 __device__ __forceinline__ void split8(const f32x16& p, int base, half8& h, half8& l) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const half_t hh = (half_t)p[base + i];
-        h[i] = hh;
-        l[i] = (half_t)(p[base + i] - (float)hh);
+    for (int i = 0; i < 8; i += 2) {
+        const half2_t hh = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(p[base + i], p[base + i + 1]));
+        const half2_t ll = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(p[base + i] - (float)hh[0], p[base + i + 1] - (float)hh[1]));
+        h[i] = hh[0]; h[i + 1] = hh[1];
+        l[i] = ll[0]; l[i + 1] = ll[1];
     }
 }
 
@@ -77,56 +79,47 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
         }
     }
 
-    // ---- staging: K tile 64 rows x 16 chunks, V^T tile 64 rows x (8 hi + 8 lo) chunks; 4 + 4 per thread
+    // ---- staging roles: a K tile is 64 rows x 16 chunks, a V^T tile 64 rows x (8 hi + 8 lo) chunks; 4 + 4 per thread
     const int srow = tid >> 4, sc = tid & 15;       // rows srow + 16 p, chunk sc
     const int gt0 = f0 / KT, gt1 = (f0 + T - 1) / KT;
+    const int n = gt1 - gt0 + 1;                    // key tiles of this clip
     f32x4 rk[4], rv[4];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto gload = [&](int gt) {
-        const int g0 = gt * KT;
+    auto gload_k = [&](int i) {
+        const int g0 = (gt0 + i) * KT;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int row = srow + 16 * p;
-            const int key = g0 + row;
+            const int key = g0 + srow + 16 * p;
             rk[p] = key < a.M ? *reinterpret_cast<const f32x4*>(Kp + (size_t)key * 2048 + sc * 16) : zero4;
-            const char* vsrc = (sc < 8 ? Vh : Vl) + ((size_t)row * a.ldv + g0) * 2 + (sc & 7) * 16;
+        }
+    };
+    auto gload_v = [&](int i) {
+        const int g0 = (gt0 + i) * KT;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const char* vsrc = (sc < 8 ? Vh : Vl) + ((size_t)(srow + 16 * p) * a.ldv + g0) * 2 + (sc & 7) * 16;
             rv[p] = *reinterpret_cast<const f32x4*>(vsrc);
         }
     };
-    auto lstore = [&](int buf) {
-        float* Ks = lds + buf * STAGE;
-        float* Vs = Ks + K_DW;
+    // LDS: K ring [2] then V^T ring [2]; the K ring runs one tile ahead of the V^T ring
+    auto kbuf = [&](int i) { return lds + (i & 1) * K_DW; };
+    auto vbuf = [&](int i) { return lds + 2 * K_DW + (i & 1) * V_DW; };
+    auto lstore_k = [&](int i) {
+        float* Ks = kbuf(i);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            *reinterpret_cast<f32x4*>(Ks + (srow + 16 * p) * LDR + sc * 4) = rk[p];
-            *reinterpret_cast<f32x4*>(Vs + (srow + 16 * p) * LDR + sc * 4) = rv[p];
-        }
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(Ks + (srow + 16 * p) * LDR + sc * 4) = rk[p];
+    };
+    auto lstore_v = [&](int i) {
+        float* Vs = vbuf(i);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(Vs + (srow + 16 * p) * LDR + sc * 4) = rv[p];
     };
 
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-    const float c = 0.125f * 1.4426950408889634f;       // head_dim^-0.5 * log2(e)
-
-    // one register set, written to LDS after the barrier and re-issued at once (see gemm_f16x3.hip)
-    gload(gt0);
-    lstore(0);
-    if (gt0 < gt1) gload(gt0 + 1);
-    __syncthreads();
-
-    for (int gt = gt0; gt <= gt1; ++gt) {
-        const int buf = (gt - gt0) & 1;
-        if (gt < gt1) lstore(buf ^ 1);
-        if (gt + 1 < gt1) gload(gt + 2);
-        const float* Ks = lds + buf * STAGE;
-        const float* Vs = Ks + K_DW;
-
-        // ---- S^T = K Q^T (raw, unscaled) for the two 32-key sub-tiles
-        f32x16 s0, s1;
+    // S^T = K Q^T (raw, unscaled) for tile i, both 32-key sub-tiles, then -inf outside the clip
+    auto qk = [&](int i, f32x16& s0, f32x16& s1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-        const float* kp = Ks + l31 * LDR + kg * 4;
+        const float* kp = kbuf(i) + l31 * LDR + kg * 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int off = (s >> 1) * 32 + (s & 1) * 8;
@@ -141,9 +134,10 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[s], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[s], s1, 0, 0, 0);
         }
-        // keys outside [f0, f0 + T): first and last global tile only
-        const int gbase = gt * KT;
-        if (gbase < f0 || gbase + KT > f0 + T) {
+    };
+    auto mask_tile = [&](int i, f32x16& s0, f32x16& s1) {
+        const int gbase = (gt0 + i) * KT;
+        if (gbase < f0 || gbase + KT > f0 + T) {          // first and last global tile only
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k0 = gbase + (r & 3) + 8 * (r >> 2) + 4 * kg;
@@ -151,13 +145,22 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
                 if (k0 + 32 < f0 || k0 + 32 >= f0 + T) s1[r] = -INFINITY;
             }
         }
-        // ---- online softmax (lane = query); scale folded into the exponent
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = 0.125f * 1.4426950408889634f;       // head_dim^-0.5 * log2(e)
+
+    // online softmax of one tile's scores (lane = query; scale folded into the exponent): s0/s1 become P
+    auto softmax = [&](f32x16& s0, f32x16& s1) {
         float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * c);
-        const float alpha = exp2_(m_run - m_new);
+        const float m_new = fmaxf(m_run, mx * c);      // finite: every tile holds at least one key of the clip
+        const float alpha = exp2_(m_run - m_new);       // first tile: exp2(-inf) = 0
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
@@ -167,12 +170,15 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
             psum += s0[r] + s1[r];
         }
         l_run = l_run * alpha + psum;
+        // unconditional (no wave-uniform "max did not move" branch): a branch here would split the basic block and
+        // stop the scheduler from spreading this VALU work under the QK(i+1) MFMAs
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-
-        // ---- O^T += V^T P^T.  P slab (sub, s'): registers r = 8 s' .. 8 s' + 7 of the sub-tile hold keys
-        //      16 s' + {0..3} + 4 kg and 16 s' + 8 + {0..3} + 4 kg  ->  two ds_read_b64 per V^T fragment
-        const float* vp = Vs + l31 * LDR + 2 * kg;
+    };
+    // O^T += V^T P^T for tile i.  P slab (sub, s'): registers r = 8 s' .. 8 s' + 7 of the sub-tile hold keys
+    // 16 s' + {0..3} + 4 kg and 16 s' + 8 + {0..3} + 4 kg  ->  two ds_read_b64 per V^T fragment
+    auto pv = [&](int i, const f32x16& s0, const f32x16& s1) {
+        const float* vp = vbuf(i) + l31 * LDR + 2 * kg;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -180,21 +186,18 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
                 half8 ph, pl;
                 split8(sub == 0 ? s0 : s1, 8 * sp, ph, pl);
                 const int kd = 16 * sub + 8 * sp;                     // dword offset of key 32 sub + 16 s'
-                half8 vh0, vl0, vh1, vl1;
-                {
-                    const half4 a0 = *reinterpret_cast<const half4*>(vp + kd);
-                    const half4 a1 = *reinterpret_cast<const half4*>(vp + kd + 4);
-                    const half4 b0 = *reinterpret_cast<const half4*>(vp + 32 + kd);
-                    const half4 b1 = *reinterpret_cast<const half4*>(vp + 32 + kd + 4);
-                    const half4 c0 = *reinterpret_cast<const half4*>(vp + 32 * LDR + kd);
-                    const half4 c1 = *reinterpret_cast<const half4*>(vp + 32 * LDR + kd + 4);
-                    const half4 d0 = *reinterpret_cast<const half4*>(vp + 32 * LDR + 32 + kd);
-                    const half4 d1 = *reinterpret_cast<const half4*>(vp + 32 * LDR + 32 + kd + 4);
-                    vh0 = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    vl0 = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    vh1 = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    vl1 = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
+                const half4 a0 = *reinterpret_cast<const half4*>(vp + kd);
+                const half4 a1 = *reinterpret_cast<const half4*>(vp + kd + 4);
+                const half4 b0 = *reinterpret_cast<const half4*>(vp + 32 + kd);
+                const half4 b1 = *reinterpret_cast<const half4*>(vp + 32 + kd + 4);
+                const half4 c0 = *reinterpret_cast<const half4*>(vp + 32 * LDR + kd);
+                const half4 c1 = *reinterpret_cast<const half4*>(vp + 32 * LDR + kd + 4);
+                const half4 d0 = *reinterpret_cast<const half4*>(vp + 32 * LDR + 32 + kd);
+                const half4 d1 = *reinterpret_cast<const half4*>(vp + 32 * LDR + 32 + kd + 4);
+                const half8 vh0 = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const half8 vl0 = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const half8 vh1 = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const half8 vl1 = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl0, ph, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl1, ph, o1, 0, 0, 0);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, pl, o0, 0, 0, 0);
@@ -203,9 +206,37 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, ph, o1, 0, 0, 0);
             }
         }
+    };
 
+    // ---- software pipeline (cdna guide T15): in iteration i the matrix pipe computes the NEXT tile's scores
+    // QK(i+1) while the VALU turns the CURRENT tile's scores into probabilities, then PV(i).  One barrier per
+    // tile; registers carry K(i+2) / V(i+1) across it (write after the barrier, re-issue at once).
+    gload_k(0);
+    gload_v(0);
+    lstore_k(0);
+    lstore_v(0);
+    if (n > 1) { gload_k(1); lstore_k(1); gload_v(1); }
+    if (n > 2) gload_k(2);
+    __syncthreads();
+    f32x16 sc0, sc1, sn0, sn1;
+    qk(0, sc0, sc1);
+    mask_tile(0, sc0, sc1);
+    for (int i = 0; i + 1 < n; ++i) {
+        if (i + 2 < n) lstore_k(i + 2);               // K ring slot i & 1: last read by QK(i) in the previous iteration
+        lstore_v(i + 1);                              // V ring slot (i+1) & 1: last read by PV(i-1)
+        if (i + 3 < n) gload_k(i + 3);
+        if (i + 2 < n) gload_v(i + 2);
+        qk(i + 1, sn0, sn1);                          // matrix pipe ...
+        softmax(sc0, sc1);                            // ... overlapped with the VALU (independent of QK(i+1))
+        pv(i, sc0, sc1);
+        mask_tile(i + 1, sn0, sn1);
         __syncthreads();
+        sc0 = sn0;
+        sc1 = sn1;
     }
+    softmax(sc0, sc1);
+    pv(n - 1, sc0, sc1);
+    __syncthreads();
 
     // ---- normalise, transpose through LDS (wave-private 32 x 64 patch), SPLIT32 row stores
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
