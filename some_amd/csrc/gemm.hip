@@ -31,7 +31,7 @@ constexpr int TILE_FLOATS = BM * LDT;             // one operand tile
 constexpr int STAGE_FLOATS = 2 * TILE_FLOATS;     // A + W
 constexpr size_t LDS_BYTES = 2 * STAGE_FLOATS * sizeof(float);   // 73,728
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
@@ -94,8 +94,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
         }
     };
 
+    // one register set: written to LDS after the barrier, re-issued at once (cdna guide T14)
     gload(0);
     lstore(0);
+    if (nk > 1) gload(1);
     __syncthreads();
 
     const int a_off = (wm * 64 + l31) * LDT + hi * 4;
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        if (kt + 2 < nk) gload(kt + 2);
         const float* As = lds + buf * STAGE_FLOATS + a_off;
         const float* Ws = lds + buf * STAGE_FLOATS + TILE_FLOATS + w_off;
 #pragma unroll
@@ -120,56 +123,84 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
             }
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    // Buffer-descriptor loads / stores (one 32-bit VGPR offset per tile + scalar row offsets, hardware bounds
+    // check instead of exec masking); residuals are fetched a whole 16-element tile BEFORE that tile's stores
+    // because C may alias res (in-place update) - see gemm_f16x3.hip.
+    const uint32_t row_c = (uint32_t)a.ldc * 4u, row_r = (uint32_t)a.ldr * 4u;
+    constexpr uint32_t kOob = 0x80000000u;
+    auto rsrc = [](const void* p, size_t bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes), 0x00020000);
+    };
+    auto rk = [](int r) { return (uint32_t)((r & 3) + 8 * (r >> 2)); };
+    const __amdgpu_buffer_rsrc_t rc = rsrc(g.C, (size_t)a.M * row_c);
+    const __amdgpu_buffer_rsrc_t rres = rsrc((EPI == EPI_BIAS_RES || EPI == EPI_GLU_RES) ? (const void*)g.res : (const void*)g.C, (size_t)a.M * row_r);
     if constexpr (EPI == EPI_GLU || EPI == EPI_GLU_RES) {
         // packed W rows: [32 a | 32 gate] per 64; this wave's nt = 0 tile is `a`, nt = 1 the matching gate
         const int np = n0 + wn * 64 + l31;            // packed column of the a half
-        if (np >= g.N) return;
+        const bool nv = np < g.N;
         const int oc = (n0 >> 1) + wn * 32 + l31;     // output column
-        const float ba = g.bias[np], bg = g.bias[np + 32];
+        const float ba = nv ? g.bias[np] : 0.f, bg = nv ? g.bias[np + 32] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
+            const int mrow = m0 + wm * 64 + mt * 32 + 4 * hi;
+            const uint32_t vc = nv ? (uint32_t)mrow * row_c + (uint32_t)oc * 4u : kOob;
+            float rr[16];
+            if constexpr (EPI == EPI_GLU_RES) {
+                const uint32_t vr = nv ? (uint32_t)mrow * row_r + (uint32_t)oc * 4u : kOob;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vr, rk(r) * row_r, 0));
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m < a.M) {
-                    float v = (acc[mt][0][r] + ba) * sigmoidf_(acc[mt][1][r] + bg);
-                    if constexpr (EPI == EPI_GLU_RES) {
-                        v += g.res[(size_t)m * a.ldr + oc];
-                        if (g.mask != nullptr && g.mask[m] == 0) v = 0.f;
+                float v = (acc[mt][0][r] + ba) * sigmoidf_(acc[mt][1][r] + bg);
+                if constexpr (EPI == EPI_GLU_RES) {
+                    v += rr[r];
+                    if (g.mask != nullptr) {
+                        const int m = mrow + (int)rk(r);
+                        if (m < a.M && g.mask[m] == 0) v = 0.f;
                     }
-                    g.C[(size_t)m * a.ldc + oc] = v;
                 }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rc, vc, rk(r) * row_c, 0);
             }
         }
     } else {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int n = n0 + wn * 64 + nt * 32 + l31;
-            if (n >= g.N) continue;
+            const bool nv = n < g.N;
             float bias = 0.f;
-            if constexpr (EPI != EPI_NONE) bias = g.bias[n];
+            if constexpr (EPI != EPI_NONE) bias = nv ? g.bias[n] : 0.f;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
+                const int mrow = m0 + wm * 64 + mt * 32 + 4 * hi;
+                const uint32_t vc = nv ? (uint32_t)mrow * row_c + (uint32_t)n * 4u : kOob;
+                float rr[16];
+                if constexpr (EPI == EPI_BIAS_RES) {
+                    const uint32_t vr = nv ? (uint32_t)mrow * row_r + (uint32_t)n * 4u : kOob;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        rr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, vr, rk(r) * row_r, 0));
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (m < a.M) {
-                        float v = acc[mt][nt][r] + bias;
-                        if constexpr (EPI == EPI_BIAS) {
-                            if (g.act == 1) v = sigmoidf_(v);
-                            if (g.mask != nullptr && g.mask[m] == 0) v = 0.f;
-                        } else if constexpr (EPI == EPI_BIAS_SILU) {
-                            v = v * sigmoidf_(v);
-                        } else if constexpr (EPI == EPI_BIAS_RES) {
-                            v = g.res[(size_t)m * a.ldr + n] + a.alpha * v;
+                    float v = acc[mt][nt][r] + bias;
+                    if constexpr (EPI == EPI_BIAS) {
+                        if (g.act == 1) v = sigmoidf_(v);
+                        if (g.mask != nullptr) {
+                            const int m = mrow + (int)rk(r);
+                            if (m < a.M && g.mask[m] == 0) v = 0.f;
                         }
-                        g.C[(size_t)m * a.ldc + n] = v;
+                    } else if constexpr (EPI == EPI_BIAS_SILU) {
+                        v = v * sigmoidf_(v);
+                    } else if constexpr (EPI == EPI_BIAS_RES) {
+                        v = rr[r] + a.alpha * v;
                     }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rc, vc, rk(r) * row_c, 0);
                 }
             }
         }
