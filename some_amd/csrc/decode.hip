@@ -5,7 +5,7 @@
 // Integer results must be bit-exact with the reference's CPU path, so every floating-point reduction whose
 // result feeds an integer decision is done in the reference's order and precision:
 //   * bounds.cumsum(): torch-CPU accumulates fp32 cumsum in fp64 and rounds each prefix to fp32 -> a
-//     sequential fp64 scan by one lane (T = 2584 -> ~10 us, one workgroup per clip, clips in parallel);
+//     sequential fp64 scan by one lane out of LDS (one workgroup per clip, clips in parallel);
 //   * .round(): round-half-even (rintf);
 //   * the weighted mean over the <= 7-bin window and the per-note value sum: sequential fp32 in ascending
 //     index / frame order, separate multiply and add (__fmul_rn / __fadd_rn: no FMA contraction);
@@ -71,77 +71,189 @@ __global__ __launch_bounds__(256) void decode_frames_kernel(FrameArgs a) {
 }
 
 // ---- stage B + C: one workgroup per clip ------------------------------------------------------------
-constexpr int SCAN_TILE = 4096;
+// decode_bounds_to_alignment (infer_utils.py:27-39).  Only the fp64 prefix sum has to be sequential to be
+// bit-identical with torch-CPU's cumsum; it runs as ONE dependent v_add_f64 per frame on lane 0 over LDS-resident
+// doubles.  Everything downstream - fp32 cast, round-half-even, diff > 0, the integer cumsum of the increments
+// (an exact, order-free workgroup scan) and the note-start compaction - is done by all 256 threads.
+// Clips of up to CAP frames (47 s at hop 512 / 44.1 kHz) keep every per-frame array in LDS for the note phase;
+// longer clips stream through the same tiles and spill frame2item / note starts to the global scratch.
+constexpr int CAP = 4096;
+constexpr int PER = CAP / 256;     // frames per thread in the parallel phases
+
+struct ClipLds {
+    double acc[CAP];       // masked bounds as fp64, overwritten in place by their running sum
+    float val[CAP];
+    int f2i[CAP];
+    int start[CAP];
+    uint8_t flg[CAP];      // bit 0: frame unmasked, bit 1: rest
+    int hist[4][128];
+    int wsum[4];
+    double carry_acc;
+    float carry_step;
+    int carry_cnt, nmax, n_long;
+};
 
 __global__ __launch_bounds__(256) void decode_notes_kernel(DecodeArgs a, const float* __restrict__ values,
                                                             const uint8_t* __restrict__ rest,
                                                             int32_t* __restrict__ f2i_s, int32_t* __restrict__ start_s) {
-    __shared__ float sb[SCAN_TILE];
-    __shared__ uint8_t sm[SCAN_TILE];
-    __shared__ int hist[4][128];
-    __shared__ int s_nnotes, s_nmax;
-    __shared__ double s_acc;
-    __shared__ long long s_prev_step;
-    __shared__ int s_cur;
+    __shared__ ClipLds L;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = a.frame_offsets[b];
     const int T = a.frame_offsets[b + 1] - f0;
-    const float* __restrict__ bounds = a.bounds + f0;
-    const uint8_t* __restrict__ mask = a.mask ? a.mask + f0 : nullptr;
-    int32_t* __restrict__ f2i = f2i_s + f0;          // masked frame2item (0 for masked frames)
-    int32_t* __restrict__ nstart = start_s + f0;      // nstart[n-1] = first frame of note n (unmasked scan)
-
-    if (tid == 0) { s_acc = 0.0; s_prev_step = -1; s_cur = 0; s_nmax = 0; }
+    const bool in_lds = T <= CAP;
+    int* f2i_g = f2i_s + f0;          // used when the clip does not fit in LDS
+    int* start_g = start_s + f0;
+    if (tid == 0) { L.carry_acc = 0.0; L.carry_step = -1.0f; L.carry_cnt = 0; L.nmax = 0; }
     __syncthreads();
-    // infer_utils.py:27-39 on bounds * masks
-    for (int t0 = 0; t0 < T; t0 += SCAN_TILE) {
-        const int nt = min(SCAN_TILE, T - t0);
+
+    for (int t0 = 0; t0 < T; t0 += CAP) {
+        const int nt = min(CAP, T - t0);
+        // (1) parallel: bounds * masks -> fp64; flags; values
         for (int i = tid; i < nt; i += 256) {
-            const bool on = mask == nullptr || mask[t0 + i] != 0;
-            sb[i] = on ? bounds[t0 + i] : 0.f;
-            sm[i] = on ? 1 : 0;
+            const int t = f0 + t0 + i;
+            const bool on = a.mask == nullptr || a.mask[t] != 0;
+            L.acc[i] = on ? (double)a.bounds[t] : 0.0;                  // bounds *= masks (me_infer.py:83)
+            L.flg[i] = (on ? 1 : 0) | (rest[t] ? 2 : 0);
+            L.val[i] = values[t];
         }
         __syncthreads();
+        // (2) sequential fp64 prefix sum (the only order-dependent step)
         if (tid == 0) {
-            double acc = s_acc;
-            long long prev = s_prev_step;
-            int cur = s_cur, nmax = s_nmax;
-            for (int i = 0; i < nt; ++i) {
-                acc += (double)sb[i];
-                const long long step = (long long)rintf((float)acc);
-                if (step - prev > 0) { nstart[cur] = t0 + i; ++cur; }
-                prev = step;
-                const int item = sm[i] ? cur : 0;                          // ... * masks (me_infer.py:84)
-                f2i[t0 + i] = item;
+            double acc = L.carry_acc;
+            for (int i = 0; i < nt; i += 8) {
+                double x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = (i + j < nt) ? L.acc[i + j] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { acc += x[j]; x[j] = acc; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (i + j < nt) L.acc[i + j] = x[j];
+            }
+            L.carry_acc = acc;
+        }
+        __syncthreads();
+        // (3) parallel: step = round_half_even((float)acc); inc = step - step_prev > 0; frame2item = cumsum(inc)
+        const int base = tid * PER;
+        int inc_bits = 0, local = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = base + j;
+            if (i < nt) {
+                const float step = rintf((float)L.acc[i]);
+                const float prev = i > 0 ? rintf((float)L.acc[i - 1]) : L.carry_step;
+                if (step - prev > 0.f) { inc_bits |= 1 << j; ++local; }
+            }
+        }
+        int incl = local;                                               // inclusive scan across the workgroup
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) L.wsum[wave] = incl;
+        __syncthreads();
+        int offset = L.carry_cnt + incl - local;
+        for (int w = 0; w < wave; ++w) offset += L.wsum[w];
+        int nmax = 0;
+        int cur = offset;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = base + j;
+            if (i < nt) {
+                if (inc_bits & (1 << j)) {
+                    if (in_lds) L.start[cur] = i; else start_g[cur] = t0 + i;
+                    ++cur;
+                }
+                const int item = (L.flg[i] & 1) ? cur : 0;              // ... * masks (me_infer.py:84)
+                if (in_lds) L.f2i[i] = item; else f2i_g[t0 + i] = item;
+                if (a.frame2item != nullptr) a.frame2item[f0 + t0 + i] = item;
                 nmax = max(nmax, item);
             }
-            s_acc = acc; s_prev_step = prev; s_cur = cur; s_nmax = nmax;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+        if (lane == 0) atomicMax(&L.nmax, nmax);
+        __syncthreads();
+        if (tid == 0) {
+            L.carry_cnt += L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3];
+            L.carry_step = rintf((float)L.acc[nt - 1]);
         }
         __syncthreads();
     }
-    if (tid == 0) { s_nnotes = s_cur; a.n_notes[b] = s_nmax; }
+    const int n_scan = L.carry_cnt;  // notes found by the scan
+    const int n_out = L.nmax;        // space - 1 = frame2item.max() (infer_utils.py:52)
+    if (tid == 0) a.n_notes[b] = n_out;
+
+    // infer_utils.py:42-76.  Notes are mostly a handful of frames: one THREAD per short note (mode of the rounded
+    // values by pairwise counting, no histogram), one WAVE per long note (LDS histogram + wavefront argmax).
+    const int* f2i = in_lds ? L.f2i : f2i_g;
+    const int* nstart = in_lds ? L.start : start_g;
+    auto frame_ok = [&](int t, int n) {      // frame belongs to note n and counts (masks_eff = ~rest & masks)
+        if (f2i[t] != n) return false;
+        return in_lds ? (L.flg[t] & 2) == 0 : rest[f0 + t] == 0;
+    };
+    auto frame_val = [&](int t) { return in_lds ? L.val[t] : values[f0 + t]; };
+    auto finish = [&](int n, int ts, int te, int center_bin, int dur, int unm) {
+        // mean of the values within +-0.5 of the mode, summed in ascending frame order like CPU scatter_add
+        const float center = (float)center_bin;
+        const float lo = __fsub_rn(center, 0.5f), hi2 = __fadd_rn(center, 0.5f);
+        int valid = 0;
+        long long iacc = 0;
+        float facc = 0.f;
+        for (int t = ts; t < te; ++t) {
+            if (!frame_ok(t, n)) continue;
+            const float v = frame_val(t);
+            if (v >= lo && v <= hi2) {
+                ++valid;
+                if (a.quantized) iacc += (long long)v; else facc = __fadd_rn(facc, v);
+            }
+        }
+        const float denom = (float)(valid + (valid == 0 ? 1 : 0));
+        a.note_midi[f0 + n - 1] = __fdiv_rn(a.quantized ? (float)iacc : facc, denom);
+        a.note_dur[f0 + n - 1] = dur;
+        // item_masks = unmasked / dur >= 0.5 in fp32 (int64 / int64 true-divide -> fp32); 0/0 = nan -> False
+        const bool keep = dur > 0 && __fdiv_rn((float)unm, (float)dur) >= 0.5f;
+        a.note_rest[f0 + n - 1] = keep ? 0 : 1;
+    };
+    constexpr int SHORT = 24;
+    if (tid == 0) L.n_long = 0;
     __syncthreads();
-    const int n_scan = s_nnotes;     // notes found by the scan
-    const int n_out = s_nmax;        // space - 1 = frame2item.max() (infer_utils.py:52)
-
-    if (a.frame2item != nullptr)
-        for (int t = tid; t < T; t += 256) a.frame2item[f0 + t] = f2i[t];
-
-    // infer_utils.py:42-76: one wave per note
-    for (int n = 1 + wave; n <= n_out; n += 4) {
+    for (int n = 1 + tid; n <= n_out; n += 256) {
         const int ts = nstart[n - 1];
         const int te = (n < n_scan) ? nstart[n] : T;
-        hist[wave][lane] = 0;
-        hist[wave][lane + 64] = 0;
+        if (te - ts > SHORT) {                                        // defer to the wave-cooperative path
+            const int slot = atomicAdd(&L.n_long, 1);
+            if (slot < CAP) {
+                L.start[CAP - 1 - slot] = n;                          // long-note list grows down from the end of L.start
+                continue;                                             // (cannot collide: a long note spans > SHORT frames)
+            }                                                         // > CAP long notes in one clip: stay on this thread
+        }
+        int dur = 0, unm = 0, best_cnt = 0, best_bin = 0;
+        for (int t = ts; t < te; ++t) {
+            if (f2i[t] != n) continue;
+            ++dur;
+            if (!frame_ok(t, n)) continue;
+            ++unm;
+            const int vq = (int)rintf(frame_val(t)) & 127;
+            int cnt = 0;
+            for (int u = ts; u < te; ++u)
+                if (frame_ok(u, n) && (((int)rintf(frame_val(u))) & 127) == vq) ++cnt;
+            if (cnt > best_cnt || (cnt == best_cnt && vq < best_bin)) { best_cnt = cnt; best_bin = vq; }   // first max
+        }
+        finish(n, ts, te, best_cnt > 0 ? best_bin : 0, dur, unm);
+    }
+    __syncthreads();
+    const int n_long = min(L.n_long, CAP);
+    for (int k = wave; k < n_long; k += 4) {
+        const int n = L.start[CAP - 1 - k];
+        const int ts = nstart[n - 1];
+        const int te = (n < n_scan) ? nstart[n] : T;
+        L.hist[wave][lane] = 0;
+        L.hist[wave][lane + 64] = 0;
         int dur = 0, unm = 0;
         for (int t = ts + lane; t < te; t += 64) {
             if (f2i[t] == n) {
                 ++dur;
-                const bool on = rest[f0 + t] == 0;                      // masks_eff = ~rest & masks (frame is unmasked here)
-                if (on) {
+                if (frame_ok(t, n)) {
                     ++unm;
-                    const int vq = (int)rintf(values[f0 + t]);
-                    atomicAdd(&hist[wave][vq & 127], 1);
+                    atomicAdd(&L.hist[wave][((int)rintf(frame_val(t))) & 127], 1);
                 }
             }
         }
@@ -149,42 +261,14 @@ __global__ __launch_bounds__(256) void decode_notes_kernel(DecodeArgs a, const f
         for (int o = 32; o > 0; o >>= 1) { dur += __shfl_xor(dur, o, 64); unm += __shfl_xor(unm, o, 64); }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        // first-max argmax of the 128-bin histogram
-        int hv = hist[wave][lane], hi_ = lane;
-        { const int h2 = hist[wave][lane + 64]; if (h2 > hv) { hv = h2; hi_ = lane + 64; } }
+        int hv = L.hist[wave][lane], hi_ = lane;                      // first-max argmax of the 128-bin histogram
+        { const int h2 = L.hist[wave][lane + 64]; if (h2 > hv) { hv = h2; hi_ = lane + 64; } }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const int ov = __shfl_xor(hv, o, 64), oi = __shfl_xor(hi_, o, 64);
             if (ov > hv || (ov == hv && oi < hi_)) { hv = ov; hi_ = oi; }
         }
-        if (lane == 0) {
-            const float center = (float)hi_;
-            const float lo = __fsub_rn(center, 0.5f), hi2 = __fadd_rn(center, 0.5f);
-            int valid = 0;
-            float item_value;
-            if (a.quantized) {
-                long long acc = 0;
-                for (int t = ts; t < te; ++t)
-                    if (f2i[t] == n && rest[f0 + t] == 0) {
-                        const float v = values[f0 + t];
-                        if (v >= lo && v <= hi2) { ++valid; acc += (long long)v; }
-                    }
-                item_value = __fdiv_rn((float)acc, (float)(valid + (valid == 0 ? 1 : 0)));
-            } else {
-                float acc = 0.f;
-                for (int t = ts; t < te; ++t)
-                    if (f2i[t] == n && rest[f0 + t] == 0) {
-                        const float v = values[f0 + t];
-                        if (v >= lo && v <= hi2) { ++valid; acc = __fadd_rn(acc, v); }
-                    }
-                item_value = __fdiv_rn(acc, (float)(valid + (valid == 0 ? 1 : 0)));
-            }
-            a.note_midi[f0 + n - 1] = item_value;
-            a.note_dur[f0 + n - 1] = dur;
-            // item_masks = unmasked / dur >= 0.5 in fp32 (int64 / int64 true-divide -> fp32); 0/0 = nan -> False
-            const bool keep = dur > 0 && __fdiv_rn((float)unm, (float)dur) >= 0.5f;
-            a.note_rest[f0 + n - 1] = keep ? 0 : 1;
-        }
+        if (lane == 0) finish(n, ts, te, hi_, dur, unm);
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -201,13 +201,14 @@ def test_decode_vs_oracle_bit_exact_batch_and_mask():
     cfg = get_config('midi_conformer', lay=0)
     eng = Engine(cfg, device='cuda')
     rng = np.random.default_rng(17)
-    lens = [300, 1, 45, 2584, 130]
+    lens = [300, 1, 45, 2584, 130, 4096, 5003]          # 5003 > the decoder's LDS-resident clip capacity
     probs, bounds, masks = [], [], []
     for t in lens:
         centers = np.repeat(rng.uniform(30, 90, t // 15 + 1), 15)[:t] + rng.standard_normal(t) * 0.4
         bump = np.exp(-0.5 * (np.arange(128)[None] - centers[:, None]) ** 2) * rng.uniform(0.02, 1.0, (t, 1))
         probs.append((bump + rng.uniform(0, 0.01, (t, 128))).astype(np.float32))
-        bounds.append((rng.uniform(0, 1, t) ** 5).astype(np.float32))
+        # every other clip: sparse boundaries -> notes of 50-300 frames (the decoder's wave-per-note path)
+        bounds.append((rng.uniform(0, 1, t) ** (5 if len(bounds) % 2 == 0 else 60)).astype(np.float32))
         m = np.ones(t, dtype=bool)
         if t > 40:
             m[t - 7:] = False
