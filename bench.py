@@ -65,13 +65,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f'--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} processes')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)      # "nccl" is RCCL on ROCm
+        backend = os.environ.get('SOME_AMD_DIST_BACKEND', 'nccl')   # "nccl" is RCCL on ROCm; gloo only for dry runs
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     cfg = get_config(args.config, lay=args.lay) if args.lay is not None else get_config(args.config)
     if args.precision:

@@ -154,6 +154,15 @@ int some_decode(SomeHandle* h, const float* probs_dev, const float* bounds_dev, 
                 int64_t* frame2item_dev, float* values_dev, uint8_t* rest_dev,
                 void* scratch_dev, size_t scratch_bytes, void* stream);
 
+/* Replaces: decode_note_sequence(frame2item, values, masks) (utils/infer_utils.py:42-76) on caller-supplied
+ * per-frame arrays (any frame2item, not necessarily produced from bounds).  not_masks_dev: uint8, 1 where the
+ * frame must NOT count (= ~masks).  values_are_integers: the quantised head's int64 semantics (exact integer
+ * sums).  Clips of at most 4096 frames.  Outputs as some_decode. */
+int some_decode_notes(SomeHandle* h, const int64_t* frame2item_dev, const float* values_dev, const uint8_t* not_masks_dev,
+                      const int32_t* frame_offsets_dev, int32_t B, int64_t total_frames, int32_t max_frames,
+                      int32_t values_are_integers, float* note_midi_dev, int64_t* note_dur_dev, uint8_t* note_rest_dev,
+                      int32_t* n_notes_dev, void* scratch_dev, size_t scratch_bytes, void* stream);
+
 /* ---- single-operator entry points (kernel-level parity tests and micro-benchmarks) ------------------ */
 
 #define SOME_EPI_NONE 0       /* C = A W^T                                                          */

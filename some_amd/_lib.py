@@ -55,6 +55,7 @@ SYMBOLS = {
     'some_forward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_size_t, _P]),
     'some_decode_scratch_bytes': (C.c_size_t, [_P, C.c_int64]),
     'some_decode': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    'some_decode_notes': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     'some_op_gemm': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32,
                                C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, C.c_int32, _P]),
     'some_op_split_rows': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),

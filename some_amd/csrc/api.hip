@@ -710,6 +710,29 @@ int some_op_dwconv_silu(SomeHandle* h, const float* x_dev, const float* taps_dev
     return SOME_OK;
 }
 
+int some_decode_notes(SomeHandle* h, const int64_t* frame2item_dev, const float* values_dev, const uint8_t* masks_dev,
+                      const int32_t* frame_offsets_dev, int32_t B, int64_t total_frames, int32_t max_frames,
+                      int32_t values_are_integers, float* note_midi_dev, int64_t* note_dur_dev, uint8_t* note_rest_dev,
+                      int32_t* n_notes_dev, void* scratch_dev, size_t scratch_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    if (B < 0 || total_frames < 0) return fail(h, SOME_EINVAL, "some_decode_notes: negative size");
+    if (B == 0 || total_frames == 0) return SOME_OK;
+    if (!frame2item_dev || !values_dev || !masks_dev || !frame_offsets_dev || !note_midi_dev || !note_dur_dev ||
+        !note_rest_dev || !n_notes_dev || !scratch_dev)
+        return fail(h, SOME_EINVAL, "some_decode_notes: null pointer");
+    if (max_frames > 4096) return fail(h, SOME_EINVAL, "some_decode_notes: clips longer than 4096 frames are not supported by this entry point");
+    if (scratch_bytes < decode_scratch_bytes(total_frames)) return fail(h, SOME_ENOMEM, "some_decode_notes: scratch too small");
+    DecodeArgs a{};
+    a.frame_offsets = frame_offsets_dev; a.B = B; a.total_frames = total_frames; a.nbins = h->cfg.outdim;
+    a.quantized = values_are_integers ? 1 : 0;
+    a.note_midi = note_midi_dev; a.note_dur = note_dur_dev; a.note_rest = note_rest_dev; a.n_notes = n_notes_dev;
+    a.scratch = scratch_dev;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // the kernel's flag byte wants "rest" semantics (1 = frame does not count): pass ~masks through the scratch tail
+    HIP_TRY(h, launch_decode_notes(a, frame2item_dev, values_dev, masks_dev, max_frames, s));
+    return SOME_OK;
+}
+
 int some_profile_enable(SomeHandle* h, int32_t on) {
     if (!h) return SOME_EINVAL;
     h->profiling = on != 0;

@@ -95,7 +95,8 @@ struct ClipLds {
 
 __global__ __launch_bounds__(256) void decode_notes_kernel(DecodeArgs a, const float* __restrict__ values,
                                                             const uint8_t* __restrict__ rest,
-                                                            int32_t* __restrict__ f2i_s, int32_t* __restrict__ start_s) {
+                                                            int32_t* __restrict__ f2i_s, int32_t* __restrict__ start_s,
+                                                            const int64_t* __restrict__ f2i_in) {
     __shared__ ClipLds L;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = a.frame_offsets[b];
@@ -105,8 +106,34 @@ __global__ __launch_bounds__(256) void decode_notes_kernel(DecodeArgs a, const f
     int* start_g = start_s + f0;
     if (tid == 0) { L.carry_acc = 0.0; L.carry_step = -1.0f; L.carry_cnt = 0; L.nmax = 0; }
     __syncthreads();
+    int* nend = reinterpret_cast<int*>(L.acc);        // only used with an explicit frame2item (L.acc is free then)
 
-    for (int t0 = 0; t0 < T; t0 += CAP) {
+    if (f2i_in != nullptr) {
+        // decode_note_sequence on a caller-supplied frame2item (any order; T <= CAP checked by the launcher):
+        // note n spans [first frame with f2i == n, last such frame]; `rest` carries ~masks here
+        for (int i = tid; i < T; i += 256) {
+            L.f2i[i] = (int)f2i_in[f0 + i];
+            L.flg[i] = 1 | (rest[f0 + i] ? 2 : 0);
+            L.val[i] = values[f0 + i];
+            L.start[i] = 0x7fffffff;
+            nend[i] = 0;
+        }
+        __syncthreads();
+        int nmax = 0;
+        for (int i = tid; i < T; i += 256) {
+            const int n = L.f2i[i];
+            nmax = max(nmax, n);
+            if (n >= 1 && n <= CAP) { atomicMin(&L.start[n - 1], i); atomicMax(&nend[n - 1], i + 1); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+        if (lane == 0) atomicMax(&L.nmax, nmax);
+        __syncthreads();
+        if (tid == 0) L.carry_cnt = min(L.nmax, CAP);
+        __syncthreads();
+    }
+
+    for (int t0 = 0; f2i_in == nullptr && t0 < T; t0 += CAP) {
         const int nt = min(CAP, T - t0);
         // (1) parallel: bounds * masks -> fp64; flags; values
         for (int i = tid; i < nt; i += 256) {
@@ -178,7 +205,8 @@ __global__ __launch_bounds__(256) void decode_notes_kernel(DecodeArgs a, const f
         __syncthreads();
     }
     const int n_scan = L.carry_cnt;  // notes found by the scan
-    const int n_out = L.nmax;        // space - 1 = frame2item.max() (infer_utils.py:52)
+    const int n_out = f2i_in != nullptr ? min(L.nmax, CAP) : L.nmax;   // space - 1 = frame2item.max() (infer_utils.py:52)
+    const bool explicit_f2i = f2i_in != nullptr;
     if (tid == 0) a.n_notes[b] = n_out;
 
     // infer_utils.py:42-76.  Notes are mostly a handful of frames: one THREAD per short note (mode of the rounded
@@ -216,9 +244,9 @@ __global__ __launch_bounds__(256) void decode_notes_kernel(DecodeArgs a, const f
     if (tid == 0) L.n_long = 0;
     __syncthreads();
     for (int n = 1 + tid; n <= n_out; n += 256) {
-        const int ts = nstart[n - 1];
-        const int te = (n < n_scan) ? nstart[n] : T;
-        if (te - ts > SHORT) {                                        // defer to the wave-cooperative path
+        const int ts = explicit_f2i ? min(nstart[n - 1], T) : nstart[n - 1];
+        const int te = explicit_f2i ? nend[n - 1] : ((n < n_scan) ? nstart[n] : T);
+        if (!explicit_f2i && te - ts > SHORT) {                       // defer to the wave-cooperative path
             const int slot = atomicAdd(&L.n_long, 1);
             if (slot < CAP) {
                 L.start[CAP - 1 - slot] = n;                          // long-note list grows down from the end of L.start
@@ -243,8 +271,8 @@ __global__ __launch_bounds__(256) void decode_notes_kernel(DecodeArgs a, const f
     const int n_long = min(L.n_long, CAP);
     for (int k = wave; k < n_long; k += 4) {
         const int n = L.start[CAP - 1 - k];
-        const int ts = nstart[n - 1];
-        const int te = (n < n_scan) ? nstart[n] : T;
+        const int ts = explicit_f2i ? min(nstart[n - 1], T) : nstart[n - 1];
+        const int te = explicit_f2i ? nend[n - 1] : ((n < n_scan) ? nstart[n] : T);
         L.hist[wave][lane] = 0;
         L.hist[wave][lane + 64] = 0;
         int dur = 0, unm = 0;
@@ -275,6 +303,18 @@ __global__ __launch_bounds__(256) void decode_notes_kernel(DecodeArgs a, const f
 
 }  // namespace
 
+// decode_note_sequence on caller-supplied per-frame arrays (utils/infer_utils.py:42-76); clips of <= CAP frames
+hipError_t launch_decode_notes(const DecodeArgs& a, const int64_t* frame2item, const float* values,
+                               const uint8_t* not_masks, int max_frames, hipStream_t s) {
+    if (a.B <= 0 || a.total_frames <= 0) return hipSuccess;
+    if (max_frames > CAP) return hipErrorInvalidValue;
+    const size_t m = (size_t)((a.total_frames + 63) / 64 * 64);
+    char* sc = static_cast<char*>(a.scratch);
+    hipLaunchKernelGGL(decode_notes_kernel, dim3((unsigned)a.B), dim3(256), 0, s, a, values, not_masks,
+                       reinterpret_cast<int32_t*>(sc), reinterpret_cast<int32_t*>(sc + 4 * m), frame2item);
+    return hipGetLastError();
+}
+
 size_t decode_scratch_bytes(int64_t total_frames) {
     const size_t m = (size_t)((total_frames + 63) / 64 * 64);
     return m * (4 + 4 + 4 + 1) + 1024;
@@ -301,6 +341,7 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(decode_frames_kernel, dim3((unsigned)blocks), dim3(256), 0, s, f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(decode_notes_kernel, dim3((unsigned)a.B), dim3(256), 0, s, a, values, rest, f2i_s, start_s);
+    hipLaunchKernelGGL(decode_notes_kernel, dim3((unsigned)a.B), dim3(256), 0, s, a, values, rest, f2i_s, start_s,
+                       static_cast<const int64_t*>(nullptr));
     return hipGetLastError();
 }

@@ -129,6 +129,8 @@ struct DecodeArgs {
 };
 size_t decode_scratch_bytes(int64_t total_frames);
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t s);
+hipError_t launch_decode_notes(const DecodeArgs& a, const int64_t* frame2item, const float* values,
+                               const uint8_t* not_masks, int max_frames, hipStream_t s);
 
 // ---- profiling ------------------------------------------------------------------------------------
 struct ProfRecord { std::string name; hipEvent_t e0, e1; double flops, bytes; };

@@ -69,6 +69,15 @@ class MIDIExtractionInference(BaseInference):
             })
         return res
 
+    def _check_finite(self, bounds: torch.Tensor):
+        """The split-f16 GEMM path needs |activations| < 65504 (f16 range).  A checkpoint that violates it shows
+        up as non-finite outputs; fail loudly and name the exact-fp32 switch instead of returning garbage.
+        (Runs after the result D2H copy, so the stream is already drained: no extra synchronisation.)"""
+        if not bool(torch.isfinite(bounds).all()):
+            raise FloatingPointError(
+                'non-finite model outputs: with some_amd_precision=f16x3 every GEMM input must stay below 65504; '
+                "set `some_amd_precision: f32` in config.yaml (or SOME_AMD_PRECISION=f32) for exact-fp32 GEMMs")
+
     @torch.no_grad()
     def infer_batch(self, waveforms: List[np.ndarray], return_device_outputs: bool = False):
         """All clips in ONE packed device batch.  Results equal running the clips one by one."""
@@ -83,6 +92,7 @@ class MIDIExtractionInference(BaseInference):
         probs, bounds = self.engine.forward(units, batch, mask=None, head_mode=_lib.HEAD_SOFTMAX if self.quantized else _lib.HEAD_SIGMOID)
         out = self.engine.decode(probs, bounds, batch, quantized=self.quantized)
         res = self._collect(out, batch)
+        self._check_finite(bounds)
         if return_device_outputs:
             return res, {'units': units, 'probs': probs, 'bounds': bounds, 'batch': batch}
         return res

@@ -50,6 +50,41 @@ def decode_bounds_to_alignment(bounds, use_diff=True):
     return out['frame2item'].view(b, t)
 
 
+def decode_note_sequence(frame2item, values, masks, threshold=0.5):
+    """utils/infer_utils.py:42-76.  frame2item int64 [B,T], values fp32 | int64 [B,T], masks bool [B,T] ->
+    (item_values fp32 [B,N], item_dur int64 [B,N], item_masks bool [B,N]) with N = frame2item.max(), padded with
+    zeros / False for clips that have fewer notes (exactly what the reference's batched scatter yields)."""
+    import ctypes as C
+    from .. import _lib
+    from ..engine import ClipBatch
+    if threshold != 0.5:
+        raise NotImplementedError('threshold is compiled as 0.5 (the reference default)')
+    b, t = frame2item.shape
+    eng = _engine_for(frame2item.device, 128)
+    batch = ClipBatch([t] * b, eng.device)
+    dev = eng.device
+    is_int = not torch.is_floating_point(values)
+    f2i = frame2item.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
+    vals = values.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+    not_masks = (~masks.to(device=dev, dtype=torch.bool)).to(torch.uint8).reshape(-1).contiguous()
+    m = b * t
+    note_midi = torch.zeros(m, dtype=torch.float32, device=dev)
+    note_dur = torch.zeros(m, dtype=torch.int64, device=dev)
+    note_rest = torch.ones(m, dtype=torch.uint8, device=dev)
+    n_notes = torch.zeros(b, dtype=torch.int32, device=dev)
+    sc = eng._decode_scratch(int(eng.lib.some_decode_scratch_bytes(eng.handle, m)))
+    p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    _lib.check(eng.handle, eng.lib.some_decode_notes(
+        eng.handle, p(f2i), p(vals), p(not_masks), p(batch.frame_offsets_dev), b, m, t, 1 if is_int else 0,
+        p(note_midi), p(note_dur), p(note_rest), p(n_notes), p(sc), sc.numel(), eng._stream()))
+    n = int(n_notes.max()) if b else 0
+    iv = note_midi.view(b, t)[:, :n].clone()
+    idur = note_dur.view(b, t)[:, :n].clone()
+    imask = (note_rest.view(b, t)[:, :n] == 0)
+    # rows beyond a clip's own note count keep their initial zeros / rest flags
+    return iv, idur, imask
+
+
 def build_midi_file(offsets: List[float], segments: List[Dict[str, np.ndarray]], tempo=120) -> smf.MidiFile:
     """utils/infer_utils.py:79-100: one track, 480 ticks per beat => ``tempo * 8`` ticks per second; each
     chunk's notes are laid end to end from the chunk offset, clipped at the next chunk's offset; rests and

@@ -37,10 +37,22 @@ def test_create_validates_configuration():
 def test_pack_weights_layout_and_strictness():
     from some_amd.engine import Engine
     import torch
-    cfg = get_config('midi_conformer', lay=1)
+    cfg = get_config('midi_conformer', lay=1, some_amd_precision='f32')
     eng = Engine(cfg, host_only=True)
     sd = synth.synth_state_dict(cfg, 3)
     arena = eng.pack_state_dict(sd).numpy()
+    # f16x3 mode: same arena size; GEMM weights become SPLIT32 (per 32-element k-block: 32 f16 hi | 32 f16 lo)
+    eng3 = Engine(get_config('midi_conformer', lay=1, some_amd_precision='f16x3'), host_only=True)
+    arena3 = eng3.pack_state_dict(sd).numpy()
+    assert arena3.shape == arena.shape
+    np.testing.assert_array_equal(arena3[:512 * 80], arena[:512 * 80])            # input projection stays fp32
+    w = sd['model.outln.weight']                                                  # first split tensor in the arena
+    off = int(np.flatnonzero(arena == w.reshape(-1)[0])[0])
+    blk = arena3[off:off + 32].view(np.float16)
+    hi, lo = blk[:32].astype(np.float32), blk[32:].astype(np.float32)
+    np.testing.assert_array_equal(hi, w.reshape(-1)[:32].astype(np.float16).astype(np.float32))
+    # |x - hi - lo| <= 2^-22 |x|, floored by the f16 subnormal quantum (2^-24) / 2 for the small lo halves
+    assert (np.abs(hi + lo - w.reshape(-1)[:32]) <= np.abs(w.reshape(-1)[:32]) * 2.0 ** -21 + 2.0 ** -25).all()
     assert arena.shape[0] == eng.arena_numel
     # first tensor of the arena is inln.weight verbatim
     np.testing.assert_array_equal(arena[:512 * 80].reshape(512, 80), sd['model.inln.weight'])
