@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int m_tile = (j / n_tiles) * 8 + xcd;
     const int n_tile = j % n_tiles;
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int m0 = a.m_begin + m_tile * BM, n0 = n_tile * BN;
     if (m0 >= a.M || n0 >= g.N) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -224,6 +224,7 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     const int m_tiles8 = (m_tiles + 7) / 8 * 8;
     GemmArgs b = a;
     b.n_tiles = n_tiles;
+    b.m_begin = 0;
     dim3 grid((unsigned)(m_tiles8 * n_tiles), (unsigned)a.groups, 1);
     hipLaunchKernelGGL(gemm_kernel<EPI>, grid, dim3(256), LDS_BYTES, s, b);
     return hipGetLastError();

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int m_tile = (j / n_tiles) * 8 + xcd;
     const int n_tile = j % n_tiles;
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int m0 = a.m_begin + m_tile * BM, n0 = n_tile * BN;
     if (m0 >= a.M || n0 >= g.N) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -290,6 +290,145 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
         epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane);
 }
 
+// ---- ring variant: 128 x 256 tile, 4 waves (2 x 2, each 64 x 128), TWO workgroups per CU -----------------------
+// Ablation of the register-staged 256 x 256 kernel (FFN1 shape): 58 % of its time is the MFMA floor, 20 % exposed
+// staging / fragment traffic, 22 % the epilogue - none of which overlaps anything with one workgroup per CU.
+// Here every workgroup is half as big and two share a CU, so one's epilogue, DMA waits and LDS reads run under
+// the other's MFMAs.  Operands go global -> LDS by DMA (global_load_lds, 16 B per lane: no VGPR round trip, no
+// ds_write) in k-steps of 16 into a 3-stage ring (24 KiB per stage, 72 KiB per workgroup) that is filled two steps
+// ahead behind a COUNTED vmcnt and a raw s_barrier (never drained to 0 in the loop).  LDS rows are 64 unpadded
+// bytes = four 16-byte chunks [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15]; chunk slot p of row r holds logical chunk
+// p ^ ((r >> 2) & 3) - the permutation is applied to the per-lane SOURCE address (the DMA destination is
+// lane-linear) and again on the fragment reads, which makes every ds_read_b128 conflict-free.
+template <int EPI, bool OUT_SPLIT>
+__global__ __launch_bounds__(256, 2) void hgemm3_ring_kernel(GemmArgs a) {
+    constexpr int WAVES_M = 2, WAVES_N = 2, TM = 2, TN = 4;
+    constexpr int NT = 256, BM = 128, BN = 256;
+    constexpr int ROWS = BM + BN;                       // 384 rows x 64 B per stage
+    constexpr int STAGE_B = ROWS * 64;
+    constexpr int NSTAGE = 3;
+    constexpr int NDMA = ROWS * 4 / NT;                 // 6 chunks per thread per step
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* lbase = reinterpret_cast<char*>(lds);
+
+    const GemmGroup g = a.g[blockIdx.y];
+    const int n_tiles = a.n_tiles;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int m_tile = (j / n_tiles) * 8 + xcd;
+    const int n_tile = j % n_tiles;
+    const int m0 = a.m_begin + m_tile * BM, n0 = n_tile * BN;
+    if (m0 >= a.M || n0 >= g.N) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int ns = a.K >> 4;                            // k-steps of 16
+
+    // DMA roles: pass p moves linear chunk L = p * 256 + tid -> LDS byte 16 L = row (L >> 2), slot (L & 3).
+    // Out-of-range rows are clamped to the last valid row (their products are never stored).
+    const char* src[NDMA];
+#pragma unroll
+    for (int p = 0; p < NDMA; ++p) {
+        const int L = p * NT + tid;
+        const int row = L >> 2, slot = L & 3;
+        const int c = slot ^ ((row >> 2) & 3);          // logical chunk: bit 1 = lo half, bit 0 = k 8-15
+        const int coff = (c >> 1) * 64 + (c & 1) * 16;
+        if (row < BM) {
+            const int r = min(m0 + row, a.M - 1);
+            src[p] = reinterpret_cast<const char*>(g.A) + (size_t)r * a.lda * 4 + coff;
+        } else {
+            const int r = min(n0 + row - BM, g.N - 1);
+            src[p] = reinterpret_cast<const char*>(g.W) + (size_t)r * a.K * 4 + coff;
+        }
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto dma = [&](int t) {                             // k-step t -> ring slot t % 3
+        const int koff = (t >> 1) * 128 + (t & 1) * 32;
+        char* stage = lbase + (t % NSTAGE) * STAGE_B;
+#pragma unroll
+        for (int p = 0; p < NDMA; ++p)
+            __builtin_amdgcn_global_load_lds(src[p] + koff, (lds_void*)(uintptr_t)(stage + (p * NT + wave * 64) * 16), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+
+    // fragment addressing: row = tile base (multiple of 32) + l31  ->  swz = (l31 >> 2) & 3 for every tile
+    const int swz = (l31 >> 2) & 3;
+    const int off_hi = (kg ^ swz) * 16, off_lo = ((2 + kg) ^ swz) * 16;
+    const int a_row = (wm * TM * 32 + l31) * 64;
+    const int w_row = (BM + wn * TN * 32 + l31) * 64;
+
+    dma(0);
+    if (ns > 1) dma(1);
+    if (ns > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < ns; ++t) {
+        if (t + 2 < ns) dma(t + 2);                     // slot (t+2) % 3 was last read in step t - 1, before the barrier
+        const char* st = lbase + (t % NSTAGE) * STAGE_B;
+        half8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ah[i] = *reinterpret_cast<const half8*>(st + a_row + i * 32 * 64 + off_hi);
+            al[i] = *reinterpret_cast<const half8*>(st + a_row + i * 32 * 64 + off_lo);
+        }
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            bh[jn] = *reinterpret_cast<const half8*>(st + w_row + jn * 32 * 64 + off_hi);
+            bl[jn] = *reinterpret_cast<const half8*>(st + w_row + jn * 32 * 64 + off_lo);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jn], acc[i][jn], 0, 0, 0);
+        // step t + 1 must have landed (this thread's part); step t + 2 (6 DMAs, just issued) may stay in flight
+        if (t + 2 < ns) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    if (m0 + BM <= a.M && n0 + BN <= g.N)
+        epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, true>(a, g, acc, m0, n0, wm, wn, lane);
+    else
+        epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane);
+}
+
+template <int EPI, bool OUT_SPLIT>
+hipError_t launch_ring(const GemmArgs& a, hipStream_t s) {
+    constexpr int BM = 128, BN = 256;
+    constexpr size_t LDS_BYTES = 3 * (size_t)(BM + BN) * 64;
+    static bool attr_set = false;
+    auto kern = &hgemm3_ring_kernel<EPI, OUT_SPLIT>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int n_max = 0;
+    for (int g = 0; g < a.groups; ++g) n_max = a.g[g].N > n_max ? a.g[g].N : n_max;
+    const int m_tiles = (a.M - a.m_begin + BM - 1) / BM, n_tiles = (n_max + BN - 1) / BN;
+    GemmArgs b = a;
+    b.n_tiles = n_tiles;
+    dim3 grid((unsigned)((m_tiles + 7) / 8 * 8 * n_tiles), (unsigned)a.groups, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, s, b);
+    return hipGetLastError();
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT>
 hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -303,7 +442,7 @@ hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     }
     int n_max = 0;
     for (int g = 0; g < a.groups; ++g) n_max = a.g[g].N > n_max ? a.g[g].N : n_max;
-    const int m_tiles = (a.M + BM - 1) / BM, n_tiles = (n_max + BN - 1) / BN;
+    const int m_tiles = (a.M - a.m_begin + BM - 1) / BM, n_tiles = (n_max + BN - 1) / BN;
     GemmArgs b = a;
     b.n_tiles = n_tiles;
     dim3 grid((unsigned)((m_tiles + 7) / 8 * 8 * n_tiles), (unsigned)a.groups, 1);
@@ -316,16 +455,14 @@ hipError_t launch_epi(const GemmArgs& a, int tile, hipStream_t s) {
     switch (tile) {
         case 0: return launch_cfg<2, 2, 2, 2, EPI, OUT_SPLIT>(a, s);    // 128 x 128, 4 waves
         case 1: return launch_cfg<4, 2, 2, 2, EPI, OUT_SPLIT>(a, s);    // 256 x 128, 8 waves
+        case 3: return launch_ring<EPI, OUT_SPLIT>(a, s);               // 128 x 256, 4 waves, DMA ring, 2 workgroups / CU
         default: return launch_cfg<4, 2, 2, 4, EPI, OUT_SPLIT>(a, s);   // 256 x 256, 8 waves
     }
 }
 
 }  // namespace
 
-hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a, bool out_split, int tile, hipStream_t s) {
-    if (a.M <= 0) return hipSuccess;
-    if ((a.K & 31) || (a.lda & 31)) return hipErrorInvalidValue;
-    if (out_split && epi != EPI_BIAS_SILU) return hipErrorInvalidValue;
+static hipError_t launch_one(GemmEpi epi, const GemmArgs& a, bool out_split, int tile, hipStream_t s) {
     switch (epi) {
         case EPI_NONE: return launch_epi<EPI_NONE, false>(a, tile, s);
         case EPI_BIAS: return launch_epi<EPI_BIAS, false>(a, tile, s);
@@ -333,10 +470,42 @@ hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a, bool out_split, int
         case EPI_BIAS_RES: return launch_epi<EPI_BIAS_RES, false>(a, tile, s);
         case EPI_GLU: return launch_epi<EPI_GLU, false>(a, tile, s);
         case EPI_GLU_RES: return launch_epi<EPI_GLU_RES, false>(a, tile, s);
-        case EPI_QKV:
-            for (int g = 0; g < a.groups; ++g)
-                if (a.g[g].N != 3 * kDim || !a.g[g].C2 || !a.g[g].C3 || (a.g[g].ldv & 255) || a.g[g].ldv < a.M) return hipErrorInvalidValue;
-            return launch_epi<EPI_QKV, false>(a, tile, s);
+        case EPI_QKV: return launch_epi<EPI_QKV, false>(a, tile, s);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a_in, bool out_split, int tile, hipStream_t s) {
+    if (a_in.M <= 0) return hipSuccess;
+    if ((a_in.K & 31) || (a_in.lda & 31)) return hipErrorInvalidValue;
+    if (out_split && epi != EPI_BIAS_SILU) return hipErrorInvalidValue;
+    if (epi == EPI_QKV)
+        for (int g = 0; g < a_in.groups; ++g)
+            if (a_in.g[g].N != 3 * kDim || !a_in.g[g].C2 || !a_in.g[g].C3 || (a_in.g[g].ldv & 255) || a_in.g[g].ldv < a_in.M) return hipErrorInvalidValue;
+    GemmArgs a = a_in;
+    a.m_begin = 0;
+    // Wave quantisation: every workgroup of the 256-row tiles takes the same time and one fits per CU, so a grid
+    // of W workgroups costs ceil(W / 256) rounds (M = 82 688, N = 512: 1292 -> 6 rounds for 5.05 rounds of work).
+    // Launch the largest row range whose workgroup count is a whole number of rounds with the big tile and give
+    // the remaining rows to the 128 x 128 kernel (two workgroups per CU, a quarter of the time each).
+    if (tile >= 2) {
+        const int BM = tile == 3 ? 128 : 256, BN = 256, slots = tile == 3 ? 512 : 256;
+        int n_max = 0;
+        for (int g = 0; g < a.groups; ++g) n_max = a.g[g].N > n_max ? a.g[g].N : n_max;
+        const int per_m = ((n_max + BN - 1) / BN) * a.groups;                 // workgroups per row block
+        int q = slots, x = per_m;                                              // q = slots / gcd(slots, per_m)
+        for (int y = slots; y; ) { const int t = x % y; x = y; y = t; }
+        q = slots / x;
+        const int m_tiles = (a.M + BM - 1) / BM;
+        const int main_tiles = m_tiles / q * q;
+        if (main_tiles > 0 && main_tiles < m_tiles && (long)(m_tiles - main_tiles) * per_m <= slots / 2) {
+            GemmArgs head = a;
+            head.M = main_tiles * BM;                   // rows [0, head.M): full tiles only
+            hipError_t e = launch_one(epi, head, out_split, tile, s);
+            if (e != hipSuccess) return e;
+            a.m_begin = main_tiles * BM;                // rows [m_begin, M) with the small tile
+            return launch_one(epi, a, out_split, 0, s);
+        }
+    }
+    return launch_one(epi, a, out_split, tile, s);
 }

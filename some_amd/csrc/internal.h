@@ -47,6 +47,7 @@ struct GemmArgs {
     int lda, ldc, ldr;
     float alpha;           // EPI_BIAS_RES: C = res + alpha * (acc + bias)
     int n_tiles;           // filled by launch_gemm
+    int m_begin;           // first row of this launch (rows [m_begin, M) are covered); filled by the launcher
 };
 
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
