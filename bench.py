@@ -209,7 +209,10 @@ def main():
         # ---- CPU baseline: the oracle (port of the reference CPU path), bounded sample, rank 0, N = 1 ---
         if world == 1 and not args.no_cpu_baseline:
             from oracle import restate
-            threads = torch.get_num_threads()
+            # B = 1 conformer inference scales poorly past ~32 threads on a 2-socket host (measured on the MI355X
+            # box, 2 x EPYC 9575F: 8 -> 8.2, 16 -> 9.2, 32 -> 10.7, 64 -> 6.9, 128 -> 3.0 audio-s/s): use the best
+            threads = min(32, torch.get_num_threads())
+            torch.set_num_threads(threads)
             sd_t = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
             restate.infer_clip(sd_t, cfg, clips[0][: sr * 2], quantized=quant)            # warm-up (2 s)
             tc = time.perf_counter()
