@@ -27,6 +27,8 @@ class MIDIExtractionInference(BaseInference):
         self.midi_max = self.config['midi_max']
         self.midi_deviation = self.config.get('midi_prob_deviation', 1.0)
         self.rest_threshold = self.config.get('rest_threshold', 0.1)
+        self._pinned = {}
+        self._copy_stream = None
 
     # ---- reference-shaped per-clip API -------------------------------------------------------------
     def preprocess(self, waveform: np.ndarray) -> Dict[str, torch.Tensor]:
@@ -69,45 +71,85 @@ class MIDIExtractionInference(BaseInference):
             })
         return res
 
-    def _check_finite(self, bounds: torch.Tensor):
-        """The split-f16 GEMM path needs |activations| < 65504 (f16 range).  A checkpoint that violates it shows
-        up as non-finite outputs; fail loudly and name the exact-fp32 switch instead of returning garbage.
-        (Runs after the result D2H copy, so the stream is already drained: no extra synchronisation.)"""
-        if not bool(torch.isfinite(bounds).all()):
+    # ---- host ingest pipeline: pinned double buffers, copy stream, deferred D2H ----
+    def _stage(self, waveforms: List[np.ndarray], slot: int):
+        """Pack the clips into a pinned host buffer (one memcpy per clip, no intermediate concatenate) and start the
+        H2D copy on the copy stream.  Returns (audio_dev, batch, ready_event)."""
+        lens = [int(w.shape[0]) for w in waveforms]
+        total = int(sum(lens))
+        batch = ClipBatch.from_sample_counts(lens, self.engine.hop, self.engine.device)
+        pin = self._pinned.get(slot)
+        if pin is None or pin.numel() < total:
+            pin = self._pinned[slot] = torch.empty(max(total, 1), dtype=torch.float32).pin_memory()
+        view = pin.numpy()
+        pos = 0
+        for w, n in zip(waveforms, lens):
+            np.copyto(view[pos:pos + n], w, casting='same_kind')
+            pos += n
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._copy_stream):
+            audio = pin[:total].to(self.device, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self._copy_stream)
+        return audio, batch, ready
+
+    def _launch(self, audio, batch, ready):
+        """Enqueue front end + network + decode for one staged batch on the current stream (no host sync)."""
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ready)
+        audio.record_stream(cur)
+        units = self.engine.logmel(audio, batch)
+        probs, bounds = self.engine.forward(units, batch, mask=None,
+                                            head_mode=_lib.HEAD_SOFTMAX if self.quantized else _lib.HEAD_SIGMOID)
+        out = self.engine.decode(probs, bounds, batch, quantized=self.quantized)
+        finite = torch.isfinite(bounds).all()
+        return out, finite, {'units': units, 'probs': probs, 'bounds': bounds, 'batch': batch}
+
+    def _finish(self, out, finite, batch) -> List[Dict[str, np.ndarray]]:
+        res = self._collect(out, batch)                 # the only host synchronisation of the batch
+        if not bool(finite):
             raise FloatingPointError(
                 'non-finite model outputs: with some_amd_precision=f16x3 every GEMM input must stay below 65504; '
                 "set `some_amd_precision: f32` in config.yaml (or SOME_AMD_PRECISION=f32) for exact-fp32 GEMMs")
+        return res
 
     @torch.no_grad()
     def infer_batch(self, waveforms: List[np.ndarray], return_device_outputs: bool = False):
         """All clips in ONE packed device batch.  Results equal running the clips one by one."""
         if not waveforms:
             return []
-        lens = [int(w.shape[0]) for w in waveforms]
-        batch = ClipBatch.from_sample_counts(lens, self.engine.hop, self.engine.device)
-        flat = np.concatenate([np.ascontiguousarray(w, dtype=np.float32) for w in waveforms]) if len(waveforms) > 1 \
-            else np.ascontiguousarray(waveforms[0], dtype=np.float32)
-        audio = torch.from_numpy(flat).to(self.device, non_blocking=True)
-        units = self.engine.logmel(audio, batch)
-        probs, bounds = self.engine.forward(units, batch, mask=None, head_mode=_lib.HEAD_SOFTMAX if self.quantized else _lib.HEAD_SIGMOID)
-        out = self.engine.decode(probs, bounds, batch, quantized=self.quantized)
-        res = self._collect(out, batch)
-        self._check_finite(bounds)
+        audio, batch, ready = self._stage(waveforms, 0)
+        out, finite, dev = self._launch(audio, batch, ready)
+        res = self._finish(out, finite, batch)
         if return_device_outputs:
-            return res, {'units': units, 'probs': probs, 'bounds': bounds, 'batch': batch}
+            return res, dev
         return res
 
+    @torch.no_grad()
     def infer(self, waveforms: List[np.ndarray]) -> List[Dict[str, np.ndarray]]:
-        """base_infer.py:46-53 semantics, executed as packed batches of at most ``max_batch_frames`` frames."""
-        results: List[Dict[str, np.ndarray]] = []
+        """base_infer.py:46-53 semantics, executed as packed batches of at most ``max_batch_frames`` frames.  While
+        the GPU works on batch i the host packs batch i + 1 into the other pinned buffer and its H2D copy runs on
+        the copy stream; results of batch i are read back after batch i + 1 has been enqueued."""
+        groups: List[List[np.ndarray]] = []
         group, frames = [], 0
         for w in waveforms:
             t = 1 + int(w.shape[0]) // self.engine.hop
             if group and frames + t > self.max_batch_frames:
-                results.extend(self.infer_batch(group))
+                groups.append(group)
                 group, frames = [], 0
             group.append(w)
             frames += t
         if group:
-            results.extend(self.infer_batch(group))
+            groups.append(group)
+        results: List[Dict[str, np.ndarray]] = []
+        pending = None
+        for i, grp in enumerate(groups):
+            audio, batch, ready = self._stage(grp, i & 1)
+            launched = self._launch(audio, batch, ready)
+            if pending is not None:
+                results.extend(self._finish(pending[0], pending[1], pending[2]))
+            pending = (launched[0], launched[1], batch)
+        if pending is not None:
+            results.extend(self._finish(pending[0], pending[1], pending[2]))
         return results
