@@ -49,7 +49,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-latency', action='store_true', help='skip the B=1 p50 latency leg')
-    ap.add_argument('--cpu-clips', type=int, default=2, help='clips in the bounded CPU-baseline sample')
+    ap.add_argument('--no-f32-leg', action='store_true', help='skip the secondary exact-f32 measurement')
+    ap.add_argument('--cpu-clips', type=int, default=4, help='clips in the bounded CPU-baseline sample')
     args = ap.parse_args()
 
     import numpy as np
@@ -206,6 +207,27 @@ def main():
         if lat:
             result['p50_clip_latency_ms'] = round(1e3 * float(np.median(lat[2:])), 3)
 
+        # ---- the same workload in the exact-f32 arithmetic mode (bit-conservative option), for reference ---------
+        if world == 1 and precision_name != 'f32' and not args.no_f32_leg:
+            cfg32 = dict(cfg, some_amd_precision='f32')
+            eng32 = Engine(cfg32, device=device)
+            arena32 = eng32.pack_state_dict(sd).to(device)
+            eng32.attach_arena(arena32)
+
+            def step32():
+                u = eng32.logmel(audio, batch)
+                p, b = eng32.forward(u, batch, head_mode=head)
+                return eng32.decode(p, b, batch, quantized=quant)
+            step32()
+            torch.cuda.synchronize(device)
+            t32 = time.perf_counter()
+            for _ in range(2):
+                step32()
+            torch.cuda.synchronize(device)
+            dt32 = (time.perf_counter() - t32) / 2
+            result['exact_f32_mode'] = {'value': round(args.batch * args.seconds / dt32, 2), 'unit': 'audio-s/s',
+                                        'ms_per_step': round(dt32 * 1e3, 3), 'dtype': 'f32 (v_mfma_f32_32x32x2_f32)'}
+            del eng32, arena32
         # ---- CPU baseline: the oracle (port of the reference CPU path), bounded sample, rank 0, N = 1 ---
         if world == 1 and not args.no_cpu_baseline:
             from oracle import restate
