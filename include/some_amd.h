@@ -176,7 +176,7 @@ int some_decode_notes(SomeHandle* h, const int64_t* frame2item_dev, const float*
  * For the GLU epilogues N counts the packed rows (2 x output width) and C gets N/2 columns. */
 #define SOME_GEMM_SPLIT_IN 1    /* A and W are in SPLIT32 format -> 3-term split-f16 kernel (K % 32 == 0)            */
 #define SOME_GEMM_SPLIT_OUT 2   /* C written in SPLIT32 format (SOME_EPI_BIAS_SILU only)                            */
-#define SOME_GEMM_TILE(t) (((t) & 3) << 8)   /* split kernel tile: 0 = 128x128, 1 = 256x128, 2 = 256x256            */
+#define SOME_GEMM_TILE(t) (((t) & 7) << 8)   /* split kernel tile: 0 = 128x128, 1 = 256x128, 2 = 256x256, 3 = DMA ring 128x256, 4 = 64x128 */
 int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t lda, const float* W_dev,
                  const float* bias_dev, const float* res_dev, int32_t ldr, float* C_dev, int32_t ldc,
                  int32_t M, int32_t N, int32_t K, float alpha, int32_t act, const uint8_t* row_mask_dev,

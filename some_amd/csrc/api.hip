@@ -409,7 +409,8 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
         auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((n_max + bn - 1) / bn) * kStreams; };
         if (blocks(256, 256) >= 512) return 2;       // >= 2 waves of workgroups over 256 CUs
         if (blocks(256, 128) >= 512) return 1;
-        return 0;
+        if (blocks(128, 128) >= 512) return 0;       // 128 x 128 tiles run two per CU
+        return 4;                                    // 64 x 128: single-clip latency regime
     };
     auto launch_any = [&](GemmEpi epi, GemmArgs& a, bool out_split, int n_max) -> hipError_t {
         if (f16x3) return launch_gemm_f16x3(epi, a, out_split, pick_tile(n_max), s);
@@ -631,7 +632,7 @@ int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t ld
     Scope sc(h, s, "op_gemm", 2.0 * M * (double)N * K, 0.0);
     if (flags & SOME_GEMM_SPLIT_IN) {
         if ((K & 31) || (lda & 31)) return fail(h, SOME_EINVAL, "some_op_gemm: SPLIT32 operands need K % 32 == 0 and lda % 32 == 0");
-        HIP_TRY(h, launch_gemm_f16x3(static_cast<GemmEpi>(epilogue), a, (flags & SOME_GEMM_SPLIT_OUT) != 0, (flags >> 8) & 3, s));
+        HIP_TRY(h, launch_gemm_f16x3(static_cast<GemmEpi>(epilogue), a, (flags & SOME_GEMM_SPLIT_OUT) != 0, (flags >> 8) & 7, s));
     } else {
         HIP_TRY(h, launch_gemm(static_cast<GemmEpi>(epilogue), a, s));
     }

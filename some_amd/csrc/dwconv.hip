@@ -14,19 +14,21 @@
 
 namespace {
 
-constexpr int TC = 128;   // output frames per block
+constexpr int TC = 128;   // output frames per block (large batches); small launches use TC_SMALL for more blocks
+constexpr int TC_SMALL = 32;
 constexpr int G = 8;      // outputs per window step
 constexpr int HALO = (kConvK - 1) / 2;
 
+template <int TCV>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
     const int b = blockIdx.z;
     const int g = blockIdx.y >> 1;
     const int c = (blockIdx.y & 1) * 256 + threadIdx.x;
     const int f0 = a.frame_offsets[b];
     const int T = a.frame_offsets[b + 1] - f0;
-    const int t_begin = blockIdx.x * TC;
+    const int t_begin = blockIdx.x * TCV;
     if (t_begin >= T) return;
-    const int t_end = min(t_begin + TC, T);
+    const int t_end = min(t_begin + TCV, T);
     const float* __restrict__ x = a.x[g] + (size_t)f0 * kDim + c;
     float* __restrict__ y = a.y[g] + (size_t)f0 * kDim + c;
 
@@ -78,7 +80,13 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
 
 hipError_t launch_dwconv(const DwArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.max_frames <= 0) return hipSuccess;
-    dim3 grid((unsigned)((a.max_frames + TC - 1) / TC), (unsigned)(2 * a.groups), (unsigned)a.B);
-    hipLaunchKernelGGL(dwconv_kernel, grid, dim3(256), 0, s, a);
+    const long blocks_big = (long)((a.max_frames + TC - 1) / TC) * 2 * a.groups * a.B;
+    if (blocks_big >= 1024) {
+        dim3 grid((unsigned)((a.max_frames + TC - 1) / TC), (unsigned)(2 * a.groups), (unsigned)a.B);
+        hipLaunchKernelGGL(dwconv_kernel<TC>, grid, dim3(256), 0, s, a);
+    } else {    // few clips: shorter time chunks keep all CUs busy (the 30-frame halo is re-read from L2)
+        dim3 grid((unsigned)((a.max_frames + TC_SMALL - 1) / TC_SMALL), (unsigned)(2 * a.groups), (unsigned)a.B);
+        hipLaunchKernelGGL(dwconv_kernel<TC_SMALL>, grid, dim3(256), 0, s, a);
+    }
     return hipGetLastError();
 }

@@ -453,6 +453,7 @@ hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
 template <int EPI, bool OUT_SPLIT>
 hipError_t launch_epi(const GemmArgs& a, int tile, hipStream_t s) {
     switch (tile) {
+        case 4: return launch_cfg<2, 2, 1, 2, EPI, OUT_SPLIT>(a, s);    // 64 x 128, 4 waves (small M: more workgroups)
         case 0: return launch_cfg<2, 2, 2, 2, EPI, OUT_SPLIT>(a, s);    // 128 x 128, 4 waves
         case 1: return launch_cfg<4, 2, 2, 2, EPI, OUT_SPLIT>(a, s);    // 256 x 128, 8 waves
         case 3: return launch_ring<EPI, OUT_SPLIT>(a, s);               // 128 x 256, 4 waves, DMA ring, 2 workgroups / CU

@@ -214,7 +214,7 @@ def test_dwconv_silu(eng, lens):
 
 
 # ---- 3-term split-f16 GEMM (gemm_f16x3.hip) ----------------------------------------------------------
-@pytest.mark.parametrize('tile', [0, 1, 2, 3])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
 @pytest.mark.parametrize('M,N,K', [(128, 128, 32), (300, 512, 512), (257, 1536, 512), (130, 512, 2048), (77, 129, 512), (64, 1, 512), (515, 2048, 512)])
 def test_gemm_f16x3_matches_fp64(eng, M, N, K, tile):
     from some_amd import _lib
@@ -244,7 +244,7 @@ def test_gemm_f16x3_small_magnitudes_need_f16_subnormals(eng):
     assert rel < 2e-5, rel
 
 
-@pytest.mark.parametrize('tile', [0, 2, 3])
+@pytest.mark.parametrize('tile', [0, 2, 3, 4])
 def test_gemm_f16x3_epilogues(eng, tile):
     from some_amd import _lib as L
     g = torch.Generator(device='cuda').manual_seed(50 + tile)
