@@ -112,8 +112,10 @@ int some_mel_filterbank(const SomeHandle* h, float* basis_host);
  * produces T_b = 1 + n_b / hop frames at rows frame_offsets[b]... of units_dev [total_frames, n_mels].
  * sample_offsets_dev / frame_offsets_dev: device int64 / int32 arrays of B+1 entries.
  * max_frames: max_b T_b (host value, sizes the launch). */
+#define SOME_PAD_ZERO 0      /* inference path: F.pad(audio, (win/2, win/2)) zeros        (modules/rmvpe/spec.py:47-50)   */
+#define SOME_PAD_REFLECT 1   /* deployment path: torch.stft(center=True) reflect padding (deployment/base_onnx_module.py:68-76); needs n_b > win/2 */
 int some_logmel(SomeHandle* h, const float* audio_dev, const int64_t* sample_offsets_dev,
-                const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames,
+                const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, int32_t pad_mode,
                 float* units_dev, void* stream);
 
 /* ---- network ------------------------------------------------------------------------------------ */

@@ -318,6 +318,34 @@ def gen_batch_csv():
     print('batch_csv_*.csv')
 
 
+def gen_deploy():
+    """Deployment twin (deployment/base_onnx_module.py:38-79, me_onnx_module.py:23-39): reflect-padded STFT front
+    end and the waveform -> notes forward, executed with the reference's own classes (B = 2)."""
+    sys.modules.setdefault('utils', types.ModuleType('utils'))
+    sys.modules['utils'].build_object_from_class_name = lambda *a, **k: None
+    sys.modules.setdefault('utils.infer_utils', ref_infer_utils)
+    base = _load_file('ref_base_onnx', REF / 'deployment/base_onnx_module.py')
+    cfg = get_config('midi_conformer', lay=2)
+    mel = base.MelSpectrogram_ONNX(n_mel_channels=80, sampling_rate=44100, win_length=2048, hop_length=512, mel_fmin=40, mel_fmax=8000)
+    model = ref_model(cfg, 41)
+    iu = ref_infer_utils
+    w = np.stack([synth.synth_clip(70, 2.0), synth.synth_clip(71, 2.0)])
+    out = {}
+    with torch.no_grad():
+        units = mel(torch.from_numpy(w)).transpose(1, 2)
+        out['units'] = units.numpy().copy()
+        masks = torch.ones(units.shape[:2], dtype=torch.bool)
+        probs, bounds = model(x=units, f0=None, mask=masks, sig=True)
+        out['probs'], out['bounds'] = probs.numpy().copy(), bounds.numpy().copy()
+        f2i = iu.decode_bounds_to_alignment(bounds, use_diff=False) * masks
+        v, rest = iu.decode_gaussian_blurred_probs(probs, vmin=0, vmax=127, deviation=1.0, threshold=0.1)
+        nm, nd, nmask = iu.decode_note_sequence(f2i, v, ~rest & masks)
+    # me_onnx_module.py:39: `note_dur_pred * self.timestep` is a TORCH op: int64 tensor * python float -> float32
+    out['note_midi'], out['note_rest'], out['note_dur'] = nm.numpy(), (~nmask).numpy(), (nd * (512 / 44100)).numpy()
+    np.savez_compressed(OUT / 'deploy.npz', **out)
+    print('deploy.npz', {k: v.shape for k, v in out.items()})
+
+
 def gen_e2e():
     """waveform -> notes through the reference's own front end, model and decoder (B=1, CPU)."""
     out = {}
@@ -363,4 +391,5 @@ if __name__ == '__main__':
     gen_midi_msgs()
     gen_batch_infer_fns()
     gen_batch_csv()
+    gen_deploy()
     gen_e2e()

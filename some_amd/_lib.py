@@ -14,6 +14,7 @@ SOME_EINVAL, SOME_EKEY, SOME_ESHAPE, SOME_EHIP, SOME_ESTATE, SOME_ENOMEM = -1, -
 HEAD_LOGITS, HEAD_SIGMOID, HEAD_SOFTMAX = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_SILU, EPI_BIAS_RES, EPI_GLU, EPI_GLU_RES = range(6)
 PRECISION_F32, PRECISION_F16X3 = 0, 1
+PAD_ZERO, PAD_REFLECT = 0, 1
 GEMM_SPLIT_IN, GEMM_SPLIT_OUT = 1, 2
 
 
@@ -50,7 +51,7 @@ SYMBOLS = {
     'some_pack_weights': (C.c_int, [_P, C.POINTER(SomeTensorDesc), C.c_int32, _P]),
     'some_attach_arena': (C.c_int, [_P, _P, C.c_size_t]),
     'some_mel_filterbank': (C.c_int, [_P, _P]),
-    'some_logmel': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
+    'some_logmel': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     'some_workspace_bytes': (C.c_size_t, [_P, C.c_int64, C.c_int32]),
     'some_forward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_size_t, _P]),
     'some_decode_scratch_bytes': (C.c_size_t, [_P, C.c_int64]),

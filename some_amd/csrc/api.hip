@@ -346,17 +346,18 @@ int some_attach_arena(SomeHandle* h, const float* arena_dev, size_t bytes) {
 }
 
 int some_logmel(SomeHandle* h, const float* audio_dev, const int64_t* sample_offsets_dev,
-                const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, float* units_dev, void* stream) {
+                const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, int32_t pad_mode, float* units_dev, void* stream) {
     if (!h) return SOME_EINVAL;
     if (B < 0 || max_frames < 0) return fail(h, SOME_EINVAL, "some_logmel: negative size");
     if (B == 0 || max_frames == 0) return SOME_OK;
     if (!audio_dev || !sample_offsets_dev || !frame_offsets_dev || !units_dev) return fail(h, SOME_EINVAL, "some_logmel: null pointer");
     if (B > 65535) return fail(h, SOME_EINVAL, "some_logmel: B > 65535");
+    if (pad_mode != SOME_PAD_ZERO && pad_mode != SOME_PAD_REFLECT) return fail(h, SOME_EINVAL, "some_logmel: bad pad_mode");
     int rc = ensure_mel_tables(h);
     if (rc != SOME_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(h, s, "logmel", 0.0, 0.0);
-    HIP_TRY(h, launch_logmel(h->mel, audio_dev, sample_offsets_dev, frame_offsets_dev, B, max_frames, units_dev, s));
+    HIP_TRY(h, launch_logmel(h->mel, audio_dev, sample_offsets_dev, frame_offsets_dev, B, max_frames, pad_mode, units_dev, s));
     return SOME_OK;
 }
 

@@ -117,7 +117,7 @@ struct LogmelTables {
     int kmax;            // highest FFT bin any band touches
 };
 hipError_t launch_logmel(const LogmelTables& t, const float* audio, const int64_t* sample_offsets,
-                         const int32_t* frame_offsets, int B, int max_frames, float* units, hipStream_t s);
+                         const int32_t* frame_offsets, int B, int max_frames, int pad_reflect, float* units, hipStream_t s);
 
 // ---- decode ---------------------------------------------------------------------------------------
 struct DecodeArgs {

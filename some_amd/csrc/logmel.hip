@@ -18,7 +18,7 @@ namespace {
 __global__ __launch_bounds__(256) void logmel_kernel(LogmelTables t, const float* __restrict__ audio,
                                                       const int64_t* __restrict__ sample_offsets,
                                                       const int32_t* __restrict__ frame_offsets,
-                                                      float* __restrict__ units, int kmax) {
+                                                      float* __restrict__ units, int kmax, int pad_reflect) {
     __shared__ cpx bufA[FFT_N];
     __shared__ cpx bufB[FFT_N];
     __shared__ float mag[FFT_N + 8];
@@ -36,8 +36,16 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelTables t, const float
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + 256 * i;
         const int64_t p = (int64_t)frame * kHop + 2 * idx - kWin / 2;
-        const float x0 = (p >= 0 && p < n) ? x[p] : 0.f;
-        const float x1 = (p + 1 >= 0 && p + 1 < n) ? x[p + 1] : 0.f;
+        float x0, x1;
+        if (pad_reflect) {       // torch.stft(center=True): reflect without repeating the edge sample (n > win/2)
+            const int64_t q0 = p < 0 ? -p : (p >= n ? 2 * (n - 1) - p : p);
+            const int64_t q1 = p + 1 < 0 ? -(p + 1) : (p + 1 >= n ? 2 * (n - 1) - (p + 1) : p + 1);
+            x0 = x[q0];
+            x1 = x[q1];
+        } else {
+            x0 = (p >= 0 && p < n) ? x[p] : 0.f;
+            x1 = (p + 1 >= 0 && p + 1 < n) ? x[p + 1] : 0.f;
+        }
         bufA[idx] = {x0 * t.window[2 * idx], x1 * t.window[2 * idx + 1]};
     }
     __syncthreads();
@@ -65,9 +73,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelTables t, const float
 }  // namespace
 
 hipError_t launch_logmel(const LogmelTables& t, const float* audio, const int64_t* sample_offsets,
-                         const int32_t* frame_offsets, int B, int max_frames, float* units, hipStream_t s) {
+                         const int32_t* frame_offsets, int B, int max_frames, int pad_reflect, float* units, hipStream_t s) {
     if (B <= 0 || max_frames <= 0) return hipSuccess;
     dim3 grid((unsigned)max_frames, (unsigned)B);
-    hipLaunchKernelGGL(logmel_kernel, grid, dim3(256), 0, s, t, audio, sample_offsets, frame_offsets, units, t.kmax);
+    hipLaunchKernelGGL(logmel_kernel, grid, dim3(256), 0, s, t, audio, sample_offsets, frame_offsets, units, t.kmax, pad_reflect);
     return hipGetLastError();
 }

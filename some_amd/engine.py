@@ -178,14 +178,17 @@ class Engine:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- stages ---------------------------------------------------------------------------------
-    def logmel(self, audio: torch.Tensor, batch: ClipBatch) -> torch.Tensor:
-        """audio: packed fp32 [total_samples] on device -> units [total_frames, n_mels]."""
+    def logmel(self, audio: torch.Tensor, batch: ClipBatch, reflect: bool = False) -> torch.Tensor:
+        """audio: packed fp32 [total_samples] on device -> units [total_frames, n_mels].  reflect=True is the
+        deployment front end (torch.stft(center=True) reflect padding, deployment/base_onnx_module.py:68-76)."""
+        if reflect and int(np.diff(batch.sample_offsets).min()) <= self.c_config.win_size // 2:
+            raise ValueError('reflect padding needs clips longer than win_size / 2 samples')
         assert audio.is_cuda and audio.dtype == torch.float32 and audio.is_contiguous()
         assert batch.sample_offsets_dev is not None and audio.numel() == int(batch.sample_offsets[-1])
         units = torch.empty((batch.total_frames, self.indim), dtype=torch.float32, device=self.device)
         _lib.check(self.handle, self.lib.some_logmel(
             self.handle, _ptr(audio), _ptr(batch.sample_offsets_dev), _ptr(batch.frame_offsets_dev),
-            batch.B, batch.max_frames, _ptr(units), self._stream()))
+            batch.B, batch.max_frames, _lib.PAD_REFLECT if reflect else _lib.PAD_ZERO, _ptr(units), self._stream()))
         return units
 
     def forward(self, units: torch.Tensor, batch: ClipBatch, mask: Optional[torch.Tensor] = None,

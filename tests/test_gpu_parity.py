@@ -325,3 +325,23 @@ def test_cli_infer_writes_midi(tmp_path):
     mid = wav.with_suffix('.mid').read_bytes()
     assert mid[:4] == b'MThd' and b'MTrk' in mid and mid[-3:] == bytes([0xFF, 0x2F, 0x00])
     assert 'MIDI file saved at' in r.stdout
+
+
+def test_deployment_twin(golden_dir, tmp_path):
+    """deployment.MIDIExtractionONNXModule.forward (reflect-padded STFT front end) vs the reference's classes."""
+    import deployment
+    g = np.load(golden_dir / 'deploy.npz')
+    cfg = get_config('midi_conformer', lay=2)
+    ckpt = synth.save_checkpoint(cfg, tmp_path / 'model.ckpt', seed=41)
+    mod = deployment.MIDIExtractionONNXModule(cfg, ckpt)
+    w = np.stack([synth.synth_clip(70, 2.0), synth.synth_clip(71, 2.0)])
+    mel = deployment.MelSpectrogram_ONNX(n_mel_channels=80, sampling_rate=44100, win_length=2048, hop_length=512, mel_fmin=40, mel_fmax=8000)
+    units = mel(torch.from_numpy(w).cuda()).transpose(1, 2)
+    np.testing.assert_allclose(units.cpu().numpy(), g['units'], rtol=0, atol=2e-4)
+    midi, rest, dur = mod(torch.from_numpy(w).cuda())
+    assert midi.shape == g['note_midi'].shape
+    np.testing.assert_array_equal(rest.cpu().numpy(), g['note_rest'])
+    np.testing.assert_array_equal(dur.cpu().numpy(), g['note_dur'])
+    np.testing.assert_allclose(midi.cpu().numpy(), g['note_midi'], rtol=0, atol=2e-3)
+    with pytest.raises(ValueError):
+        mel(torch.zeros(1, 512).cuda())
