@@ -26,16 +26,37 @@ constexpr int LDR = 68;                         // LDS row (dwords): 64 data + 4
 constexpr int K_DW = KT * LDR;                  // K tile: [64 keys][hi|lo hi|lo]
 constexpr int V_DW = kHeadDim * LDR;            // V^T tile: [64 d][64 keys hi | 64 keys lo]
 constexpr size_t LDS_BYTES = 2 * (K_DW + V_DW) * sizeof(float);
+constexpr float kPShift = 14.f;                 // P is carried as 2^14 p (see softmax)
 
 __device__ __forceinline__ float exp2_(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// p = hi + lo with packed round-toward-zero converts (v_cvt_pkrtz_f16_f32: two values per instruction).  hi need
-// not be the NEAREST f16: lo = rtz_f16(p - hi) still leaves |p - hi - lo| < 2^-20 p, the same class as split_f16.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// v_max3_f32 without the v_max_f32 x, x, x canonicalisation clang puts in front of every fmaxf operand (scores are
+// MFMA results or -inf, never signalling NaNs)
+__device__ __forceinline__ float max2_(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float max3_(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// p = hi + lo.  hi = p with the 13 low mantissa bits cleared (the f16 round-toward-zero value of p, exact in f16 while
+// p >= 2^-14), lo = rtz_f16(p - hi): |p - hi - lo| < 2^-21 p.  Packed fp32 subtract, packed converts: 5 VALU
+// instructions per two probabilities.  hi need not be the NEAREST f16 - same error class as split_f16.
 __device__ __forceinline__ void split8(const f32x16& p, int base, half8& h, half8& l) {
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
-        const half2_t hh = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(p[base + i], p[base + i + 1]));
-        const half2_t ll = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(p[base + i] - (float)hh[0], p[base + i + 1] - (float)hh[1]));
+        const float p0 = p[base + i], p1 = p[base + i + 1];      // (scalars: bit_cast of a vector element miscompiles)
+        const f32x2 pp = {p0, p1};
+        const f32x2 hf = {__uint_as_float(__float_as_uint(p0) & 0xFFFFE000u), __uint_as_float(__float_as_uint(p1) & 0xFFFFE000u)};
+        const f32x2 lf = pp - hf;
+        const half2_t hh = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(hf[0], hf[1]));
+        const half2_t ll = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(lf[0], lf[1]));
         h[i] = hh[0]; h[i + 1] = hh[1];
         l[i] = ll[0]; l[i + 1] = ll[1];
     }
@@ -155,21 +176,32 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
 
     // online softmax of one tile's scores (lane = query; scale folded into the exponent): s0/s1 become P
     auto softmax = [&](f32x16& s0, f32x16& s1) {
-        float mx = fmaxf(s0[0], s1[0]);
+        float mxa = max2_(s0[0], s1[0]), mxb = max2_(s0[1], s1[1]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * c);      // finite: every tile holds at least one key of the clip
+        for (int r = 2; r < 16; r += 2) {
+            mxa = max3_(mxa, s0[r], s1[r]);
+            mxb = max3_(mxb, s0[r + 1], s1[r + 1]);
+        }
+        float mx = max2_(mxa, mxb);
+        mx = max2_(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = max2_(m_run, mx * c);      // finite: every tile holds at least one key of the clip
         const float alpha = exp2_(m_run - m_new);       // first tile: exp2(-inf) = 0
         m_run = m_new;
-        float psum = 0.f;
+        // probabilities are kept scaled by 2^kPShift (<= 16384, inside f16): keys far below the running maximum
+        // stay out of the f16 subnormal range when P is split; the scale cancels in O / l
+        const f32x2 c2 = {c, c}, nm2 = {kPShift - m_new, kPShift - m_new};
+        f32x2 ps = {0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = exp2_(fmaf(s0[r], c, -m_new));
-            s1[r] = exp2_(fmaf(s1[r], c, -m_new));
-            psum += s0[r] + s1[r];
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 t0 = __builtin_elementwise_fma(f32x2{s0[r], s0[r + 1]}, c2, nm2);
+            const f32x2 t1 = __builtin_elementwise_fma(f32x2{s1[r], s1[r + 1]}, c2, nm2);
+            const f32x2 e0 = {exp2_(t0[0]), exp2_(t0[1])};
+            const f32x2 e1 = {exp2_(t1[0]), exp2_(t1[1])};
+            s0[r] = e0[0]; s0[r + 1] = e0[1];
+            s1[r] = e1[0]; s1[r + 1] = e1[1];
+            ps += e0 + e1;
         }
-        l_run = l_run * alpha + psum;
+        l_run = l_run * alpha + (ps[0] + ps[1]);
         // unconditional (no wave-uniform "max did not move" branch): a branch here would split the basic block and
         // stop the scheduler from spreading this VALU work under the QK(i+1) MFMAs
 #pragma unroll
@@ -218,24 +250,33 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
     if (n > 1) { gload_k(1); lstore_k(1); gload_v(1); }
     if (n > 2) gload_k(2);
     __syncthreads();
-    f32x16 sc0, sc1, sn0, sn1;
-    qk(0, sc0, sc1);
-    mask_tile(0, sc0, sc1);
-    for (int i = 0; i + 1 < n; ++i) {
-        if (i + 2 < n) lstore_k(i + 2);               // K ring slot i & 1: last read by QK(i) in the previous iteration
+    f32x16 sa0, sa1, sb0, sb1;                        // scores of even / odd tiles (ping-pong: no register copies)
+    auto step = [&](int i, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
+        if (i + 2 < n) lstore_k(i + 2);               // K ring slot i & 1: last read by QK(i) in the previous step
         lstore_v(i + 1);                              // V ring slot (i+1) & 1: last read by PV(i-1)
         if (i + 3 < n) gload_k(i + 3);
         if (i + 2 < n) gload_v(i + 2);
-        qk(i + 1, sn0, sn1);                          // matrix pipe ...
-        softmax(sc0, sc1);                            // ... overlapped with the VALU (independent of QK(i+1))
-        pv(i, sc0, sc1);
-        mask_tile(i + 1, sn0, sn1);
+        qk(i + 1, n0, n1);                            // matrix pipe ...
+        softmax(c0, c1);                              // ... overlapped with the VALU (independent of QK(i+1))
+        pv(i, c0, c1);
+        mask_tile(i + 1, n0, n1);
         __syncthreads();
-        sc0 = sn0;
-        sc1 = sn1;
+    };
+    qk(0, sa0, sa1);
+    mask_tile(0, sa0, sa1);
+    int i = 0;
+    for (; i + 2 < n; i += 2) {
+        step(i, sa0, sa1, sb0, sb1);
+        step(i + 1, sb0, sb1, sa0, sa1);
     }
-    softmax(sc0, sc1);
-    pv(n - 1, sc0, sc1);
+    if (i + 1 < n) {
+        step(i, sa0, sa1, sb0, sb1);
+        softmax(sb0, sb1);
+        pv(n - 1, sb0, sb1);
+    } else {
+        softmax(sa0, sa1);
+        pv(n - 1, sa0, sa1);
+    }
     __syncthreads();
 
     // ---- normalise, transpose through LDS (wave-private 32 x 64 patch), SPLIT32 row stores
