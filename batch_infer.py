@@ -7,6 +7,7 @@ Multi-GPU: launch with ``python -m torch.distributed.run --nproc-per-node 8 batc
 sharded across the ranks (largest first, round-robin), rank 0 packs the weights and broadcasts them once with
 RCCL, every rank works on its own rows with no cross-GPU dependence, rank 0 gathers and writes the CSV."""
 import pathlib
+from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 from csv import DictReader, DictWriter
 from typing import Dict, List
@@ -15,7 +16,7 @@ import click
 
 from infer import load_inference
 from some_amd import batch_logic, sharding
-from some_amd.utils.audio import load_wav
+from some_amd.utils.audio import load_pcm, load_wav
 from utils.slicer2 import Slicer
 
 CSV_FIELDS = ['name', 'ph_seq', 'ph_dur', 'ph_num', 'note_seq', 'note_dur']
@@ -40,10 +41,13 @@ def infer(wav, infer_ins, config):
 
 
 def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, infer_ins, config,
-                 round_midi: bool, max_batch_frames: int = 131072, io_threads: int = 8) -> Dict[int, tuple]:
-    """Rows ``indices`` of the CSV -> {row index: (note_seq, note_dur)}.  WAV decode + slicing run in a thread
-    pool ahead of the GPU; chunks of consecutive rows share packed device batches."""
+                 round_midi: bool, max_batch_frames: int = 131072, io_threads: int = 8, prefetch: int = 256,
+                 flush_batches: int = 8) -> Dict[int, tuple]:
+    """Rows ``indices`` of the CSV -> {row index: (note_seq, note_dur)}.  WAV files are read by a thread pool with a
+    bounded read-ahead; up to ``flush_batches`` device batches of rows go through ``infer_files`` at a time (upload +
+    RMS of batch k + 1 overlap the forward of batch k); chunks of consecutive rows share packed device batches."""
     hop = config['hop_size']
+    infer_ins.max_batch_frames = max_batch_frames
     out: Dict[int, tuple] = {}
     jobs = []
     for i in indices:
@@ -53,26 +57,39 @@ def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, 
             continue
         jobs.append((i, audio_path))
 
+    slicer = Slicer(sr=config['audio_sample_rate'], max_sil_kept=1000)
+
     def flush(group):
-        waves = [c['waveform'] for _, chunks in group for c in chunks]
-        results = infer_ins.infer(waves)
-        pos = 0
-        for i, chunks in group:
-            segs = results[pos:pos + len(chunks)]
-            pos += len(chunks)
-            notes = batch_logic.notes_from_segments([c['offset'] for c in chunks], segs)
+        # Slicer.slice + infer of batch_infer.py:52-57 for many rows at once: files go up as stored (int16 PCM), the
+        # RMS curve and the chunk cut run on the device, the silence decisions on the host
+        per_file = infer_ins.infer_files([pcm for _, pcm in group], slicer)
+        for (i, _), segments in zip(group, per_file):
+            notes = batch_logic.notes_from_segments([off for off, _ in segments], [seg for _, seg in segments])
             out[i] = batch_logic.align_row(notes, rows[i]['ph_dur'], rows[i]['ph_num'], round_midi)
 
+    rate = config['audio_sample_rate']
     with ThreadPoolExecutor(max_workers=io_threads) as pool:
-        futures = [(i, pool.submit(load_and_slice, p, config)) for i, p in jobs]
+        window = deque()                                  # bounded read-ahead: at most `prefetch` decoded files in flight
+        it = iter(jobs)
+
+        def refill():
+            while len(window) < prefetch:
+                job = next(it, None)
+                if job is None:
+                    return
+                window.append((job[0], pool.submit(load_pcm, job[1], rate)))
+
+        refill()
         group, frames = [], 0
-        for i, fut in futures:
-            chunks = fut.result()
-            t = sum(1 + c['waveform'].shape[-1] // hop for c in chunks)
-            if group and frames + t > max_batch_frames:
+        while window:
+            i, fut = window.popleft()
+            refill()
+            pcm, _ = fut.result()
+            t = 1 + pcm.shape[-1] // hop
+            if group and frames + t > flush_batches * max_batch_frames:
                 flush(group)
                 group, frames = [], 0
-            group.append((i, chunks))
+            group.append((i, pcm))
             frames += t
         if group:
             flush(group)

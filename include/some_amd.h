@@ -165,6 +165,29 @@ int some_decode_notes(SomeHandle* h, const int64_t* frame2item_dev, const float*
                       int32_t values_are_integers, float* note_midi_dev, int64_t* note_dur_dev, uint8_t* note_rest_dev,
                       int32_t* n_notes_dev, void* scratch_dev, size_t scratch_bytes, void* stream);
 
+/* ---- host ingest either side of the silence slicer ---------------------- */
+
+#define SOME_SAMPLE_F32 0     /* float32 samples in [-1, 1]                                            */
+#define SOME_SAMPLE_PCM16 1   /* int16 PCM as stored in the WAV file; value = x / 32768 (exact in fp32) */
+
+/* Replaces: get_rms(y, frame_length, hop_length) (utils/slicer2.py:5-38), the numpy reduction Slicer.slice runs
+ * over every file (slicer2.py:87): zero centre padding, mean of squares over hop-strided frames, sqrt - with numpy's
+ * float32 pairwise summation order, so rms < threshold and argmin decide exactly as on the host.
+ * audio_dev: packed clips of `sample_format`; clip b = [sample_offsets[b], sample_offsets[b+1]) (device int64 [B+1]).
+ * Clip b yields 1 + n_b / hop_length values at rms_dev[rms_offsets[b] ...] (device int64 [B+1]);
+ * max_rms_frames = max_b of that count (host value, sizes the launch). */
+int some_slicer_rms(SomeHandle* h, const void* audio_dev, int32_t sample_format, const int64_t* sample_offsets_dev,
+                    const int64_t* rms_offsets_dev, int32_t B, int64_t max_rms_frames, int32_t frame_length,
+                    int32_t hop_length, float* rms_dev, void* stream);
+
+/* Replaces: the chunk cut of Slicer.slice (utils/slicer2.py:73-82) fused with librosa.load's sample conversion
+ * (infer.py:34, batch_infer.py:51): span b = src_dev[src_offsets[b] ... + n_b) is written as fp32 to
+ * audio_out_dev[dst_offsets[b] ...), n_b = dst_offsets[b+1] - dst_offsets[b]; the result is the packed layout
+ * some_logmel reads with sample_offsets = dst_offsets.  src_offsets_dev: device int64 [B]; dst_offsets_dev: device
+ * int64 [B+1]; max_len = max_b n_b (host value). */
+int some_pcm_gather(SomeHandle* h, const void* src_dev, int32_t sample_format, const int64_t* src_offsets_dev,
+                    const int64_t* dst_offsets_dev, int32_t B, int64_t max_len, float* audio_out_dev, void* stream);
+
 /* ---- single-operator entry points (kernel-level parity tests and micro-benchmarks) ------------------ */
 
 #define SOME_EPI_NONE 0       /* C = A W^T                                                          */

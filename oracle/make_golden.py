@@ -205,6 +205,33 @@ def gen_decode():
     print('decode.npz', len(out))
 
 
+SCALED = dict(midi_min=36.0, midi_max=96.5, midi_prob_deviation=0.8, rest_threshold=0.05)   # interval 60.5 / 127
+
+
+def gen_decode_scaled():
+    """A non-default value range: idx * interval + vmin is no longer exact in fp32, so a fused multiply-add in the
+    decoder would show (tests/golden/decode_scaled.npz)."""
+    iu = ref_infer_utils
+    t, nb = 600, 128
+    rng = np.random.default_rng(8)
+    centers = np.repeat(rng.uniform(10, 110, t // 20 + 1), 20)[:t] + rng.standard_normal(t) * 0.3
+    bump = np.exp(-0.5 * ((np.arange(nb)[None, :] - centers[:, None]) / 1.7) ** 2)
+    logits = (np.log(bump * rng.uniform(0.02, 1.0, (t, 1)) + 1e-4) + rng.standard_normal((t, nb)) * 0.2).astype(np.float32)
+    probs = torch.sigmoid(torch.from_numpy(logits))
+    bounds = torch.from_numpy((rng.uniform(0, 1, t) ** 6).astype(np.float32))
+    masks = torch.ones(1, t, dtype=torch.bool)
+    p, b = probs[None].clone(), bounds[None].clone()
+    f2i = iu.decode_bounds_to_alignment(b) * masks
+    v, rest = iu.decode_gaussian_blurred_probs(p, vmin=SCALED['midi_min'], vmax=SCALED['midi_max'],
+                                               deviation=SCALED['midi_prob_deviation'], threshold=SCALED['rest_threshold'])
+    nm, nd, nmask = iu.decode_note_sequence(f2i, v, ~rest & masks)
+    out = {'probs': probs.numpy(), 'bounds': bounds.numpy(), 'frame2item': f2i[0].numpy(), 'values': v[0].numpy(),
+           'rest': rest[0].numpy(), 'note_midi': nm[0].numpy(), 'note_dur_frames': nd[0].numpy(), 'note_rest': (~nmask)[0].numpy()}
+    out.update({k: np.array(x) for k, x in SCALED.items()})
+    np.savez_compressed(OUT / 'decode_scaled.npz', **out)
+    print('decode_scaled.npz', len(out))
+
+
 def gen_slicer():
     out = {}
     cases = {
@@ -387,6 +414,7 @@ if __name__ == '__main__':
     gen_mel()
     gen_model()
     gen_decode()
+    gen_decode_scaled()
     gen_slicer()
     gen_midi_msgs()
     gen_batch_infer_fns()

@@ -15,6 +15,7 @@ HEAD_LOGITS, HEAD_SIGMOID, HEAD_SOFTMAX = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_SILU, EPI_BIAS_RES, EPI_GLU, EPI_GLU_RES = range(6)
 PRECISION_F32, PRECISION_F16X3 = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
+SAMPLE_F32, SAMPLE_PCM16 = 0, 1
 GEMM_SPLIT_IN, GEMM_SPLIT_OUT = 1, 2
 
 
@@ -57,6 +58,8 @@ SYMBOLS = {
     'some_decode_scratch_bytes': (C.c_size_t, [_P, C.c_int64]),
     'some_decode': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     'some_decode_notes': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    'some_slicer_rms': (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
+    'some_pcm_gather': (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int64, _P, _P]),
     'some_op_gemm': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32,
                                C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, C.c_int32, _P]),
     'some_op_split_rows': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),

@@ -16,8 +16,8 @@ HERE = pathlib.Path(__file__).resolve().parent
 CSRC = HERE / 'csrc'
 OBJ = CSRC / 'build'
 LIB = HERE / 'libsome_amd.so'
-SOURCES = ['api.hip', 'gemm.hip', 'gemm_f16x3.hip', 'rowops.hip', 'attention.hip', 'attention_f16x3.hip', 'dwconv.hip', 'logmel.hip', 'decode.hip']
-HEADERS = [CSRC / 'internal.h', CSRC / 'fft_core.h', CSRC / 'split.h', HERE.parent / 'include' / 'some_amd.h']
+SOURCES = ['api.hip', 'gemm.hip', 'gemm_f16x3.hip', 'rowops.hip', 'attention.hip', 'attention_f16x3.hip', 'dwconv.hip', 'logmel.hip', 'decode.hip', 'ingest.hip']
+HEADERS = [CSRC / 'internal.h', CSRC / 'fft_core.h', CSRC / 'split.h', CSRC / 'rms_core.h', HERE.parent / 'include' / 'some_amd.h']
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
 

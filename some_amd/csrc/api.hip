@@ -361,6 +361,39 @@ int some_logmel(SomeHandle* h, const float* audio_dev, const int64_t* sample_off
     return SOME_OK;
 }
 
+int some_slicer_rms(SomeHandle* h, const void* audio_dev, int32_t sample_format, const int64_t* sample_offsets_dev,
+                    const int64_t* rms_offsets_dev, int32_t B, int64_t max_rms_frames, int32_t frame_length,
+                    int32_t hop_length, float* rms_dev, void* stream) {
+    if (!h) return SOME_EINVAL;
+    if (B < 0 || max_rms_frames < 0) return fail(h, SOME_EINVAL, "some_slicer_rms: negative size");
+    if (frame_length <= 0 || hop_length <= 0) return fail(h, SOME_EINVAL, "some_slicer_rms: frame_length and hop_length must be positive");
+    if (frame_length > (1 << 19)) return fail(h, SOME_EINVAL, "some_slicer_rms: frame_length > 524288");
+    if (sample_format != SOME_SAMPLE_F32 && sample_format != SOME_SAMPLE_PCM16) return fail(h, SOME_EINVAL, "some_slicer_rms: bad sample_format");
+    if (B == 0 || max_rms_frames == 0) return SOME_OK;
+    if (B > 65535) return fail(h, SOME_EINVAL, "some_slicer_rms: B > 65535");
+    if (!audio_dev || !sample_offsets_dev || !rms_offsets_dev || !rms_dev) return fail(h, SOME_EINVAL, "some_slicer_rms: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(h, s, "slicer_rms", 0.0, 0.0);
+    HIP_TRY(h, launch_slicer_rms(audio_dev, sample_format == SOME_SAMPLE_PCM16, sample_offsets_dev, rms_offsets_dev, B,
+                                 max_rms_frames, frame_length, hop_length, rms_dev, s));
+    return SOME_OK;
+}
+
+int some_pcm_gather(SomeHandle* h, const void* src_dev, int32_t sample_format, const int64_t* src_offsets_dev,
+                    const int64_t* dst_offsets_dev, int32_t B, int64_t max_len, float* audio_out_dev, void* stream) {
+    if (!h) return SOME_EINVAL;
+    if (B < 0 || max_len < 0) return fail(h, SOME_EINVAL, "some_pcm_gather: negative size");
+    if (sample_format != SOME_SAMPLE_F32 && sample_format != SOME_SAMPLE_PCM16) return fail(h, SOME_EINVAL, "some_pcm_gather: bad sample_format");
+    if (B == 0 || max_len == 0) return SOME_OK;
+    if (B > 65535) return fail(h, SOME_EINVAL, "some_pcm_gather: B > 65535");
+    if (!src_dev || !src_offsets_dev || !dst_offsets_dev || !audio_out_dev) return fail(h, SOME_EINVAL, "some_pcm_gather: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(h, s, "pcm_gather", 0.0, 0.0);
+    HIP_TRY(h, launch_pcm_gather(src_dev, sample_format == SOME_SAMPLE_PCM16, src_offsets_dev, dst_offsets_dev, B, max_len,
+                                 audio_out_dev, s));
+    return SOME_OK;
+}
+
 size_t some_workspace_bytes(const SomeHandle* h, int64_t total_frames, int32_t B) {
     (void)B;
     if (!h || total_frames <= 0) return 0;

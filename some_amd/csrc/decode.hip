@@ -8,10 +8,14 @@
 //     sequential fp64 scan by one lane out of LDS (one workgroup per clip, clips in parallel);
 //   * .round(): round-half-even (rintf);
 //   * the weighted mean over the <= 7-bin window and the per-note value sum: sequential fp32 in ascending
-//     index / frame order, separate multiply and add (__fmul_rn / __fadd_rn: no FMA contraction);
+//     index / frame order, separate multiply and add (plain operators under `fp contract(off)`: the
+//     __fmul_rn / __fadd_rn wrappers are ordinary * and + compiled with the contract flag in this toolchain's
+//     headers and DO fuse into FMAs after inlining);
 //   * per-note counts and the 128-bin histogram are integers (LDS atomics, order-free), argmax = first max.
 // HBM-bound: reads 4 (N + 1) bytes per frame, writes <= 13 bytes per frame.
 #include "internal.h"
+
+#pragma clang fp contract(off)
 
 namespace {
 
@@ -57,11 +61,11 @@ __global__ __launch_bounds__(256) void decode_frames_kernel(FrameArgs a) {
                 float ps = 0.f, ws = 0.f;
                 for (int j = s; j < e; ++j) {
                     const float pj = on ? p[j] : 0.f;
-                    const float vj = __fadd_rn(__fmul_rn((float)j, a.interval), a.vmin);
-                    ps = __fadd_rn(ps, __fmul_rn(pj, vj));
-                    ws = __fadd_rn(ws, pj);
+                    const float vj = (float)j * a.interval + a.vmin;      // two roundings (contract off)
+                    ps = ps + pj * vj;
+                    ws = ws + pj;
                 }
-                value = __fdiv_rn(ps, __fadd_rn(ws, ws == 0.f ? 1.f : 0.f));
+                value = ps / (ws + (ws == 0.f ? 1.f : 0.f));
                 rest = best < a.threshold;
             }
             a.values[m] = value;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void decode_notes_kernel(DecodeArgs a, const f
     auto finish = [&](int n, int ts, int te, int center_bin, int dur, int unm) {
         // mean of the values within +-0.5 of the mode, summed in ascending frame order like CPU scatter_add
         const float center = (float)center_bin;
-        const float lo = __fsub_rn(center, 0.5f), hi2 = __fadd_rn(center, 0.5f);
+        const float lo = center - 0.5f, hi2 = center + 0.5f;
         int valid = 0;
         long long iacc = 0;
         float facc = 0.f;
@@ -230,14 +234,14 @@ __global__ __launch_bounds__(256) void decode_notes_kernel(DecodeArgs a, const f
             const float v = frame_val(t);
             if (v >= lo && v <= hi2) {
                 ++valid;
-                if (a.quantized) iacc += (long long)v; else facc = __fadd_rn(facc, v);
+                if (a.quantized) iacc += (long long)v; else facc = facc + v;
             }
         }
         const float denom = (float)(valid + (valid == 0 ? 1 : 0));
-        a.note_midi[f0 + n - 1] = __fdiv_rn(a.quantized ? (float)iacc : facc, denom);
+        a.note_midi[f0 + n - 1] = (a.quantized ? (float)iacc : facc) / denom;
         a.note_dur[f0 + n - 1] = dur;
         // item_masks = unmasked / dur >= 0.5 in fp32 (int64 / int64 true-divide -> fp32); 0/0 = nan -> False
-        const bool keep = dur > 0 && __fdiv_rn((float)unm, (float)dur) >= 0.5f;
+        const bool keep = dur > 0 && (float)unm / (float)dur >= 0.5f;
         a.note_rest[f0 + n - 1] = keep ? 0 : 1;
     };
     constexpr int SHORT = 24;

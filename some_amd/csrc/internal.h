@@ -133,6 +133,12 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t s);
 hipError_t launch_decode_notes(const DecodeArgs& a, const int64_t* frame2item, const float* values,
                                const uint8_t* not_masks, int max_frames, hipStream_t s);
 
+// ---- host ingest (ingest.hip) ------------------------------------------------------------------------
+hipError_t launch_slicer_rms(const void* audio, int is_pcm16, const int64_t* sample_offsets, const int64_t* rms_offsets,
+                             int B, int64_t max_rms_frames, int frame_length, int hop, float* rms, hipStream_t s);
+hipError_t launch_pcm_gather(const void* src, int is_pcm16, const int64_t* src_offsets, const int64_t* dst_offsets, int B,
+                             int64_t max_len, float* dst, hipStream_t s);
+
 // ---- profiling ------------------------------------------------------------------------------------
 struct ProfRecord { std::string name; hipEvent_t e0, e1; double flops, bytes; };
 

@@ -191,6 +191,51 @@ class Engine:
             batch.B, batch.max_frames, _lib.PAD_REFLECT if reflect else _lib.PAD_ZERO, _ptr(units), self._stream()))
         return units
 
+    # ---- host ingest either side of the silence slicer ------------------------------------------------------
+    @staticmethod
+    def _sample_format(audio: torch.Tensor) -> int:
+        if audio.dtype == torch.int16:
+            return _lib.SAMPLE_PCM16
+        if audio.dtype == torch.float32:
+            return _lib.SAMPLE_F32
+        raise TypeError(f'audio must be int16 PCM or float32, got {audio.dtype}')
+
+    def slicer_rms(self, audio: torch.Tensor, sample_counts: Sequence[int], frame_length: int, hop_length: int):
+        """get_rms (utils/slicer2.py:5-38) of every packed clip on the device, bit-identical to the numpy reduction.
+        audio: packed int16 PCM or fp32 [total_samples] on device.  Returns (rms [sum_b (1 + n_b // hop)] device
+        fp32, rms_offsets numpy int64 [B + 1])."""
+        assert audio.is_cuda and audio.is_contiguous() and audio.dim() == 1
+        sc = np.asarray(sample_counts, dtype=np.int64)
+        assert int(sc.sum()) == audio.numel()
+        so = np.zeros(sc.shape[0] + 1, dtype=np.int64)
+        np.cumsum(sc, out=so[1:])
+        counts = 1 + sc // int(hop_length)
+        ro = np.zeros_like(so)
+        np.cumsum(counts, out=ro[1:])
+        offs = torch.from_numpy(np.stack([so, ro])).to(self.device)          # one H2D for both offset tables
+        rms = torch.empty((int(ro[-1]),), dtype=torch.float32, device=self.device)
+        _lib.check(self.handle, self.lib.some_slicer_rms(
+            self.handle, _ptr(audio), self._sample_format(audio), _ptr(offs[0]), _ptr(offs[1]), int(sc.shape[0]),
+            int(counts.max()) if sc.shape[0] else 0, int(frame_length), int(hop_length), _ptr(rms), self._stream()))
+        return rms, ro
+
+    def pcm_gather(self, audio: torch.Tensor, src_offsets: Sequence[int], lengths: Sequence[int]):
+        """Cut spans [src_offsets[b], src_offsets[b] + lengths[b]) out of the packed upload (int16 PCM or fp32) into
+        the packed fp32 layout ``logmel`` reads.  Returns (audio_f32 device, ClipBatch)."""
+        assert audio.is_cuda and audio.is_contiguous() and audio.dim() == 1
+        ln = np.asarray(lengths, dtype=np.int64)
+        src = np.asarray(src_offsets, dtype=np.int64)
+        assert src.shape == ln.shape
+        if ln.size and (src.min() < 0 or (src + ln).max() > audio.numel() or ln.min() < 0):
+            raise ValueError('pcm_gather: span outside the uploaded audio')
+        batch = ClipBatch.from_sample_counts(ln, self.hop, self.device)
+        out = torch.empty((int(batch.sample_offsets[-1]),), dtype=torch.float32, device=self.device)
+        src_dev = torch.from_numpy(src).to(self.device)
+        _lib.check(self.handle, self.lib.some_pcm_gather(
+            self.handle, _ptr(audio), self._sample_format(audio), _ptr(src_dev), _ptr(batch.sample_offsets_dev), batch.B,
+            int(ln.max()) if ln.size else 0, _ptr(out), self._stream()))
+        return out, batch
+
     def forward(self, units: torch.Tensor, batch: ClipBatch, mask: Optional[torch.Tensor] = None,
                 head_mode: int = _lib.HEAD_LOGITS):
         """units [total_frames, indim] -> (midi [total_frames, outdim], bound [total_frames])."""

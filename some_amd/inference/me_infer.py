@@ -3,7 +3,7 @@
 The three per-clip methods keep the reference's tensor contracts; ``infer`` (and ``infer_batch``) run whole
 lists of clips as packed var-len batches: one log-mel launch, one forward, one decode, one D2H copy."""
 import pathlib
-from typing import Dict, List
+from typing import Dict, List, Tuple
 
 import numpy as np
 import torch
@@ -152,4 +152,120 @@ class MIDIExtractionInference(BaseInference):
             pending = (launched[0], launched[1], batch)
         if pending is not None:
             results.extend(self._finish(pending[0], pending[1], pending[2]))
+        return results
+
+    # ---- device-side ingest of whole files -----------------------------------------
+    def _stage_files(self, clips: List[np.ndarray], slicer, slot: int):
+        """Upload whole files (int16 PCM as stored in the WAV, or fp32) through a pinned buffer and compute the slicer's
+        RMS curve on the copy stream; the curve comes back through pinned memory.  No host-side float conversion."""
+        dtype = np.int16 if all(c.dtype == np.int16 for c in clips) else np.float32
+        tdtype = torch.int16 if dtype == np.int16 else torch.float32
+        lens = np.asarray([int(c.shape[0]) for c in clips], dtype=np.int64)
+        total = int(lens.sum())
+        key = ('files', slot, tdtype)
+        pin = self._pinned.get(key)
+        if pin is None or pin.numel() < total:
+            pin = self._pinned[key] = torch.empty(max(total, 1), dtype=tdtype).pin_memory()
+        view = pin.numpy()
+        pos = 0
+        for c, n in zip(clips, lens):
+            if dtype == np.int16:
+                view[pos:pos + n] = c
+            else:
+                view[pos:pos + n] = c if c.dtype == np.float32 else c.astype(np.float32) / np.float32(32768.0)
+            pos += int(n)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        need = np.asarray([slicer.needs_rms(int(n)) for n in lens])
+        with torch.cuda.stream(self._copy_stream):
+            audio = pin[:total].to(self.device, non_blocking=True)
+            uploaded = torch.cuda.Event()
+            uploaded.record(self._copy_stream)
+            rms_host, ro = None, None
+            if need.any():
+                rms, ro = self.engine.slicer_rms(audio, lens, slicer.win_size, slicer.hop_size)
+                rkey = ('rms', slot)
+                rpin = self._pinned.get(rkey)
+                if rpin is None or rpin.numel() < rms.numel():
+                    rpin = self._pinned[rkey] = torch.empty(max(rms.numel(), 1), dtype=torch.float32).pin_memory()
+                rpin[:rms.numel()].copy_(rms, non_blocking=True)
+                rms_host = rpin.numpy()
+            curve_ready = torch.cuda.Event()
+            curve_ready.record(self._copy_stream)
+        return {'audio': audio, 'lens': lens, 'need': need, 'rms': rms_host, 'ro': ro, 'uploaded': uploaded,
+                'curve_ready': curve_ready}
+
+    def _launch_files(self, st, slicer):
+        """Silence decisions on the host from the device RMS curve, then cut + front end + network + decode."""
+        st['curve_ready'].synchronize()                 # waits for the copy stream only, not for the compute stream
+        so = np.zeros(st['lens'].shape[0] + 1, dtype=np.int64)
+        np.cumsum(st['lens'], out=so[1:])
+        spans_per_file, src, ln = [], [], []
+        for f, n in enumerate(st['lens']):
+            n = int(n)
+            if st['need'][f]:
+                spans = slicer.spans_from_rms(st['rms'][int(st['ro'][f]):int(st['ro'][f + 1])], n)
+            else:
+                spans = [(0, n)]
+            spans_per_file.append(spans)
+            for a, b in spans:
+                src.append(int(so[f]) + a)
+                ln.append(b - a)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(st['uploaded'])
+        st['audio'].record_stream(cur)
+        audio, batch = self.engine.pcm_gather(st['audio'], src, ln)
+        units = self.engine.logmel(audio, batch)
+        probs, bounds = self.engine.forward(units, batch, mask=None,
+                                            head_mode=_lib.HEAD_SOFTMAX if self.quantized else _lib.HEAD_SIGMOID)
+        out = self.engine.decode(probs, bounds, batch, quantized=self.quantized)
+        finite = torch.isfinite(bounds).all()
+        return out, finite, batch, spans_per_file
+
+    def _group_files(self, clips: List[np.ndarray]) -> List[List[int]]:
+        """Consecutive files per device batch: at most ``max_batch_frames`` whole-file frames each."""
+        groups: List[List[int]] = []
+        group, frames = [], 0
+        for i, c in enumerate(clips):
+            if c.ndim != 1:
+                raise ValueError('infer_files takes mono [L] arrays')
+            t = 1 + int(c.shape[0]) // self.engine.hop
+            if group and frames + t > self.max_batch_frames:
+                groups.append(group)
+                group, frames = [], 0
+            group.append(i)
+            frames += t
+        if group:
+            groups.append(group)
+        return groups
+
+    @torch.no_grad()
+    def infer_files(self, clips: List[np.ndarray], slicer) -> List[List[Tuple[float, Dict[str, np.ndarray]]]]:
+        """Whole mono files -> per file [(chunk offset in seconds, {'note_midi', 'note_dur', 'note_rest'})]: the
+        ``Slicer(...).slice(waveform)`` + ``infer(chunks)`` pair of infer.py:35-38 / batch_infer.py:52-57 with the file
+        uploaded once as it is stored (int16 PCM), the slicer's RMS curve and the chunk cut computed on the device and
+        only the silence state machine left on the host.  Chunk boundaries and results equal the host path's."""
+        groups = self._group_files(clips)
+        sr = slicer.sr
+        results: List[List[Tuple[float, Dict[str, np.ndarray]]]] = [None] * len(clips)
+
+        def finish(p):
+            out, finite, batch, spans_per_file, idx = p
+            res = self._finish(out, finite, batch)
+            pos = 0
+            for i, spans in zip(idx, spans_per_file):
+                results[i] = [(a / sr, res[pos + k]) for k, (a, _) in enumerate(spans)]
+                pos += len(spans)
+
+        pending = None
+        staged = self._stage_files([clips[i] for i in groups[0]], slicer, 0) if groups else None
+        for g, idx in enumerate(groups):
+            launched = self._launch_files(staged, slicer)
+            if g + 1 < len(groups):                    # upload + RMS of the next group run under this group's forward
+                staged = self._stage_files([clips[i] for i in groups[g + 1]], slicer, (g + 1) & 1)
+            if pending is not None:
+                finish(pending)
+            pending = launched + (idx,)
+        if pending is not None:
+            finish(pending)
         return results

@@ -28,6 +28,17 @@ def load_wav(path, sr: int, mono: bool = True):
     return np.ascontiguousarray(y, dtype=np.float32), sr
 
 
+def load_pcm(path, sr: int):
+    """The same file as ``load_wav(path, sr, mono=True)`` but WITHOUT the host-side sample conversion when the payload
+    is mono int16 PCM: returns the int16 samples as stored (value = x / 32768, converted on the device by
+    some_pcm_gather / some_slicer_rms).  Any other layout goes through ``load_wav`` and comes back float32."""
+    from scipy.io import wavfile
+    file_sr, data = wavfile.read(str(path))
+    if data.dtype == np.int16 and data.ndim == 1 and file_sr == sr:
+        return np.ascontiguousarray(data), sr
+    return load_wav(path, sr, mono=True)
+
+
 def save_wav(path, y: np.ndarray, sr: int):
     from scipy.io import wavfile
     pcm = np.clip(np.round(np.asarray(y, dtype=np.float64) * 32768.0), -32768, 32767).astype(np.int16)

@@ -20,3 +20,19 @@ extern "C" void emu_rfft_mag(const float* x2048, const float* window2048, float*
     }
     for (int k = 0; k <= 1024; ++k) mag1025[k] = rfft_mag(k, in, tw.data());
 }
+
+// ---- slicer RMS: the device summation order (some_amd/csrc/rms_core.h), one frame at a time -----------------------
+#include <cstdint>
+#include "../../some_amd/csrc/rms_core.h"
+
+extern "C" void emu_slicer_rms(const float* y, int64_t n, int frame_length, int hop, float* rms) {
+    const int64_t frames = 1 + n / hop;
+    for (int64_t j = 0; j < frames; ++j) {
+        const int64_t first = j * hop - frame_length / 2;
+        const float sum = rms_pairwise_sumsq([&](int i) {
+            const int64_t q = first + i;
+            return (q >= 0 && q < n) ? y[q] : 0.f;
+        }, frame_length);
+        rms[j] = std::sqrt(sum / (float)frame_length);
+    }
+}

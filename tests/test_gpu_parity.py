@@ -193,6 +193,31 @@ def test_decode_golden_bit_exact(golden_dir, ci):
     np.testing.assert_allclose(out['note_midi'].cpu().numpy()[:n], g[k + '.note_midi'], rtol=1e-6, atol=0)
 
 
+def test_decode_scaled_value_range(golden_dir):
+    """Non-default midi_min / midi_max / deviation / threshold: the reference's values from identical probs, and the
+    sequential numpy oracle bit for bit (idx * interval + vmin must round twice - no fused multiply-add)."""
+    from oracle import restate
+    from some_amd.engine import ClipBatch, Engine
+    g = np.load(golden_dir / 'decode_scaled.npz')
+    cfg = get_config('midi_conformer', lay=0)
+    cfg.update({k: float(g[k]) for k in ('midi_min', 'midi_max', 'midi_prob_deviation', 'rest_threshold')})
+    eng = Engine(cfg, device='cuda')
+    batch = ClipBatch([len(g['bounds'])], 'cuda')
+    out = eng.decode(torch.from_numpy(g['probs']).cuda(), torch.from_numpy(g['bounds']).cuda(), batch, quantized=False, debug=True)
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    n = int(out['n_notes'][0])
+    np.testing.assert_array_equal(out['frame2item'], g['frame2item'])
+    np.testing.assert_array_equal(out['rest'].astype(bool), g['rest'])
+    np.testing.assert_allclose(out['values'], g['values'], rtol=1e-6, atol=0)
+    assert n == len(g['note_dur_frames'])
+    np.testing.assert_array_equal(out['note_dur'][:n], g['note_dur_frames'])
+    np.testing.assert_array_equal(out['note_rest'][:n].astype(bool), g['note_rest'])
+    np.testing.assert_allclose(out['note_midi'][:n], g['note_midi'], rtol=1e-6, atol=0)
+    ref = restate.postprocess(g['probs'], g['bounds'], cfg, quantized=False)
+    np.testing.assert_array_equal(out['values'], ref['_values'])
+    np.testing.assert_array_equal(out['note_midi'][:n], ref['note_midi'])
+
+
 def test_decode_vs_oracle_bit_exact_batch_and_mask():
     """GPU decoder == sequential numpy oracle (which fixes the summation order) exactly, incl. fp32 values,
     on a ragged batch with masked frames."""

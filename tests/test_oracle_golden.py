@@ -81,6 +81,20 @@ def test_decode_cases(golden_dir, ci):
     assert res['note_midi'].dtype == np.float32
 
 
+def test_decode_scaled_value_range(golden_dir):
+    """Non-default midi_min / midi_max / deviation / threshold (interval 60.5 / 127: idx * interval + vmin rounds twice)."""
+    g = np.load(golden_dir / 'decode_scaled.npz')
+    cfg = get_config('midi_conformer')
+    cfg.update({k: float(g[k]) for k in ('midi_min', 'midi_max', 'midi_prob_deviation', 'rest_threshold')})
+    res = restate.postprocess(g['probs'], g['bounds'], cfg, quantized=False)
+    np.testing.assert_array_equal(res['_frame2item'], g['frame2item'])
+    np.testing.assert_array_equal(res['_rest'], g['rest'])
+    np.testing.assert_allclose(res['_values'], g['values'], rtol=1e-6, atol=0)
+    np.testing.assert_array_equal(res['note_rest'], g['note_rest'])
+    np.testing.assert_allclose(res['note_midi'], g['note_midi'], rtol=1e-6, atol=0)
+    assert len(res['note_midi']) == len(g['note_dur_frames'])
+
+
 @pytest.mark.parametrize('name', ['e2e_conf', 'e2e_quant'])
 def test_end_to_end_clip(golden_dir, name):
     meta = json.loads((golden_dir / 'e2e.json').read_text())[name]

@@ -42,6 +42,32 @@ def main():
     print(f'{args.clips} x {args.seconds:g} s clips from host memory: {dt * 1e3:.1f} ms  ->  '
           f'{args.clips * args.seconds / dt:.0f} audio-s/s end to end ({notes} notes)')
 
+    # whole FILES (int16 PCM as stored, 0.6 s silences every 8 s so the slicer cuts): host Slicer + infer vs the
+    # device ingest (upload int16, RMS + chunk cut on the GPU, silence state machine on the host)
+    from some_amd.utils.slicer2 import Slicer
+    slicer = Slicer(sr=44100, max_sil_kept=1000)
+    fbase = [synth.synth_clip(100 + i, args.seconds, silence_every=8.0) for i in range(8)]
+    pcm8 = [np.clip(np.round(w.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16) for w in fbase]
+    files = [pcm8[i % 8] for i in range(args.clips)]
+
+    def host_path():
+        chunks = []
+        for p in files:
+            w = p.astype(np.float32) / np.float32(32768.0)                   # utils/audio.load_wav
+            chunks.extend(c['waveform'] for c in slicer.slice(w))
+        return ins.infer(chunks)
+
+    for name, fn in (('host Slicer + infer', host_path), ('device ingest infer_files', lambda: ins.infer_files(files, slicer))):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_seg = len(out) if name.startswith('host') else sum(len(f) for f in out)
+        print(f'{args.clips} int16 files x {args.seconds:g} s, {name}: {dt * 1e3:.1f} ms  ->  '
+              f'{args.clips * args.seconds / dt:.0f} audio-s/s ({n_seg} chunks)')
+
 
 if __name__ == '__main__':
     main()
