@@ -13,6 +13,7 @@ from csv import DictReader, DictWriter
 from typing import Dict, List
 
 import click
+import numpy as np
 
 from infer import load_inference
 from some_amd import batch_logic, sharding
@@ -59,10 +60,19 @@ def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, 
 
     slicer = Slicer(sr=config['audio_sample_rate'], max_sil_kept=1000)
 
+    device_ingest = hasattr(infer_ins, 'infer_files')      # any other BaseInference: host Slicer + infer(), as the reference
+
     def flush(group):
         # Slicer.slice + infer of batch_infer.py:52-57 for many rows at once: files go up as stored (int16 PCM), the
         # RMS curve and the chunk cut run on the device, the silence decisions on the host
-        per_file = infer_ins.infer_files([pcm for _, pcm in group], slicer)
+        if device_ingest:
+            per_file = infer_ins.infer_files([pcm for _, pcm in group], slicer)
+        else:
+            per_file = []
+            for _, pcm in group:
+                wave = pcm if pcm.dtype == np.float32 else pcm.astype(np.float32) / np.float32(32768.0)
+                chunks = slicer.slice(wave)
+                per_file.append(list(zip([c['offset'] for c in chunks], infer_ins.infer([c['waveform'] for c in chunks]))))
         for (i, _), segments in zip(group, per_file):
             notes = batch_logic.notes_from_segments([off for off, _ in segments], [seg for _, seg in segments])
             out[i] = batch_logic.align_row(notes, rows[i]['ph_dur'], rows[i]['ph_num'], round_midi)

@@ -36,6 +36,18 @@ class FakeInference:
         return out
 
 
+class FakeIngestInference(FakeInference):
+    """Adds the whole-file entry point (``MIDIExtractionInference.infer_files``) with the slicing done on the host."""
+
+    def infer_files(self, files, slicer):
+        out = []
+        for pcm in files:
+            wave = pcm if pcm.dtype == np.float32 else pcm.astype(np.float32) / np.float32(32768.0)
+            chunks = slicer.slice(wave)
+            out.append(list(zip([c['offset'] for c in chunks], self.infer([c['waveform'] for c in chunks]))))
+        return out
+
+
 def build_dataset(root: pathlib.Path, n_rows: int = 5, extra_missing_row: bool = True):
     """wavs/clip_XX.wav (int16 PCM, with silences so the Slicer cuts) + transcriptions.csv."""
     (root / 'wavs').mkdir(parents=True, exist_ok=True)

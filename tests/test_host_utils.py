@@ -56,15 +56,17 @@ def test_batch_logic_functions_match_reference(golden_dir):
             assert got == want['all']
 
 
+@pytest.mark.parametrize('stub', ['FakeInference', 'FakeIngestInference'])
 @pytest.mark.parametrize('tag,round_midi', [('round', True), ('full', False)])
-def test_batch_infer_csv_text_matches_reference(golden_dir, tmp_path, tag, round_midi, monkeypatch):
+def test_batch_infer_csv_text_matches_reference(golden_dir, tmp_path, tag, round_midi, stub, monkeypatch):
     """Our batch_infer command with the model stubbed out == the reference's command with the same stub,
-    byte for byte (CSV order, skipped missing wav, rounding, rest filling)."""
+    byte for byte (CSV order, skipped missing wav, rounding, rest filling) - both through the reference's generic
+    ``infer`` interface and through the whole-file ``infer_files`` entry point the HIP inference classes add."""
     import batch_infer as bi
     import dataset_util
     from some_amd.configs import get_config
     dataset_util.build_dataset(tmp_path)
-    monkeypatch.setattr(bi, 'model_init', lambda p: (dataset_util.FakeInference(), get_config('midi_conformer')))
+    monkeypatch.setattr(bi, 'model_init', lambda p: (getattr(dataset_util, stub)(), get_config('midi_conformer')))
     out = tmp_path / f'out_{tag}.csv'
     bi.batch_infer.callback(dataset=str(tmp_path), model=str(tmp_path / 'm.ckpt'), round_midi=round_midi, csv=str(out), overwrite=True)
     assert out.read_bytes() == (golden_dir / f'batch_csv_{tag}.csv').read_bytes()

@@ -36,7 +36,7 @@ ref = eng.pack_state_dict(synth.synth_state_dict(cfg, 5))
 assert torch.equal(arena, ref), 'arena broadcast mismatch'
 # the command itself, with the model stubbed
 seen = []
-class Spy(dataset_util.FakeInference):
+class Spy(dataset_util.FakeIngestInference):
     def infer(self, waves):
         seen.append(len(waves))
         return super().infer(waves)
