@@ -122,3 +122,52 @@ def test_cpu_device_is_refused(tmp_path):
     from some_amd.configs import get_config
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         inference.MIDIExtractionInference(config=get_config('midi_conformer', lay=1), model_path=tmp_path / 'x.ckpt', device='cpu')
+
+
+def test_extraction_service_dispatch_logic(tmp_path):
+    """The service's queue / coalescing / error-string logic with the model stubbed (no GPU): every request gets its
+    own result, requests that queued up together share one ``infer_files`` call, handler errors are strings."""
+    import threading
+    import dataset_util
+    from some_amd.configs import get_config
+    from some_amd.serving import ExtractionService
+    from some_amd.utils.audio import save_wav
+
+    calls = []
+
+    class Stub(dataset_util.FakeIngestInference):
+        def infer_files(self, files, slicer):
+            calls.append(len(files))
+            gate.wait(timeout=30)
+            return super().infer_files(files, slicer)
+
+    gate = threading.Event()
+    files = [np.clip(np.round(synth.synth_clip(500 + i, 1.0 + i).astype(np.float64) * 32768), -32768, 32767).astype(np.int16)
+             for i in range(6)]
+    with ExtractionService(work_dir=tmp_path) as svc:
+        svc._instances['m.ckpt'] = (Stub(), get_config('midi_conformer'))
+        futs = [svc.submit('m.ckpt', files[0])]           # occupies the dispatcher (blocked on the gate) ...
+        while not calls:
+            pass
+        futs += [svc.submit('m.ckpt', f) for f in files[1:]]      # ... while these queue up
+        gate.set()
+        res = [f.result(timeout=60) for f in futs]
+        assert calls == [1, 5] and svc.batches_run == 2 and svc.requests_served == 6
+        ref = dataset_util.FakeIngestInference()
+        from some_amd.utils.slicer2 import Slicer
+        for f, r in zip(files, res):
+            want = ref.infer_files([f], Slicer(sr=44100, max_sil_kept=1000))[0]
+            assert len(r) == len(want)
+            for (o1, a), (o2, b) in zip(r, want):
+                assert o1 == o2 and np.array_equal(a['note_dur'], b['note_dur'])
+        wav = tmp_path / 'a.wav'
+        save_wav(wav, synth.synth_clip(1, 2.0), 44100)
+        mid, msg = svc.extract_midi('m.ckpt', wav, 120, output_midi_path=tmp_path / 'o.mid')
+        assert mid.read_bytes()[:4] == b'MThd' and msg.startswith('Cost ')
+        assert svc.extract_midi(None, wav, 120)[1] == 'Error: required inputs not specified.'
+        (tmp_path / 'bad.wav').write_bytes(b'xx')
+        assert svc.extract_midi('m.ckpt', tmp_path / 'bad.wav', 120)[0] is None
+        with pytest.raises(ValueError):
+            svc.submit('m.ckpt', np.zeros((2, 10), dtype=np.float32))
+    with pytest.raises(RuntimeError):
+        svc.submit('m.ckpt', files[0])
