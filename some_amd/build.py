@@ -19,6 +19,7 @@ LIB = HERE / 'libsome_amd.so'
 SOURCES = ['api.hip', 'gemm.hip', 'gemm_f16x3.hip', 'rowops.hip', 'attention.hip', 'attention_f16x3.hip', 'dwconv.hip', 'logmel.hip', 'decode.hip', 'ingest.hip']
 HEADERS = [CSRC / 'internal.h', CSRC / 'fft_core.h', CSRC / 'split.h', CSRC / 'rms_core.h', HERE.parent / 'include' / 'some_amd.h']
 ARCH = 'gfx950'
+EXTRA_FLAGS = {}        # per-source additions, e.g. {'attention_f16x3.hip': ['-fno-slp-vectorize']}
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
 
 
@@ -47,7 +48,7 @@ def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ['-c', str(s), '-o', str(o)]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s.name, []) + os.environ.get('SOME_AMD_HIPCC_FLAGS', '').split() + ['-c', str(s), '-o', str(o)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed for {s.name}:\n{r.stdout}\n{r.stderr}')

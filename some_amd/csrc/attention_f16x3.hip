@@ -26,11 +26,19 @@ constexpr int LDR = 68;                         // LDS row (dwords): 64 data + 4
 constexpr int K_DW = KT * LDR;                  // K tile: [64 keys][hi|lo hi|lo]
 constexpr int V_DW = kHeadDim * LDR;            // V^T tile: [64 d][64 keys hi | 64 keys lo]
 constexpr size_t LDS_BYTES = 2 * (K_DW + V_DW) * sizeof(float);
-constexpr float kPShift = 14.f;                 // P is carried as 2^14 p (see softmax)
+#ifndef ATTN_LAZY_RESCALE
+#define ATTN_LAZY_RESCALE 0
+#endif
+constexpr float kLazy = 8.f;                    // lazy rescale threshold (log2 domain)
+constexpr float kPShift = ATTN_LAZY_RESCALE ? 14.f - kLazy : 14.f;   // P is carried as 2^kPShift p <= 2^14 (see softmax)
 
 __device__ __forceinline__ float exp2_(float x) { return __builtin_amdgcn_exp2f(x); }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef ATTN_PACKED_F32
+#define ATTN_PACKED_F32 0       // softmax / P split on v_pk_fma_f32 / v_pk_add_f32 (0: scalar fp32 VALU)
+#endif
 
 // v_max3_f32 without the v_max_f32 x, x, x canonicalisation clang puts in front of every fmaxf operand (scores are
 // MFMA results or -inf, never signalling NaNs)
@@ -52,9 +60,14 @@ __device__ __forceinline__ void split8(const f32x16& p, int base, half8& h, half
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
         const float p0 = p[base + i], p1 = p[base + i + 1];      // (scalars: bit_cast of a vector element miscompiles)
+#if ATTN_PACKED_F32
         const f32x2 pp = {p0, p1};
         const f32x2 hf = {__uint_as_float(__float_as_uint(p0) & 0xFFFFE000u), __uint_as_float(__float_as_uint(p1) & 0xFFFFE000u)};
         const f32x2 lf = pp - hf;
+#else
+        const float hf[2] = {__uint_as_float(__float_as_uint(p0) & 0xFFFFE000u), __uint_as_float(__float_as_uint(p1) & 0xFFFFE000u)};
+        const float lf[2] = {p0 - hf[0], p1 - hf[1]};
+#endif
         const half2_t hh = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(hf[0], hf[1]));
         const half2_t ll = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(lf[0], lf[1]));
         h[i] = hh[0]; h[i + 1] = hh[1];
@@ -184,11 +197,28 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
         }
         float mx = max2_(mxa, mxb);
         mx = max2_(mx, __shfl_xor(mx, 32, 64));
+#if ATTN_LAZY_RESCALE
+        // cdna guide T13: the running maximum only moves (and O, l are only rescaled) when some query's tile maximum
+        // exceeds it by more than 2^kLazy; until then p may reach 2^kLazy (kPShift leaves that headroom in f16)
+        const float ms = mx * c;
+        if (!__all(ms - m_run <= kLazy)) {
+            const float m_up = max2_(m_run, ms);
+            const float alpha = exp2_(m_run - m_up);    // first tile: exp2(-inf) = 0
+            m_run = m_up;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+        const float m_new = m_run;
+        const float alpha = 1.f;
+#else
         const float m_new = max2_(m_run, mx * c);      // finite: every tile holds at least one key of the clip
         const float alpha = exp2_(m_run - m_new);       // first tile: exp2(-inf) = 0
         m_run = m_new;
+#endif
         // probabilities are kept scaled by 2^kPShift (<= 16384, inside f16): keys far below the running maximum
         // stay out of the f16 subnormal range when P is split; the scale cancels in O / l
+#if ATTN_PACKED_F32
         const f32x2 c2 = {c, c}, nm2 = {kPShift - m_new, kPShift - m_new};
         f32x2 ps = {0.f, 0.f};
 #pragma unroll
@@ -201,11 +231,21 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
             s1[r] = e1[0]; s1[r + 1] = e1[1];
             ps += e0 + e1;
         }
+#else
+        const float nm = kPShift - m_new;
+        float ps[2] = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = exp2_(fmaf(s0[r], c, nm));
+            s1[r] = exp2_(fmaf(s1[r], c, nm));
+            ps[r & 1] += s0[r] + s1[r];
+        }
+#endif
         l_run = l_run * alpha + (ps[0] + ps[1]);
-        // unconditional (no wave-uniform "max did not move" branch): a branch here would split the basic block and
-        // stop the scheduler from spreading this VALU work under the QK(i+1) MFMAs
+#if !ATTN_LAZY_RESCALE
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#endif
     };
     // O^T += V^T P^T for tile i.  P slab (sub, s'): registers r = 8 s' .. 8 s' + 7 of the sub-tile hold keys
     // 16 s' + {0..3} + 4 kg and 16 s' + 8 + {0..3} + 4 kg  ->  two ds_read_b64 per V^T fragment
