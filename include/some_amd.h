@@ -188,6 +188,73 @@ int some_slicer_rms(SomeHandle* h, const void* audio_dev, int32_t sample_format,
 int some_pcm_gather(SomeHandle* h, const void* src_dev, int32_t sample_format, const int64_t* src_offsets_dev,
                     const int64_t* dst_offsets_dev, int32_t B, int64_t max_len, float* audio_out_dev, void* stream);
 
+/* ---- training operators (train.py, training/me_task.py:79-111) ------------------
+ * Forward + backward building blocks of midi_conforms in train mode on packed [M, C] fp32 activations (M = B * T_max
+ * frames of the padded training batch).  The dense contractions reuse some_op_gemm (weight gradients contract over M:
+ * dW = dY^T X is some_op_gemm on the two transposes).  `scratch_dev` arguments need some_train_scratch_bytes(M, N)
+ * bytes; column reductions are two-pass and deterministic. */
+size_t some_train_scratch_bytes(const SomeHandle* h, int64_t M, int32_t N);
+
+/* out[n, m] = in[m, n] for m < M, 0 for M <= m < ld_out (the zero padding makes ld_out a valid contraction length). */
+int some_train_transpose(SomeHandle* h, const float* in_dev, int32_t M, int32_t N, int32_t ld_in, float* out_dev,
+                         int32_t ld_out, void* stream);
+/* out[n] (+)= sum_m x[m, n]: bias gradient of nn.Linear / Conv1d. */
+int some_train_colsum(SomeHandle* h, const float* x_dev, int32_t M, int32_t N, int32_t ld, float* out_dev,
+                      int32_t accumulate, void* scratch_dev, size_t scratch_bytes, void* stream);
+/* nn.LayerNorm(512, eps 1e-5) forward with saved statistics, and its backward (Gconform.py:48-52). */
+int some_train_layernorm_fwd(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                             float* y_dev, float* mean_dev, float* rstd_dev, int32_t M, void* stream);
+int some_train_layernorm_bwd(SomeHandle* h, const float* dy_dev, const float* x_dev, const float* gamma_dev,
+                             const float* mean_dev, const float* rstd_dev, float* dx_dev, float* dgamma_dev,
+                             float* dbeta_dev, int32_t accumulate, int32_t M, void* scratch_dev, size_t scratch_bytes,
+                             void* stream);
+/* nn.BatchNorm1d(C) in train mode over the M rows (base_conv.py:56): batch statistics, running-stat update
+ * (momentum, unbiased variance), saved mean / rstd for the backward. */
+int some_train_batchnorm_fwd(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                             int32_t M, int32_t C, float eps, float momentum, float* running_mean_dev,
+                             float* running_var_dev, float* y_dev, float* save_mean_dev, float* save_rstd_dev,
+                             void* scratch_dev, size_t scratch_bytes, void* stream);
+int some_train_batchnorm_bwd(SomeHandle* h, const float* dy_dev, const float* x_dev, const float* gamma_dev,
+                             const float* save_mean_dev, const float* save_rstd_dev, int32_t M, int32_t C,
+                             float* dx_dev, float* dgamma_dev, float* dbeta_dev, void* scratch_dev,
+                             size_t scratch_bytes, void* stream);
+#define SOME_ELT_SILU_FWD 0     /* out = a silu                                       */
+#define SOME_ELT_SILU_BWD 1     /* out = a * silu'(b)        a = dy, b = pre-activation */
+#define SOME_ELT_SIGMOID_FWD 2  /* out = sigmoid(a)                                   */
+#define SOME_ELT_SIGMOID_BWD 3  /* out = a * b * (1 - b)     a = dy, b = sigmoid output */
+#define SOME_ELT_AXPY 4         /* out = alpha * a + b       (x = f(x) * 0.5 + x, Gconform.py:57,60); b NULL: alpha * a */
+#define SOME_ELT_DROPOUT 5      /* out = a * keep / (1 - alpha), keep ~ Bernoulli(1 - alpha) from (seed, index) */
+int some_train_eltwise(SomeHandle* h, int32_t op, const float* a_dev, const float* b_dev, float* out_dev, int64_t n,
+                       float alpha, uint64_t seed, void* stream);
+/* GLU over channel halves of [M, 2C] (Gconform.py:11-17, base_conv.py:7-15); backward = 1: dy [M, C], x -> dx [M, 2C]. */
+int some_train_glu(SomeHandle* h, const float* dy_dev, const float* x_dev, float* out_dev, int64_t M, int32_t C,
+                   int32_t backward, void* stream);
+/* x.masked_fill(~mask[:, None], 0) (Gconform.py:128-133); the same call maps dy -> dx. */
+int some_train_mask_rows(SomeHandle* h, const float* x_dev, const uint8_t* mask_dev, float* y_dev, int64_t M,
+                         int32_t C, void* stream);
+/* Depthwise Conv1d(C, C, 31, padding 15, groups C) over time inside each clip (base_conv.py:48-53); taps [31, C]
+ * (tap-major), bias may be NULL.  flip = 1 applies the taps reversed: the data gradient dx = conv(dy, flip(w)). */
+int some_train_dwconv(SomeHandle* h, const float* x_dev, const float* taps_dev, const float* bias_dev,
+                      const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, float* y_dev, int32_t C,
+                      int32_t flip, void* stream);
+/* dtaps[k, c] (+)= sum_t dy[t, c] x[t + k - 15, c]; clip_of_row_dev: int32 [M], the clip index of every row. */
+int some_train_dwconv_bwd_taps(SomeHandle* h, const float* dy_dev, const float* x_dev, const int32_t* clip_of_row_dev,
+                               const int32_t* frame_offsets_dev, int32_t M, int32_t C, float* dtaps_dev,
+                               int32_t accumulate, void* scratch_dev, size_t scratch_bytes, void* stream);
+/* nn.BCEWithLogitsLoss() (mean over all n elements; training/me_task.py:74,105): loss_dev[0] and, when dlogits_dev is
+ * not NULL, d loss / d logits. */
+int some_train_bce_with_logits(SomeHandle* h, const float* logits_dev, const float* target_dev, int64_t n,
+                               float* dlogits_dev, float* loss_dev, void* scratch_dev, size_t scratch_bytes,
+                               void* stream);
+/* modules.losses.BinaryEMDLoss() (modules/losses/bound_loss.py:6-19, bidirectional=False) on [B, T] rows. */
+int some_train_binary_emd(SomeHandle* h, const float* pred_dev, const float* gt_dev, int32_t B, int32_t T,
+                          float* dpred_dev, float* loss_dev, void* scratch_dev, size_t scratch_bytes, void* stream);
+/* torch.optim.AdamW step (configs/two_head_model.yaml:42-47) on flat arrays; step counts from 1; the gradient is
+ * multiplied by grad_scale first (1 / world_size after a summing all-reduce). */
+int some_train_adamw(SomeHandle* h, float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
+                     int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                     float grad_scale, void* stream);
+
 /* ---- single-operator entry points (kernel-level parity tests and micro-benchmarks) ------------------ */
 
 #define SOME_EPI_NONE 0       /* C = A W^T                                                          */

@@ -139,6 +139,30 @@ hipError_t launch_slicer_rms(const void* audio, int is_pcm16, const int64_t* sam
 hipError_t launch_pcm_gather(const void* src, int is_pcm16, const int64_t* src_offsets, const int64_t* dst_offsets, int B,
                              int64_t max_len, float* dst, hipStream_t s);
 
+// ---- training operators (train_ops.hip) -------------------------------------------------------------------
+size_t train_col_scratch_bytes(int M, int N);
+size_t train_dwconv_w_scratch_bytes(int M, int C);
+hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, hipStream_t s);
+hipError_t launch_colsum(const float* x, int M, int N, int ld, float* out, int accumulate, float* scratch, hipStream_t s);
+hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, hipStream_t s);
+hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx,
+                         float* dgamma, float* dbeta, int accumulate, int M, float* scratch, hipStream_t s);
+hipError_t launch_bn_fwd(const float* x, const float* g, const float* b, int M, int C, float eps, float momentum, float* running_mean,
+                         float* running_var, float* y, float* save_mean, float* save_rstd, float* scratch, hipStream_t s);
+hipError_t launch_bn_bwd(const float* dy, const float* x, const float* g, const float* save_mean, const float* save_rstd, int M, int C,
+                         float* dx, float* dgamma, float* dbeta, float* scratch, hipStream_t s);
+hipError_t launch_eltwise(int op, const float* a, const float* b, float* out, int64_t n, float alpha, uint64_t seed, hipStream_t s);
+hipError_t launch_glu(const float* dy, const float* x, float* out, int64_t M, int C, int backward, hipStream_t s);
+hipError_t launch_mask_rows(const float* x, const uint8_t* mask, float* y, int64_t M, int C, hipStream_t s);
+hipError_t launch_dwconv_train(const float* x, const float* w, const float* bias, const int32_t* frame_offsets, int B, int max_frames, float* y,
+                               int C, int flip, hipStream_t s);
+hipError_t launch_dwconv_bwd_w(const float* dy, const float* x, const int32_t* clip_of_row, const int32_t* frame_offsets, int M, int C, float* dw,
+                               int accumulate, float* scratch, hipStream_t s);
+hipError_t launch_bce(const float* x, const float* t, int64_t n, float* dx, float* loss, double* scratch, hipStream_t s);
+hipError_t launch_emd(const float* pred, const float* gt, int B, int T, float* dpred, float* loss, double* scratch, hipStream_t s);
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        int step, float grad_scale, hipStream_t s);
+
 // ---- profiling ------------------------------------------------------------------------------------
 struct ProfRecord { std::string name; hipEvent_t e0, e1; double flops, bytes; };
 

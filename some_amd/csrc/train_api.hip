@@ -1,0 +1,189 @@
+// C ABI of the training operators (include/some_amd.h, "training operators"): argument checks + launches.
+#include <string>
+
+#include "internal.h"
+
+namespace {
+
+int tfail(SomeHandle* h, int code, const char* msg) {
+    if (h) h->err = msg;
+    return code;
+}
+#define T_TRY(h, expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            if (h) (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                         \
+            return SOME_EHIP;                                                                            \
+        }                                                                                                \
+    } while (0)
+#define T_CHECK(h, cond, msg) \
+    do { if (!(cond)) return tfail((h), SOME_EINVAL, msg); } while (0)
+
+inline hipStream_t st(void* s) { return static_cast<hipStream_t>(s); }
+inline size_t chunks(int64_t M) { return (size_t)((M + 511) / 512); }
+
+}  // namespace
+
+extern "C" {
+
+size_t some_train_scratch_bytes(const SomeHandle* h, int64_t M, int32_t N) {
+    (void)h;
+    if (M <= 0 || N <= 0) return 256;
+    const size_t col = chunks(M) * (size_t)(kConvK > 2 ? kConvK : 2) * (size_t)N * sizeof(float);   // column partials / tap partials
+    const size_t loss = 1024 * sizeof(double) + (size_t)M * sizeof(double) / 64 + 8192;             // loss partials (<= 1024 blocks or B rows)
+    return (col > loss ? col : loss) + 256;
+}
+
+int some_train_transpose(SomeHandle* h, const float* in_dev, int32_t M, int32_t N, int32_t ld_in, float* out_dev,
+                         int32_t ld_out, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M >= 0 && N >= 0 && ld_in >= N && ld_out >= M, "some_train_transpose: bad shape");
+    if (M == 0 || N == 0) return SOME_OK;
+    T_CHECK(h, in_dev && out_dev, "some_train_transpose: null pointer");
+    T_TRY(h, launch_transpose(in_dev, M, N, ld_in, out_dev, ld_out, st(stream)));
+    return SOME_OK;
+}
+
+int some_train_colsum(SomeHandle* h, const float* x_dev, int32_t M, int32_t N, int32_t ld, float* out_dev,
+                      int32_t accumulate, void* scratch_dev, size_t scratch_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M >= 0 && N > 0 && ld >= N && out_dev, "some_train_colsum: bad argument");
+    if (M == 0) return SOME_OK;
+    T_CHECK(h, x_dev && scratch_dev && scratch_bytes >= train_col_scratch_bytes(M, N), "some_train_colsum: scratch too small");
+    T_TRY(h, launch_colsum(x_dev, M, N, ld, out_dev, accumulate, static_cast<float*>(scratch_dev), st(stream)));
+    return SOME_OK;
+}
+
+int some_train_layernorm_fwd(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                             float* y_dev, float* mean_dev, float* rstd_dev, int32_t M, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M >= 0 && x_dev && gamma_dev && beta_dev && y_dev && mean_dev && rstd_dev, "some_train_layernorm_fwd: bad argument");
+    T_TRY(h, launch_ln_fwd(x_dev, gamma_dev, beta_dev, y_dev, mean_dev, rstd_dev, M, st(stream)));
+    return SOME_OK;
+}
+
+int some_train_layernorm_bwd(SomeHandle* h, const float* dy_dev, const float* x_dev, const float* gamma_dev,
+                             const float* mean_dev, const float* rstd_dev, float* dx_dev, float* dgamma_dev,
+                             float* dbeta_dev, int32_t accumulate, int32_t M, void* scratch_dev, size_t scratch_bytes,
+                             void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M >= 0 && dy_dev && x_dev && gamma_dev && mean_dev && rstd_dev && dx_dev && dgamma_dev && dbeta_dev,
+            "some_train_layernorm_bwd: bad argument");
+    if (M == 0) return SOME_OK;
+    T_CHECK(h, scratch_dev && scratch_bytes >= train_col_scratch_bytes(M, kDim), "some_train_layernorm_bwd: scratch too small");
+    T_TRY(h, launch_ln_bwd(dy_dev, x_dev, gamma_dev, mean_dev, rstd_dev, dx_dev, dgamma_dev, dbeta_dev, accumulate, M,
+                           static_cast<float*>(scratch_dev), st(stream)));
+    return SOME_OK;
+}
+
+int some_train_batchnorm_fwd(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                             int32_t M, int32_t C, float eps, float momentum, float* running_mean_dev,
+                             float* running_var_dev, float* y_dev, float* save_mean_dev, float* save_rstd_dev,
+                             void* scratch_dev, size_t scratch_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M > 0 && C > 0 && (C % 4) == 0 && x_dev && gamma_dev && beta_dev && y_dev && save_mean_dev && save_rstd_dev,
+            "some_train_batchnorm_fwd: bad argument");
+    T_CHECK(h, (running_mean_dev == nullptr) == (running_var_dev == nullptr), "some_train_batchnorm_fwd: running stats come in pairs");
+    T_CHECK(h, scratch_dev && scratch_bytes >= train_col_scratch_bytes(M, C), "some_train_batchnorm_fwd: scratch too small");
+    T_TRY(h, launch_bn_fwd(x_dev, gamma_dev, beta_dev, M, C, eps, momentum, running_mean_dev, running_var_dev, y_dev, save_mean_dev,
+                           save_rstd_dev, static_cast<float*>(scratch_dev), st(stream)));
+    return SOME_OK;
+}
+
+int some_train_batchnorm_bwd(SomeHandle* h, const float* dy_dev, const float* x_dev, const float* gamma_dev,
+                             const float* save_mean_dev, const float* save_rstd_dev, int32_t M, int32_t C,
+                             float* dx_dev, float* dgamma_dev, float* dbeta_dev, void* scratch_dev,
+                             size_t scratch_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M > 0 && C > 0 && (C % 4) == 0 && dy_dev && x_dev && gamma_dev && save_mean_dev && save_rstd_dev && dx_dev && dgamma_dev && dbeta_dev,
+            "some_train_batchnorm_bwd: bad argument");
+    T_CHECK(h, scratch_dev && scratch_bytes >= train_col_scratch_bytes(M, C), "some_train_batchnorm_bwd: scratch too small");
+    T_TRY(h, launch_bn_bwd(dy_dev, x_dev, gamma_dev, save_mean_dev, save_rstd_dev, M, C, dx_dev, dgamma_dev, dbeta_dev,
+                           static_cast<float*>(scratch_dev), st(stream)));
+    return SOME_OK;
+}
+
+int some_train_eltwise(SomeHandle* h, int32_t op, const float* a_dev, const float* b_dev, float* out_dev, int64_t n,
+                       float alpha, uint64_t seed, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, op >= 0 && op <= SOME_ELT_DROPOUT && n >= 0, "some_train_eltwise: bad op or size");
+    if (n == 0) return SOME_OK;
+    const bool needs_b = op == SOME_ELT_SILU_BWD || op == SOME_ELT_SIGMOID_BWD;
+    T_CHECK(h, a_dev && out_dev && (!needs_b || b_dev), "some_train_eltwise: null pointer");
+    T_CHECK(h, op != SOME_ELT_DROPOUT || (alpha >= 0.f && alpha < 1.f), "some_train_eltwise: dropout probability must be in [0, 1)");
+    T_TRY(h, launch_eltwise(op, a_dev, b_dev, out_dev, n, alpha, seed, st(stream)));
+    return SOME_OK;
+}
+
+int some_train_glu(SomeHandle* h, const float* dy_dev, const float* x_dev, float* out_dev, int64_t M, int32_t C,
+                   int32_t backward, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M >= 0 && C > 0 && x_dev && out_dev && (!backward || dy_dev), "some_train_glu: bad argument");
+    T_TRY(h, launch_glu(dy_dev, x_dev, out_dev, M, C, backward, st(stream)));
+    return SOME_OK;
+}
+
+int some_train_mask_rows(SomeHandle* h, const float* x_dev, const uint8_t* mask_dev, float* y_dev, int64_t M,
+                         int32_t C, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M >= 0 && C > 0 && x_dev && mask_dev && y_dev, "some_train_mask_rows: bad argument");
+    T_TRY(h, launch_mask_rows(x_dev, mask_dev, y_dev, M, C, st(stream)));
+    return SOME_OK;
+}
+
+int some_train_dwconv(SomeHandle* h, const float* x_dev, const float* taps_dev, const float* bias_dev,
+                      const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, float* y_dev, int32_t C,
+                      int32_t flip, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, B >= 0 && max_frames >= 0 && C > 0 && (C % 4) == 0 && B <= 65535, "some_train_dwconv: bad shape");
+    if (B == 0 || max_frames == 0) return SOME_OK;
+    T_CHECK(h, x_dev && taps_dev && frame_offsets_dev && y_dev, "some_train_dwconv: null pointer");
+    T_TRY(h, launch_dwconv_train(x_dev, taps_dev, bias_dev, frame_offsets_dev, B, max_frames, y_dev, C, flip, st(stream)));
+    return SOME_OK;
+}
+
+int some_train_dwconv_bwd_taps(SomeHandle* h, const float* dy_dev, const float* x_dev, const int32_t* clip_of_row_dev,
+                               const int32_t* frame_offsets_dev, int32_t M, int32_t C, float* dtaps_dev,
+                               int32_t accumulate, void* scratch_dev, size_t scratch_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M >= 0 && C > 0 && dtaps_dev, "some_train_dwconv_bwd_taps: bad argument");
+    if (M == 0) return SOME_OK;
+    T_CHECK(h, dy_dev && x_dev && clip_of_row_dev && frame_offsets_dev, "some_train_dwconv_bwd_taps: null pointer");
+    T_CHECK(h, scratch_dev && scratch_bytes >= train_dwconv_w_scratch_bytes(M, C), "some_train_dwconv_bwd_taps: scratch too small");
+    T_TRY(h, launch_dwconv_bwd_w(dy_dev, x_dev, clip_of_row_dev, frame_offsets_dev, M, C, dtaps_dev, accumulate,
+                                 static_cast<float*>(scratch_dev), st(stream)));
+    return SOME_OK;
+}
+
+int some_train_bce_with_logits(SomeHandle* h, const float* logits_dev, const float* target_dev, int64_t n,
+                               float* dlogits_dev, float* loss_dev, void* scratch_dev, size_t scratch_bytes,
+                               void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, n > 0 && logits_dev && target_dev && loss_dev, "some_train_bce_with_logits: bad argument");
+    T_CHECK(h, scratch_dev && scratch_bytes >= 1024 * sizeof(double), "some_train_bce_with_logits: scratch too small");
+    T_TRY(h, launch_bce(logits_dev, target_dev, n, dlogits_dev, loss_dev, static_cast<double*>(scratch_dev), st(stream)));
+    return SOME_OK;
+}
+
+int some_train_binary_emd(SomeHandle* h, const float* pred_dev, const float* gt_dev, int32_t B, int32_t T,
+                          float* dpred_dev, float* loss_dev, void* scratch_dev, size_t scratch_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, B > 0 && T > 0 && pred_dev && gt_dev && loss_dev, "some_train_binary_emd: bad argument");
+    T_CHECK(h, scratch_dev && scratch_bytes >= (size_t)B * sizeof(double), "some_train_binary_emd: scratch too small");
+    T_TRY(h, launch_emd(pred_dev, gt_dev, B, T, dpred_dev, loss_dev, static_cast<double*>(scratch_dev), st(stream)));
+    return SOME_OK;
+}
+
+int some_train_adamw(SomeHandle* h, float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
+                     int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                     float grad_scale, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, n >= 0 && step >= 1, "some_train_adamw: bad argument (step counts from 1)");
+    if (n == 0) return SOME_OK;
+    T_CHECK(h, param_dev && grad_dev && exp_avg_dev && exp_avg_sq_dev, "some_train_adamw: null pointer");
+    T_TRY(h, launch_adamw(param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, st(stream)));
+    return SOME_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,552 @@
+// Training-side operators (train.py / training/me_task.py:79-111): everything of the
+// forward + backward pass of midi_conforms that is not a GEMM or attention.  All HBM-bound row / column movers over
+// packed [M, C] fp32 activations (M = B * T_max frames of the padded training batch, clip b = rows [bT, (b+1)T)):
+//
+//   transpose            dY^T / X^T operands of the weight-gradient GEMMs (the GEMM kernels contract the contiguous axis)
+//   column reductions    bias gradients, LayerNorm / BatchNorm gamma-beta gradients, BatchNorm batch statistics,
+//                        depthwise-conv tap gradients: deterministic two-pass (per-chunk partials, ordered final sum)
+//   layernorm fwd / bwd  nn.LayerNorm(512) with saved mean / rstd            (modules/conform/Gconform.py:48-52)
+//   batchnorm fwd / bwd  nn.BatchNorm1d(512) in train mode, running stats    (modules/conv/base_conv.py:56)
+//   silu, glu, sigmoid   fwd / bwd                                           (Gconform.py:11-17,27; base_conv.py:22,64-67)
+//   axpy, mask_rows, dropout                                                 (Gconform.py:57-61,128-133)
+//   depthwise conv fwd / bwd-data / bwd-taps, k = 31, zero padding per clip  (base_conv.py:48-53)
+//   BCEWithLogits(mean) and BinaryEMDLoss with their gradients               (training/me_task.py:74-75, modules/losses/bound_loss.py:6-19)
+//   AdamW step on flat parameter / gradient / moment arrays                  (configs/two_head_model.yaml:42-47)
+#include "internal.h"
+
+namespace {
+
+constexpr int kLnDim = kDim;                    // LayerNorm / BatchNorm width of the model (512)
+
+__device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- transpose ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int M, int N, int ld_in,
+                                                         float* __restrict__ out, int ld_out) {
+    __shared__ float tile[32][33];
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty + 8 * i, n = n0 + tx;
+        tile[ty + 8 * i][tx] = (m < M && n < N) ? in[(size_t)m * ld_in + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, m = m0 + tx;
+        if (n < N && m < ld_out) out[(size_t)n * ld_out + m] = tile[tx][ty + 8 * i];   // zeros beyond M
+    }
+}
+
+// ---- column reductions: partial[p][2][N] over row chunk p, then an ordered final sum -----------------------------
+constexpr int kChunkRows = 512;
+
+template <class F>
+__global__ __launch_bounds__(256) void col_partial_kernel(int M, int N, float* __restrict__ partial, F f) {
+    __shared__ float red[2][4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * kChunkRows, r1 = min(M, r0 + kChunkRows);
+    float s1 = 0.f, s2 = 0.f;
+    if (n < N)
+        for (int m = r0 + ty; m < r1; m += 4) f(m, n, s1, s2);
+    red[0][ty][threadIdx.x & 63] = s1;
+    red[1][ty][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        const int c = threadIdx.x;
+        float* p = partial + (size_t)blockIdx.y * 2 * N;
+        p[n] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        p[N + n] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    }
+}
+
+// out1[n] (+)= sum_p partial[p][0][n], out2[n] (+)= sum_p partial[p][1][n] in double, chunk order
+__global__ __launch_bounds__(256) void col_final_kernel(const float* __restrict__ partial, int P, int N, float* out1, float* out2,
+                                                         int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    double a = 0.0, b = 0.0;
+    for (int p = 0; p < P; ++p) { a += partial[(size_t)p * 2 * N + n]; b += partial[(size_t)p * 2 * N + N + n]; }
+    if (out1) out1[n] = (accumulate ? out1[n] : 0.f) + (float)a;
+    if (out2) out2[n] = (accumulate ? out2[n] : 0.f) + (float)b;
+}
+
+struct ColsumF {
+    const float* x; int ld;
+    __device__ void operator()(int m, int n, float& s1, float& s2) const { s1 += x[(size_t)m * ld + n]; (void)s2; }
+};
+struct ColStatsF {
+    const float* x; int ld;
+    __device__ void operator()(int m, int n, float& s1, float& s2) const { const float v = x[(size_t)m * ld + n]; s1 += v; s2 += v * v; }
+};
+struct LnGradF {         // s1 = sum dy (dbeta), s2 = sum dy * xhat (dgamma); per-ROW statistics
+    const float* dy; const float* x; const float* mean; const float* rstd; int ld;
+    __device__ void operator()(int m, int n, float& s1, float& s2) const {
+        const float d = dy[(size_t)m * ld + n];
+        s1 += d;
+        s2 += d * (x[(size_t)m * ld + n] - mean[m]) * rstd[m];
+    }
+};
+struct BnGradF {         // per-COLUMN statistics
+    const float* dy; const float* x; const float* mean; const float* rstd; int ld;
+    __device__ void operator()(int m, int n, float& s1, float& s2) const {
+        const float d = dy[(size_t)m * ld + n];
+        s1 += d;
+        s2 += d * (x[(size_t)m * ld + n] - mean[n]) * rstd[n];
+    }
+};
+
+// ---- LayerNorm (width 512): one wave per row, lane owns columns 4 l .. 4 l + 3 and 256 + 4 l .. -------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                      float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int M) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + (size_t)row * kLnDim + lane * 4);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(x + (size_t)row * kLnDim + 256 + lane * 4);
+    float s = (a0[0] + a0[1]) + (a0[2] + a0[3]) + (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    const float mu = wave_sum(s) * (1.0f / kLnDim);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { q += (a0[i] - mu) * (a0[i] - mu); q += (a1[i] - mu) * (a1[i] - mu); }
+    const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / kLnDim) + 1e-5f);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + lane * 4), g1 = *reinterpret_cast<const f32x4*>(g + 256 + lane * 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + lane * 4), b1 = *reinterpret_cast<const f32x4*>(b + 256 + lane * 4);
+    f32x4 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o0[i] = (a0[i] - mu) * rs * g0[i] + b0[i]; o1[i] = (a1[i] - mu) * rs * g1[i] + b1[i]; }
+    *reinterpret_cast<f32x4*>(y + (size_t)row * kLnDim + lane * 4) = o0;
+    *reinterpret_cast<f32x4*>(y + (size_t)row * kLnDim + 256 + lane * 4) = o1;
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx = rstd (g dy - mean(g dy) - xhat mean(g dy xhat))
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ dx, int M) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float mu = mean[row], rs = rstd[row];
+    float gd[8], xh[8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = h * 256 + lane * 4;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (size_t)row * kLnDim + c);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * kLnDim + c);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            gd[h * 4 + i] = d[i] * gv[i];
+            xh[h * 4 + i] = (xv[i] - mu) * rs;
+            s1 += gd[h * 4 + i];
+            s2 += gd[h * 4 + i] * xh[h * 4 + i];
+        }
+    }
+    const float c1 = wave_sum(s1) * (1.0f / kLnDim), c2 = wave_sum(s2) * (1.0f / kLnDim);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = rs * (gd[h * 4 + i] - c1 - xh[h * 4 + i] * c2);
+        *reinterpret_cast<f32x4*>(dx + (size_t)row * kLnDim + h * 256 + lane * 4) = o;
+    }
+}
+
+// ---- BatchNorm1d(train) over the M rows of [M, C] -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int P, int C, int M, float eps, float momentum,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                           float* running_mean, float* running_var) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int p = 0; p < P; ++p) { a += partial[(size_t)p * 2 * C + n]; b += partial[(size_t)p * 2 * C + C + n]; }
+    const double mu = a / M;
+    double var = b / M - mu * mu;                         // biased (normalisation); double: no cancellation issue
+    if (var < 0.0) var = 0.0;
+    save_mean[n] = (float)mu;
+    save_rstd[n] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = M > 1 ? var * M / (M - 1) : var;
+        running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mu;
+        running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unbiased;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ y,
+                                                        int64_t n4, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % C);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (v[k] - mean[c + k]) * rstd[c + k] * g[c + k] + b[c + k];
+    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+}
+
+// dx = g rstd (dy - dbeta / M - xhat dgamma / M)
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ dgamma, const float* __restrict__ dbeta, float* __restrict__ dx,
+                                                         int64_t n4, int C, float inv_m) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % C);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dy + i * 4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float xh = (v[k] - mean[c + k]) * rstd[c + k];
+        o[k] = g[c + k] * rstd[c + k] * (d[k] - dbeta[c + k] * inv_m - xh * dgamma[c + k] * inv_m);
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+}
+
+// ---- element-wise ----------------------------------------------------------------------------------------------------
+enum { ELT_SILU_FWD, ELT_SILU_BWD, ELT_SIGMOID_FWD, ELT_SIGMOID_BWD, ELT_AXPY, ELT_DROPOUT };
+
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {          // splitmix64 finaliser -> 32 random bits per element
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void eltwise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                       int64_t n, float alpha, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i];
+    float r;
+    if (OP == ELT_SILU_FWD) r = x * sigmoid_(x);
+    else if (OP == ELT_SILU_BWD) { const float u = b[i], s = sigmoid_(u); r = x * s * (1.f + u * (1.f - s)); }       // a = dy, b = pre-activation
+    else if (OP == ELT_SIGMOID_FWD) r = sigmoid_(x);
+    else if (OP == ELT_SIGMOID_BWD) { const float y = b[i]; r = x * y * (1.f - y); }                                 // a = dy, b = sigmoid output
+    else if (OP == ELT_AXPY) r = alpha * x + (b ? b[i] : 0.f);                                                       // alpha a (+ b)
+    else {                                                                                                           // keep with prob 1 - alpha, scale 1 / (1 - alpha)
+        const float u = (float)(mix32(seed + (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
+        r = u >= alpha ? x * (1.0f / (1.0f - alpha)) : 0.f;
+    }
+    out[i] = r;
+}
+
+// GLU over the channel halves of [M, 2C]: y = x[:, :C] * sigmoid(x[:, C:])
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t M, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * C) return;
+    const int64_t m = i / C;
+    const int c = (int)(i % C);
+    y[i] = x[m * 2 * C + c] * sigmoid_(x[m * 2 * C + C + c]);
+}
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int64_t M, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * C) return;
+    const int64_t m = i / C;
+    const int c = (int)(i % C);
+    const float o = x[m * 2 * C + c], s = sigmoid_(x[m * 2 * C + C + c]), d = dy[i];
+    dx[m * 2 * C + c] = d * s;
+    dx[m * 2 * C + C + c] = d * o * s * (1.f - s);
+}
+// rows with mask == 0 become 0 (masked_fill(~mask, 0)); the same op maps dy -> dx
+__global__ __launch_bounds__(256) void mask_rows_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, float* __restrict__ y, int64_t M, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * C) return;
+    y[i] = mask[i / C] ? x[i] : 0.f;
+}
+
+// ---- depthwise conv k = 31 over time, zero padding at clip edges; taps [31][C] -------------------------------------
+constexpr int kTaps = kConvK;
+
+__global__ __launch_bounds__(256) void dwconv_train_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            const int32_t* __restrict__ frame_offsets, int B, float* __restrict__ y, int C, int flip) {
+    const int b = blockIdx.z;
+    const int f0 = frame_offsets[b], T = frame_offsets[b + 1] - f0;
+    const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (t >= T || c >= C) return;
+    f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+        const int u = t + k - kTaps / 2;
+        if (u < 0 || u >= T) continue;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)(f0 + u) * C + c);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)(flip ? kTaps - 1 - k : k) * C + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += xv[i] * wv[i];
+    }
+    *reinterpret_cast<f32x4*>(y + (size_t)(f0 + t) * C + c) = acc;
+}
+
+// tap gradients: partial[p][k][c] = sum over the chunk's rows t of dy[t, c] x[t + k - 15, c] (inside the row's clip)
+__global__ __launch_bounds__(256) void dwconv_bwd_w_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                    const int32_t* __restrict__ clip_of_row, const int32_t* __restrict__ frame_offsets,
+                                                                    int M, int C, float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * kChunkRows, r1 = min(M, r0 + kChunkRows);
+    float acc[kTaps];
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) acc[k] = 0.f;
+    if (c < C) {
+        for (int m = r0 + ty; m < r1; m += 4) {
+            const int b = clip_of_row[m];
+            const int lo = frame_offsets[b], hi = frame_offsets[b + 1];
+            const float d = dy[(size_t)m * C + c];
+#pragma unroll
+            for (int k = 0; k < kTaps; ++k) {
+                const int u = m + k - kTaps / 2;
+                if (u >= lo && u < hi) acc[k] += d * x[(size_t)u * C + c];
+            }
+        }
+    }
+    for (int k = 0; k < kTaps; ++k) {
+        red[ty][threadIdx.x & 63] = acc[k];
+        __syncthreads();
+        if (ty == 0 && c < C) {
+            const int l = threadIdx.x;
+            partial[((size_t)blockIdx.y * kTaps + k) * C + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void dwconv_bwd_w_final_kernel(const float* __restrict__ partial, int P, int n, float* __restrict__ dw, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double a = 0.0;
+    for (int p = 0; p < P; ++p) a += partial[(size_t)p * n + i];
+    dw[i] = (accumulate ? dw[i] : 0.f) + (float)a;
+}
+
+// ---- losses ------------------------------------------------------------------------------------------------------------
+// BCEWithLogitsLoss(reduction='mean'): partial sums per block + gradient (sigmoid(x) - t) / n
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t n, float inv_n,
+                                                   float* __restrict__ dx, double* __restrict__ partial) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i], tv = t[i];
+        s += (double)(fmaxf(v, 0.f) - v * tv + log1pf(__expf(-fabsf(v))));
+        if (dx) dx[i] = (sigmoid_(v) - tv) * inv_n;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sum_partials_kernel(const double* __restrict__ partial, int P, double scale, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int p = 0; p < P; ++p) s += partial[p];
+        out[0] = (float)(s * scale);
+    }
+}
+
+// BinaryEMDLoss (bound_loss.py:12-19, bidirectional=False): mean |cumsum(pred) - cumsum(gt)| / sqrt(T) over [B, T];
+// grad pred[b, t] = sum_{t' >= t} sign(cp - cg)[t'] / (sqrt(T) B T).  One workgroup per row, one contiguous segment per
+// thread: segment sums -> exclusive scan -> per-element cumsum, |.| and sign -> suffix sums of the signs.
+__global__ __launch_bounds__(256) void emd_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int T, float inv_scale, float inv_n,
+                                                   float* __restrict__ dpred, double* __restrict__ partial) {
+    __shared__ double seg[256];
+    __shared__ double red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* p = pred + (size_t)b * T;
+    const float* g = gt + (size_t)b * T;
+    float* dp = dpred ? dpred + (size_t)b * T : nullptr;
+    const int per = (T + 255) / 256;
+    const int t0 = min(T, tid * per), t1 = min(T, t0 + per);
+    double s = 0.0;
+    for (int t = t0; t < t1; ++t) s += (double)p[t] - (double)g[t];
+    seg[tid] = s;
+    __syncthreads();
+    if (tid == 0) { double run = 0.0; for (int i = 0; i < 256; ++i) { const double v = seg[i]; seg[i] = run; run += v; } }   // exclusive scan
+    __syncthreads();
+    double run = seg[tid], loss = 0.0;
+    int cnt = 0;                                      // sum of signs inside the segment
+    for (int t = t0; t < t1; ++t) {
+        run += (double)p[t] - (double)g[t];
+        const float d = (float)run * inv_scale;       // (cp - cg) / scale
+        loss += (double)fabsf(d);
+        const int sg = (d > 0.f) - (d < 0.f);
+        cnt += sg;
+        if (dp) dp[t] = (float)sg;                    // parked; turned into the suffix sum below
+    }
+    __syncthreads();
+    seg[tid] = (double)cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = loss;
+    __syncthreads();
+    if (tid == 0) {
+        partial[b] = (red[0] + red[1]) + (red[2] + red[3]);
+        double r = 0.0;                                // signs of all LATER segments
+        for (int i = 255; i >= 0; --i) { const double v = seg[i]; seg[i] = r; r += v; }
+    }
+    __syncthreads();
+    if (dp) {
+        float acc = (float)seg[tid];
+        const float k = inv_scale * inv_n;
+        for (int t = t1 - 1; t >= t0; --t) { acc += dp[t]; dp[t] = acc * k; }
+    }
+}
+
+// AdamW (torch.optim.AdamW semantics, amsgrad off): decoupled decay, bias-corrected moments
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                     int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                                     float bc1, float bc2_sqrt, float grad_scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * grad_scale;
+    float pi = p[i] * (1.f - lr * weight_decay);
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
+}  // namespace
+
+// ---- launchers -----------------------------------------------------------------------------------------------------------
+static inline int n_chunks(int M) { return (M + kChunkRows - 1) / kChunkRows; }
+size_t train_col_scratch_bytes(int M, int N) { return (size_t)n_chunks(M) * 2 * N * sizeof(float); }
+size_t train_dwconv_w_scratch_bytes(int M, int C) { return (size_t)n_chunks(M) * kTaps * C * sizeof(float); }
+
+hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, hipStream_t s) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    dim3 grid((unsigned)((ld_out + 31) / 32), (unsigned)((N + 31) / 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, M, N, ld_in, out, ld_out);
+    return hipGetLastError();
+}
+
+template <class F>
+static hipError_t col_reduce(int M, int N, F f, float* out1, float* out2, int accumulate, float* scratch, hipStream_t s) {
+    const int P = n_chunks(M);
+    hipLaunchKernelGGL(col_partial_kernel<F>, dim3((unsigned)((N + 63) / 64), (unsigned)P), dim3(256), 0, s, M, N, scratch, f);
+    hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, scratch, P, N, out1, out2, accumulate);
+    return hipGetLastError();
+}
+
+hipError_t launch_colsum(const float* x, int M, int N, int ld, float* out, int accumulate, float* scratch, hipStream_t s) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    return col_reduce(M, N, ColsumF{x, ld}, out, nullptr, accumulate, scratch, s);
+}
+
+hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, g, b, y, mean, rstd, M);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx,
+                         float* dgamma, float* dbeta, int accumulate, int M, float* scratch, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, dy, x, g, mean, rstd, dx, M);
+    return col_reduce(M, kLnDim, LnGradF{dy, x, mean, rstd, kLnDim}, dbeta, dgamma, accumulate, scratch, s);
+}
+
+hipError_t launch_bn_fwd(const float* x, const float* g, const float* b, int M, int C, float eps, float momentum, float* running_mean,
+                         float* running_var, float* y, float* save_mean, float* save_rstd, float* scratch, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    const int P = n_chunks(M);
+    hipLaunchKernelGGL(col_partial_kernel<ColStatsF>, dim3((unsigned)((C + 63) / 64), (unsigned)P), dim3(256), 0, s, M, C, scratch, ColStatsF{x, C});
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, scratch, P, C, M, eps, momentum, save_mean, save_rstd,
+                       running_mean, running_var);
+    const int64_t n4 = (int64_t)M * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, g, b, save_mean, save_rstd, y, n4, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_bwd(const float* dy, const float* x, const float* g, const float* save_mean, const float* save_rstd, int M, int C,
+                         float* dx, float* dgamma, float* dbeta, float* scratch, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipError_t e = col_reduce(M, C, BnGradF{dy, x, save_mean, save_rstd, C}, dbeta, dgamma, 0, scratch, s);
+    if (e != hipSuccess) return e;
+    const int64_t n4 = (int64_t)M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dy, x, g, save_mean, save_rstd, dgamma, dbeta, dx, n4, C,
+                       1.0f / (float)M);
+    return hipGetLastError();
+}
+
+hipError_t launch_eltwise(int op, const float* a, const float* b, float* out, int64_t n, float alpha, uint64_t seed, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    switch (op) {
+        case ELT_SILU_FWD: hipLaunchKernelGGL(eltwise_kernel<ELT_SILU_FWD>, grid, dim3(256), 0, s, a, b, out, n, alpha, seed); break;
+        case ELT_SILU_BWD: hipLaunchKernelGGL(eltwise_kernel<ELT_SILU_BWD>, grid, dim3(256), 0, s, a, b, out, n, alpha, seed); break;
+        case ELT_SIGMOID_FWD: hipLaunchKernelGGL(eltwise_kernel<ELT_SIGMOID_FWD>, grid, dim3(256), 0, s, a, b, out, n, alpha, seed); break;
+        case ELT_SIGMOID_BWD: hipLaunchKernelGGL(eltwise_kernel<ELT_SIGMOID_BWD>, grid, dim3(256), 0, s, a, b, out, n, alpha, seed); break;
+        case ELT_AXPY: hipLaunchKernelGGL(eltwise_kernel<ELT_AXPY>, grid, dim3(256), 0, s, a, b, out, n, alpha, seed); break;
+        case ELT_DROPOUT: hipLaunchKernelGGL(eltwise_kernel<ELT_DROPOUT>, grid, dim3(256), 0, s, a, b, out, n, alpha, seed); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_glu(const float* dy, const float* x, float* out, int64_t M, int C, int backward, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((M * C + 255) / 256));
+    if (backward) hipLaunchKernelGGL(glu_bwd_kernel, grid, dim3(256), 0, s, dy, x, out, M, C);
+    else hipLaunchKernelGGL(glu_fwd_kernel, grid, dim3(256), 0, s, x, out, M, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_mask_rows(const float* x, const uint8_t* mask, float* y, int64_t M, int C, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mask_rows_kernel, dim3((unsigned)((M * C + 255) / 256)), dim3(256), 0, s, x, mask, y, M, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_dwconv_train(const float* x, const float* w, const float* bias, const int32_t* frame_offsets, int B, int max_frames, float* y,
+                               int C, int flip, hipStream_t s) {
+    if (B <= 0 || max_frames <= 0) return hipSuccess;
+    dim3 grid((unsigned)((C / 4 + 63) / 64), (unsigned)((max_frames + 3) / 4), (unsigned)B);
+    hipLaunchKernelGGL(dwconv_train_kernel, grid, dim3(256), 0, s, x, w, bias, frame_offsets, B, y, C, flip);
+    return hipGetLastError();
+}
+
+hipError_t launch_dwconv_bwd_w(const float* dy, const float* x, const int32_t* clip_of_row, const int32_t* frame_offsets, int M, int C, float* dw,
+                               int accumulate, float* scratch, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    const int P = n_chunks(M);
+    hipLaunchKernelGGL(dwconv_bwd_w_partial_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)P), dim3(256), 0, s, dy, x, clip_of_row, frame_offsets, M, C,
+                       scratch);
+    hipLaunchKernelGGL(dwconv_bwd_w_final_kernel, dim3((unsigned)((kTaps * C + 255) / 256)), dim3(256), 0, s, scratch, P, kTaps * C, dw, accumulate);
+    return hipGetLastError();
+}
+
+hipError_t launch_bce(const float* x, const float* t, int64_t n, float* dx, float* loss, double* scratch, hipStream_t s) {
+    const int blocks = (int)(n + 255) / 256 < 1024 ? (int)((n + 255) / 256) : 1024;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, t, n, 1.0f / (float)n, dx, scratch);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, scratch, blocks, 1.0 / (double)n, loss);
+    return hipGetLastError();
+}
+
+hipError_t launch_emd(const float* pred, const float* gt, int B, int T, float* dpred, float* loss, double* scratch, hipStream_t s) {
+    if (B <= 0 || T <= 0) return hipSuccess;
+    const float inv_scale = 1.0f / sqrtf((float)T), inv_n = 1.0f / ((float)B * (float)T);
+    hipLaunchKernelGGL(emd_kernel, dim3((unsigned)B), dim3(256), 0, s, pred, gt, T, inv_scale, inv_n, dpred, scratch);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, scratch, B, (double)inv_n, loss);
+    return hipGetLastError();
+}
+
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        int step, float grad_scale, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1,
+                       sqrtf(bc2), grad_scale);
+    return hipGetLastError();
+}

@@ -1,0 +1,362 @@
+"""Autograd functions over the C-ABI training operators (include/some_amd.h, "training operators").
+
+Activations are packed [M, C] fp32 row-major tensors on the GPU (M = B * T_max frames of the padded training batch).
+PyTorch only records the tape and owns the memory; forward and backward math run in libsome_amd.so.  Each function
+names the reference op it stands for."""
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..engine import Engine
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class TrainOps:
+    """Holds the library handle + a scratch buffer; every method is differentiable."""
+
+    def __init__(self, engine: Engine):
+        if engine.host_only or engine.device.type != 'cuda':
+            raise RuntimeError('the training operators need an AMD GPU (no CPU fallback)')
+        self.engine = engine
+        self.lib, self.h, self.device = engine.lib, engine.handle, engine.device
+        self._scratch: Optional[torch.Tensor] = None
+
+    # ---- plumbing -------------------------------------------------------------------------------------------
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def scratch(self, M: int, N: int) -> torch.Tensor:
+        need = int(self.lib.some_train_scratch_bytes(self.h, M, N))
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._scratch
+
+    def check(self, rc):
+        _lib.check(self.h, rc)
+
+    def new(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    # ---- raw (non-differentiable) helpers -------------------------------------------------------------------------
+    def gemm(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """a [M, K] @ w[N, K]^T (+ bias): exact fp32 MFMA GEMM (gemm.hip).  K is padded to a multiple of 4."""
+        M, K = a.shape
+        N = w.shape[0]
+        assert w.shape[1] == K and a.is_contiguous() and w.is_contiguous()
+        if K % 4:
+            pad = 4 - K % 4
+            a = torch.nn.functional.pad(a, (0, pad))
+            w = torch.nn.functional.pad(w, (0, pad))
+            K += pad
+        out = self.new(M, N)
+        if M == 0:
+            return out
+        epi = _lib.EPI_BIAS if bias is not None else _lib.EPI_NONE
+        self.check(self.lib.some_op_gemm(self.h, epi, _p(a), K, _p(w), _p(bias), None, N, _p(out), N, M, N, K, 1.0, 0, None, 0,
+                                         self.stream()))
+        return out
+
+    def transpose(self, x: torch.Tensor, pad_to: int = 32) -> torch.Tensor:
+        """[M, N] -> [N, Mp] with Mp = M rounded up to ``pad_to`` (zero padded): a contraction operand over M."""
+        M, N = x.shape
+        Mp = (M + pad_to - 1) // pad_to * pad_to
+        out = self.new(N, Mp)
+        self.check(self.lib.some_train_transpose(self.h, _p(x), M, N, N, _p(out), Mp, self.stream()))
+        return out
+
+    def colsum(self, x: torch.Tensor) -> torch.Tensor:
+        M, N = x.shape
+        out = self.new(N)
+        sc = self.scratch(M, N)
+        self.check(self.lib.some_train_colsum(self.h, _p(x), M, N, N, _p(out), 0, _p(sc), sc.numel(), self.stream()))
+        return out
+
+    def eltwise(self, op: int, a: torch.Tensor, b: Optional[torch.Tensor] = None, alpha: float = 0.0, seed: int = 0) -> torch.Tensor:
+        out = torch.empty_like(a)
+        self.check(self.lib.some_train_eltwise(self.h, op, _p(a), _p(b), _p(out), a.numel(), float(alpha), C.c_uint64(seed), self.stream()))
+        return out
+
+    # ---- differentiable operators ---------------------------------------------------------------------------------------
+    def linear(self, x, weight, bias=None):
+        """nn.Linear / k = 1 Conv1d: x [M, K], weight [N, K] -> [M, N]."""
+        return _Linear.apply(self, x, weight, bias)
+
+    def layernorm(self, x, gamma, beta):
+        return _LayerNorm.apply(self, x, gamma, beta)
+
+    def silu(self, x):
+        return _Silu.apply(self, x)
+
+    def sigmoid(self, x):
+        return _Sigmoid.apply(self, x)
+
+    def glu(self, x):
+        return _Glu.apply(self, x)
+
+    def axpy(self, alpha: float, y, x):
+        """alpha * y + x (``x = f(x) * 0.5 + x``, Gconform.py:57,60)."""
+        return _Axpy.apply(self, alpha, y, x)
+
+    def mask_rows(self, x, mask_u8):
+        return _MaskRows.apply(self, x, mask_u8)
+
+    def dropout(self, x, p: float, seed: int):
+        if p <= 0.0:
+            return x
+        return _Dropout.apply(self, x, p, seed)
+
+    def dwconv(self, x, weight, bias, batch):
+        """Depthwise Conv1d(C, C, 31, padding 15, groups C): weight [C, 1, 31] as in the state dict."""
+        return _DwConv.apply(self, x, weight, bias, batch)
+
+    def batchnorm(self, x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
+        return _BatchNorm.apply(self, x, gamma, beta, running_mean, running_var, momentum, eps)
+
+    def bce_with_logits(self, logits, target):
+        return _Bce.apply(self, logits, target)
+
+    def binary_emd(self, pred, gt, B: int, T: int):
+        return _Emd.apply(self, pred, gt, B, T)
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops: TrainOps, x, weight, bias):
+        ctx.ops = ops
+        w2 = weight.reshape(weight.shape[0], -1)                  # Conv1d k = 1 weights are [N, K, 1]
+        ctx.save_for_backward(x, w2)
+        ctx.wshape, ctx.has_bias = weight.shape, bias is not None
+        return ops.gemm(x.contiguous(), w2.contiguous(), bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops: TrainOps = ctx.ops
+        x, w2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            dx = ops.gemm(dy, ops.transpose(w2, pad_to=1))                              # dy [M, N] . W [N, K]
+        if ctx.needs_input_grad[2]:
+            dw = ops.gemm(ops.transpose(dy), ops.transpose(x)).reshape(ctx.wshape)      # contraction over the (padded) rows
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = ops.colsum(dy)
+        return None, dx, dw, db
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops: TrainOps, x, gamma, beta):
+        M = x.shape[0]
+        x = x.contiguous()
+        y, mean, rstd = torch.empty_like(x), ops.new(M), ops.new(M)
+        ops.check(ops.lib.some_train_layernorm_fwd(ops.h, _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, ops.stream()))
+        ctx.ops = ops
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops: TrainOps = ctx.ops
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        M = x.shape[0]
+        dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+        sc = ops.scratch(M, 512)
+        ops.check(ops.lib.some_train_layernorm_bwd(ops.h, _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), 0, M,
+                                                   _p(sc), sc.numel(), ops.stream()))
+        return None, dx, dg, db
+
+
+class _Silu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, x):
+        ctx.ops = ops
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.eltwise(_lib.ELT_SILU_FWD, x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return None, ctx.ops.eltwise(_lib.ELT_SILU_BWD, dy.contiguous(), x)
+
+
+class _Sigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, x):
+        ctx.ops = ops
+        y = ops.eltwise(_lib.ELT_SIGMOID_FWD, x.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return None, ctx.ops.eltwise(_lib.ELT_SIGMOID_BWD, dy.contiguous(), y)
+
+
+class _Glu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, x):
+        ctx.ops = ops
+        x = x.contiguous()
+        M, C2 = x.shape
+        y = ops.new(M, C2 // 2)
+        ops.check(ops.lib.some_train_glu(ops.h, None, _p(x), _p(y), M, C2 // 2, 0, ops.stream()))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = ctx.ops
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        ops.check(ops.lib.some_train_glu(ops.h, _p(dy.contiguous()), _p(x), _p(dx), x.shape[0], x.shape[1] // 2, 1, ops.stream()))
+        return None, dx
+
+
+class _Axpy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, alpha, y, x):
+        ctx.ops, ctx.alpha = ops, alpha
+        return ops.eltwise(_lib.ELT_AXPY, y.contiguous(), x.contiguous(), alpha=alpha)
+
+    @staticmethod
+    def backward(ctx, d):
+        dy = ctx.ops.eltwise(_lib.ELT_AXPY, d.contiguous(), None, alpha=ctx.alpha) if ctx.alpha != 1.0 else d
+        return None, None, dy, d
+
+
+class _MaskRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, x, mask_u8):
+        ctx.ops = ops
+        ctx.save_for_backward(mask_u8)
+        y = torch.empty_like(x)
+        ops.check(ops.lib.some_train_mask_rows(ops.h, _p(x.contiguous()), _p(mask_u8), _p(y), x.shape[0], x.shape[1], ops.stream()))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = ctx.ops
+        (mask_u8,) = ctx.saved_tensors
+        dx = torch.empty_like(dy)
+        ops.check(ops.lib.some_train_mask_rows(ops.h, _p(dy.contiguous()), _p(mask_u8), _p(dx), dy.shape[0], dy.shape[1], ops.stream()))
+        return None, dx, None
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, x, p, seed):
+        ctx.ops, ctx.p, ctx.seed = ops, p, seed
+        return ops.eltwise(_lib.ELT_DROPOUT, x.contiguous(), alpha=p, seed=seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return None, ctx.ops.eltwise(_lib.ELT_DROPOUT, dy.contiguous(), alpha=ctx.p, seed=ctx.seed), None, None
+
+
+class _DwConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, x, weight, bias, batch):
+        ctx.ops, ctx.batch = ops, batch
+        x = x.contiguous()
+        Cn = x.shape[1]
+        taps = weight.reshape(Cn, -1).t().contiguous()             # [31, C] tap-major
+        y = torch.empty_like(x)
+        ops.check(ops.lib.some_train_dwconv(ops.h, _p(x), _p(taps), _p(bias), _p(batch.frame_offsets_dev), batch.B, batch.max_frames,
+                                            _p(y), Cn, 0, ops.stream()))
+        ctx.save_for_backward(x, taps)
+        ctx.wshape, ctx.has_bias = weight.shape, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops, batch = ctx.ops, ctx.batch
+        x, taps = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, Cn = x.shape
+        dx = torch.empty_like(x)
+        ops.check(ops.lib.some_train_dwconv(ops.h, _p(dy), _p(taps), None, _p(batch.frame_offsets_dev), batch.B, batch.max_frames,
+                                            _p(dx), Cn, 1, ops.stream()))
+        dt = torch.empty_like(taps)
+        sc = ops.scratch(M, Cn)
+        ops.check(ops.lib.some_train_dwconv_bwd_taps(ops.h, _p(dy), _p(x), _p(clip_of_row(batch)), _p(batch.frame_offsets_dev), M, Cn, _p(dt), 0,
+                                                     _p(sc), sc.numel(), ops.stream()))
+        dw = dt.t().reshape(ctx.wshape)
+        db = ops.colsum(dy) if ctx.has_bias else None
+        return None, dx, dw, db, None
+
+
+def clip_of_row(batch) -> torch.Tensor:
+    """int32 [M]: clip index of every packed row (cached on the batch descriptor)."""
+    cached = getattr(batch, '_clip_of_row_dev', None)
+    if cached is None:
+        idx = np.repeat(np.arange(batch.B, dtype=np.int32), batch.frame_counts)
+        cached = batch._clip_of_row_dev = torch.from_numpy(idx).to(batch.frame_offsets_dev.device)
+    return cached
+
+
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, x, gamma, beta, running_mean, running_var, momentum, eps):
+        x = x.contiguous()
+        M, Cn = x.shape
+        y, mean, rstd = torch.empty_like(x), ops.new(Cn), ops.new(Cn)
+        sc = ops.scratch(M, Cn)
+        ops.check(ops.lib.some_train_batchnorm_fwd(ops.h, _p(x), _p(gamma), _p(beta), M, Cn, float(eps), float(momentum), _p(running_mean),
+                                                   _p(running_var), _p(y), _p(mean), _p(rstd), _p(sc), sc.numel(), ops.stream()))
+        ctx.ops = ops
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = ctx.ops
+        x, gamma, mean, rstd = ctx.saved_tensors
+        M, Cn = x.shape
+        dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+        sc = ops.scratch(M, Cn)
+        ops.check(ops.lib.some_train_batchnorm_bwd(ops.h, _p(dy.contiguous()), _p(x), _p(gamma), _p(mean), _p(rstd), M, Cn, _p(dx), _p(dg), _p(db),
+                                                   _p(sc), sc.numel(), ops.stream()))
+        return None, dx, dg, db, None, None, None, None
+
+
+class _Bce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, logits, target):
+        logits, target = logits.contiguous(), target.contiguous()
+        n = logits.numel()
+        dl, loss = torch.empty_like(logits), ops.new(1)
+        sc = ops.scratch(1, 1)
+        ops.check(ops.lib.some_train_bce_with_logits(ops.h, _p(logits), _p(target), n, _p(dl), _p(loss), _p(sc), sc.numel(), ops.stream()))
+        ctx.save_for_backward(dl)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return None, dl * g, None
+
+
+class _Emd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, pred, gt, B, T):
+        pred, gt = pred.contiguous(), gt.contiguous()
+        assert pred.numel() == B * T == gt.numel()
+        dp, loss = torch.empty_like(pred), ops.new(1)
+        sc = ops.scratch(B * 8, 1)
+        ops.check(ops.lib.some_train_binary_emd(ops.h, _p(pred), _p(gt), B, T, _p(dp), _p(loss), _p(sc), sc.numel(), ops.stream()))
+        ctx.save_for_backward(dp)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return None, dp * g, None, None, None

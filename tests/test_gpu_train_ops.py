@@ -1,0 +1,157 @@
+"""Training operators (forward AND backward) against plain PyTorch fp32 references of the same ops with autograd, on the
+GPU.  Tolerances: fp32 kernels vs fp32 torch, different summation orders -> 2e-5 of the
+tensor's scale unless stated.  Needs a real MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from some_amd.configs import get_config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from some_amd.engine import Engine
+    from some_amd.training.ops import TrainOps
+    return TrainOps(Engine(get_config('two_head_model', lay=0), device='cuda'))
+
+
+def _close(a, b, tol=2e-5):
+    a, b = a.detach().double(), b.detach().double()
+    scale = max(b.abs().max().item(), 1e-30)
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, (err, scale)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    return (torch.randn(*shape, device='cuda', generator=g) * scale).requires_grad_(True)
+
+
+def _pair(fn_mine, fn_ref, inputs, tol=2e-5, seed=99):
+    """Run both on clones of ``inputs``; compare outputs and the gradients of a random cotangent."""
+    a = [t.detach().clone().requires_grad_(t.requires_grad) if torch.is_tensor(t) and t.is_floating_point() else t for t in inputs]
+    b = [t.detach().clone().requires_grad_(t.requires_grad) if torch.is_tensor(t) and t.is_floating_point() else t for t in inputs]
+    ya, yb = fn_mine(*a), fn_ref(*b)
+    _close(ya, yb, tol)
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    cot = torch.randn(yb.shape, device='cuda', generator=g)
+    ya.backward(cot)
+    yb.backward(cot)
+    for ta, tb in zip(a, b):
+        if torch.is_tensor(ta) and ta.requires_grad:
+            assert ta.grad is not None
+            _close(ta.grad, tb.grad, tol)
+
+
+@pytest.mark.parametrize('M,K,N,bias', [(300, 512, 2048, True), (70, 80, 512, True), (129, 512, 1, True), (33, 2048, 512, True),
+                                         (257, 512, 1536, False), (1, 512, 128, True)])
+def test_linear(ops, M, K, N, bias):
+    x, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    b = _rand(N, seed=3) if bias else None
+    if bias:
+        _pair(lambda x, w, b: ops.linear(x, w, b), lambda x, w, b: F.linear(x, w, b), [x, w, b], tol=3e-5)
+    else:
+        _pair(lambda x, w: ops.linear(x, w), lambda x, w: F.linear(x, w), [x, w], tol=3e-5)
+
+
+def test_linear_conv1d_weight_shape(ops):
+    x, w, b = _rand(50, 512, seed=1), _rand(1024, 512, 1, seed=2, scale=0.05), _rand(1024, seed=3)
+    _pair(lambda x, w, b: ops.linear(x, w, b), lambda x, w, b: F.conv1d(x.t()[None], w, b)[0].t(), [x, w, b], tol=3e-5)
+
+
+@pytest.mark.parametrize('M', [1, 5, 1000])
+def test_layernorm(ops, M):
+    x, g, b = _rand(M, 512, seed=4, scale=3.0), _rand(512, seed=5), _rand(512, seed=6)
+    with torch.no_grad():
+        x += 1.5
+    _pair(lambda x, g, b: ops.layernorm(x, g, b), lambda x, g, b: F.layer_norm(x, (512,), g, b, 1e-5), [x, g, b])
+
+
+def test_elementwise(ops):
+    x = _rand(77, 640, seed=7, scale=2.0)
+    _pair(lambda x: ops.silu(x), lambda x: F.silu(x), [x])
+    _pair(lambda x: ops.sigmoid(x), lambda x: torch.sigmoid(x), [x])
+    _pair(lambda x: ops.glu(x), lambda x: F.glu(x, dim=-1), [x])
+    y = _rand(77, 640, seed=8)
+    _pair(lambda y, x: ops.axpy(0.5, y, x), lambda y, x: y * 0.5 + x, [y, x])
+    _pair(lambda y, x: ops.axpy(1.0, y, x), lambda y, x: y + x, [y, x])
+    mask = (torch.arange(77, device='cuda') % 3 != 0)
+    _pair(lambda x: ops.mask_rows(x, mask.to(torch.uint8)), lambda x: x.masked_fill(~mask[:, None], 0), [x])
+
+
+def test_dropout(ops):
+    x = _rand(400, 512, seed=9)
+    y = ops.dropout(x, 0.1, seed=1234)
+    keep = (y != 0)
+    assert abs(keep.float().mean().item() - 0.9) < 0.01
+    torch.testing.assert_close(y[keep], (x / 0.9)[keep])
+    assert torch.equal(ops.dropout(x, 0.1, seed=1234), y) and not torch.equal(ops.dropout(x, 0.1, seed=1235), y)
+    y.backward(torch.ones_like(y))
+    torch.testing.assert_close(x.grad, keep.float() / 0.9)
+    assert ops.dropout(x, 0.0, seed=1) is x
+
+
+def test_dwconv(ops):
+    from some_amd.engine import ClipBatch
+    lens = [40, 1, 17, 300]
+    batch = ClipBatch(lens, 'cuda')
+    x, w, b = _rand(sum(lens), 512, seed=10), _rand(512, 1, 31, seed=11, scale=0.2), _rand(512, seed=12)
+
+    def ref(x, w, b):
+        outs, pos = [], 0
+        for t in lens:
+            outs.append(F.conv1d(x[pos:pos + t].t()[None], w, b, padding=15, groups=512)[0].t())
+            pos += t
+        return torch.cat(outs)
+
+    _pair(lambda x, w, b: ops.dwconv(x, w, b, batch), ref, [x, w, b])
+
+
+def test_batchnorm_train(ops):
+    M = 1300
+    x, g, b = _rand(M, 512, seed=13, scale=2.0), _rand(512, seed=14), _rand(512, seed=15)
+    with torch.no_grad():
+        x += 0.7
+    rm1, rv1 = torch.zeros(512, device='cuda'), torch.ones(512, device='cuda')
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    _pair(lambda x, g, b: ops.batchnorm(x, g, b, rm1, rv1, 0.1, 1e-5),
+          lambda x, g, b: F.batch_norm(x, rm2, rv2, g, b, True, 0.1, 1e-5), [x, g, b])
+    _close(rm1, rm2)
+    _close(rv1, rv2)
+
+
+def test_bce_with_logits(ops):
+    x = _rand(200, 128, seed=16, scale=4.0)
+    t = torch.rand(200, 128, device='cuda')
+    _pair(lambda x: ops.bce_with_logits(x, t), lambda x: F.binary_cross_entropy_with_logits(x, t), [x], tol=1e-5)
+
+
+@pytest.mark.parametrize('B,T', [(1, 5), (3, 1000), (8, 2500)])
+def test_binary_emd(ops, B, T):
+    pred = torch.sigmoid(_rand(B, T, seed=17).detach() - 2.0).requires_grad_(True)
+    gt = (torch.rand(B, T, device='cuda') < 0.05).float()
+
+    def ref(p):                                                 # modules/losses/bound_loss.py:12-16
+        scale = T ** 0.5
+        return F.l1_loss(p.cumsum(dim=1) / scale, gt.cumsum(dim=1) / scale)
+
+    _pair(lambda p: ops.binary_emd(p.reshape(-1), gt.reshape(-1), B, T), ref, [pred], tol=2e-5)
+
+
+def test_adamw_matches_torch(ops):
+    import ctypes as C
+    n = 10007
+    p0 = torch.randn(n, device='cuda')
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([p_ref], lr=1e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    p, m, v = p0.clone(), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    for step in range(1, 6):
+        g = torch.randn(n, device='cuda', generator=torch.Generator(device='cuda').manual_seed(step))
+        p_ref.grad = g.clone()
+        opt.step()
+        ops.check(ops.lib.some_train_adamw(ops.h, C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+                                           C.c_void_p(v.data_ptr()), n, 1e-3, 0.9, 0.98, 1e-8, 0.01, step, 1.0, ops.stream()))
+        _close(p, p_ref, tol=2e-6)
