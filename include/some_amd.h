@@ -255,6 +255,16 @@ int some_train_adamw(SomeHandle* h, float* param_dev, const float* grad_dev, flo
                      int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                      float grad_scale, void* stream);
 
+/* F.scaled_dot_product_attention (8 heads x 64, scale 1/8, per clip, unmasked; base_attention.py:34-44) on the fused
+ * projection output qkv [M, 1536] (q | k | v), exact fp32 MFMA.  Forward also writes lse_dev [8, M] (base-2
+ * log-sum-exp per head and frame) for the backward; backward recomputes the probabilities flash-style and writes
+ * dqkv_dev [M, 1536] completely.  dsum_scratch_dev: 8 * M floats. */
+int some_train_attention_fwd(SomeHandle* h, const float* qkv_dev, const int32_t* frame_offsets_dev, int32_t B,
+                             int32_t max_frames, int32_t M, float* out_dev, float* lse_dev, void* stream);
+int some_train_attention_bwd(SomeHandle* h, const float* qkv_dev, const float* out_dev, const float* dout_dev,
+                             const float* lse_dev, const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames,
+                             int32_t M, float* dqkv_dev, float* dsum_scratch_dev, void* stream);
+
 /* ---- single-operator entry points (kernel-level parity tests and micro-benchmarks) ------------------ */
 
 #define SOME_EPI_NONE 0       /* C = A W^T                                                          */

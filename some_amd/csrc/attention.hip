@@ -186,6 +186,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, int nqb) 
     // ---- normalise, transpose through LDS (wave-private 32 x 64 patch, row pad 4), coalesced row stores
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    if (a.lse[g] != nullptr && hi == 0) {            // training: P = exp2(s2 - lse2) is recomputed by the backward
+        const int q = q0 + wave * 32 + l31;
+        if (q < T) a.lse[g][(size_t)head * a.M + f0 + q] = m_run + __log2f(l_tot);
+    }
     float* patch = lds + wave * (32 * LDK);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

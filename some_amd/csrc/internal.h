@@ -79,8 +79,19 @@ struct AttnArgs {
     const int32_t* frame_offsets;  // device [B+1]
     int groups, B, max_frames;
     int out_split;                 // 1: write `out` in SPLIT32 format
+    float* lse[kStreams];          // optional (training): [8 heads][M] base-2 log-sum-exp of the scaled scores
+    int M;                         // total frames (row count of lse planes); only read when lse is set
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+// attention backward (train_attention.hip): dqkv [M, 1536] from dout [M, 512]; dsum [8][M] is scratch
+struct AttnBwdArgs {
+    const float* qkv; const float* out; const float* dout; const float* lse;
+    float* dsum; float* dqkv;
+    const int32_t* frame_offsets;
+    int B, max_frames, M;
+};
+hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s);
 
 // split-f16 attention (attention_f16x3.hip): operands as written by the EPI_QKV GEMM epilogue; out is SPLIT32.
 struct Attn3Args {

@@ -186,4 +186,29 @@ int some_train_adamw(SomeHandle* h, float* param_dev, const float* grad_dev, flo
     return SOME_OK;
 }
 
+int some_train_attention_fwd(SomeHandle* h, const float* qkv_dev, const int32_t* frame_offsets_dev, int32_t B,
+                             int32_t max_frames, int32_t M, float* out_dev, float* lse_dev, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, B >= 0 && max_frames >= 0 && M >= 0, "some_train_attention_fwd: negative size");
+    if (B == 0 || M == 0) return SOME_OK;
+    T_CHECK(h, qkv_dev && frame_offsets_dev && out_dev && lse_dev, "some_train_attention_fwd: null pointer");
+    AttnArgs a{};
+    a.qkv[0] = qkv_dev; a.out[0] = out_dev; a.frame_offsets = frame_offsets_dev; a.groups = 1; a.B = B; a.max_frames = max_frames;
+    a.lse[0] = lse_dev; a.M = M;
+    T_TRY(h, launch_attention(a, st(stream)));
+    return SOME_OK;
+}
+
+int some_train_attention_bwd(SomeHandle* h, const float* qkv_dev, const float* out_dev, const float* dout_dev,
+                             const float* lse_dev, const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames,
+                             int32_t M, float* dqkv_dev, float* dsum_scratch_dev, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, B >= 0 && max_frames >= 0 && M >= 0, "some_train_attention_bwd: negative size");
+    if (B == 0 || M == 0) return SOME_OK;
+    T_CHECK(h, qkv_dev && out_dev && dout_dev && lse_dev && frame_offsets_dev && dqkv_dev && dsum_scratch_dev, "some_train_attention_bwd: null pointer");
+    AttnBwdArgs a{qkv_dev, out_dev, dout_dev, lse_dev, dsum_scratch_dev, dqkv_dev, frame_offsets_dev, B, max_frames, M};
+    T_TRY(h, launch_attention_bwd(a, st(stream)));
+    return SOME_OK;
+}
+
 }  // extern "C"

@@ -118,6 +118,10 @@ class TrainOps:
     def batchnorm(self, x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
         return _BatchNorm.apply(self, x, gamma, beta, running_mean, running_var, momentum, eps)
 
+    def attention(self, qkv, batch):
+        """F.scaled_dot_product_attention on the fused projection qkv [M, 1536] -> merged heads [M, 512]."""
+        return _Attention.apply(self, qkv, batch)
+
     def bce_with_logits(self, logits, target):
         return _Bce.apply(self, logits, target)
 
@@ -326,6 +330,30 @@ class _BatchNorm(torch.autograd.Function):
         ops.check(ops.lib.some_train_batchnorm_bwd(ops.h, _p(dy.contiguous()), _p(x), _p(gamma), _p(mean), _p(rstd), M, Cn, _p(dx), _p(dg), _p(db),
                                                    _p(sc), sc.numel(), ops.stream()))
         return None, dx, dg, db, None, None, None, None
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, qkv, batch):
+        qkv = qkv.contiguous()
+        M = qkv.shape[0]
+        assert qkv.shape[1] == 1536 and M == batch.total_frames
+        out, lse = ops.new(M, 512), ops.new(8, M)
+        ops.check(ops.lib.some_train_attention_fwd(ops.h, _p(qkv), _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M, _p(out), _p(lse),
+                                                   ops.stream()))
+        ctx.ops, ctx.batch = ops, batch
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ops, batch = ctx.ops, ctx.batch
+        qkv, out, lse = ctx.saved_tensors
+        M = qkv.shape[0]
+        dqkv, dsum = torch.empty_like(qkv), ops.new(8, M)
+        ops.check(ops.lib.some_train_attention_bwd(ops.h, _p(qkv), _p(out), _p(dout.contiguous()), _p(lse), _p(batch.frame_offsets_dev), batch.B,
+                                                   batch.max_frames, M, _p(dqkv), _p(dsum), ops.stream()))
+        return None, dqkv, None
 
 
 class _Bce(torch.autograd.Function):

@@ -155,3 +155,26 @@ def test_adamw_matches_torch(ops):
         ops.check(ops.lib.some_train_adamw(ops.h, C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
                                            C.c_void_p(v.data_ptr()), n, 1e-3, 0.9, 0.98, 1e-8, 0.01, step, 1.0, ops.stream()))
         _close(p, p_ref, tol=2e-6)
+
+
+@pytest.mark.parametrize('lens', [[64], [1], [33, 130], [257, 5, 128], [700]])
+def test_attention_fwd_bwd(ops, lens):
+    """Flash attention forward (with saved log-sum-exp) and its two-kernel backward vs torch SDPA autograd."""
+    from some_amd.engine import ClipBatch
+    batch = ClipBatch(lens, 'cuda')
+    M = sum(lens)
+    qkv = _rand(M, 1536, seed=20 + M)
+    with torch.no_grad():
+        qkv[:, :512] *= 2.0                                     # sharper softmax
+
+    def ref(qkv):
+        outs, pos = [], 0
+        for t in lens:
+            x = qkv[pos:pos + t]
+            q, k, v = (x[:, i * 512:(i + 1) * 512].reshape(t, 8, 64).transpose(0, 1) for i in range(3))
+            p = torch.softmax(q @ k.transpose(1, 2) * 0.125, dim=-1)
+            outs.append((p @ v).transpose(0, 1).reshape(t, 512))
+            pos += t
+        return torch.cat(outs)
+
+    _pair(lambda qkv: ops.attention(qkv, batch), ref, [qkv], tol=3e-5)
