@@ -373,6 +373,47 @@ def gen_deploy():
     print('deploy.npz', {k: v.shape for k, v in out.items()})
 
 
+def gen_train():
+    """One training step of the reference model + losses (training/me_task.py:96-109) with torch autograd and
+    torch.optim.AdamW: losses, a digest of every parameter gradient, BatchNorm running stats, parameters after the step.
+    Dropout probabilities are 0 (torch's RNG stream is not reproducible elsewhere); BatchNorm runs in train mode."""
+    import copy
+    import zlib
+    cfg = get_config('two_head_model', lay=1)
+    for k in ('conv_drop', 'ffn_latent_drop', 'ffn_out_drop', 'attention_drop'):
+        cfg['midi_extractor_args'][k] = 0.0
+    model = RefModel(copy.deepcopy(cfg)).train()
+    sd = synth.synth_state_dict(cfg, 31)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    ref_losses = _load_file('ref_bound_loss', REF / 'modules/losses/bound_loss.py')
+    batch = synth.synth_train_batch()
+    t = {k: torch.from_numpy(v) for k, v in batch.items()}
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4 * (1 / 5000), betas=(0.9, 0.98), weight_decay=0)   # WarmupLR at step 1
+    mask = t['unit2note'] > 0
+    probs, bounds = model(x=t['units'], f0=None, mask=mask, sig=False)
+    bound_loss = ref_losses.BinaryEMDLoss()(bounds, t['bounds'])
+    midi_loss = torch.nn.BCEWithLogitsLoss()(probs, t['probs'])
+    (bound_loss + midi_loss).backward()
+    out = {'bound_loss': np.array(bound_loss.item()), 'midi_loss': np.array(midi_loss.item()),
+           'probs_head': probs.detach().numpy()[:, :4, :8].copy(), 'bounds_out': bounds.detach().numpy().copy()}
+    names = []
+    for name, p in model.named_parameters():
+        g = p.grad.detach().numpy().astype(np.float64).reshape(-1)
+        proj = np.random.default_rng(zlib.crc32(name.encode())).standard_normal(g.size)
+        out['grad.' + name] = np.array(list(g[:8]) + [0.0] * max(0, 8 - g.size) + [g.sum(), np.abs(g).sum(), np.sqrt((g * g).sum()), (g * proj).sum()])
+        names.append(name)
+    opt.step()
+    for name, p in model.named_parameters():
+        v = p.detach().numpy().astype(np.float64).reshape(-1)
+        out['after.' + name] = np.array(list(v[:8]) + [0.0] * max(0, 8 - v.size) + [v.sum()])
+    for name, b in model.named_buffers():
+        if name.endswith('running_mean') or name.endswith('running_var'):
+            out['buf.' + name] = b.detach().numpy().copy()
+    out['names'] = np.array(names)
+    np.savez_compressed(OUT / 'train_step.npz', **out)
+    print('train_step.npz', len(out), 'bound_loss', bound_loss.item(), 'midi_loss', midi_loss.item())
+
+
 def gen_e2e():
     """waveform -> notes through the reference's own front end, model and decoder (B=1, CPU)."""
     out = {}
@@ -420,4 +461,5 @@ if __name__ == '__main__':
     gen_batch_infer_fns()
     gen_batch_csv()
     gen_deploy()
+    gen_train()
     gen_e2e()

@@ -61,6 +61,13 @@ _CONFIGS = {
         midi_prob_deviation=1.0,
         rest_threshold=0.1,
         midi_extractor_args=_extractor_args(3),
+        # training keys (configs/two_head_model.yaml:38-56)
+        use_bound_loss=True,
+        use_midi_loss=True,
+        optimizer_args={'optimizer_cls': 'torch.optim.AdamW', 'lr': 0.0001, 'beta1': 0.9, 'beta2': 0.98, 'weight_decay': 0},
+        lr_scheduler_args={'scheduler_cls': 'lr_scheduler.scheduler.WarmupLR', 'warmup_steps': 5000, 'min_lr': 0.00001},
+        max_batch_size=8,
+        max_batch_frames=80000,
     ),
     'quant_two_head_model': dict(
         _BASE,

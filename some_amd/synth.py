@@ -145,3 +145,21 @@ def save_checkpoint(config: dict, path, seed: int = 114514):
     with open(path.with_name('config.yaml'), 'w', encoding='utf8') as f:
         yaml.safe_dump(config, f)
     return path
+
+
+def synth_train_batch(B=2, T=96, nb=128, seed=21):
+    """A padded training batch shaped like MIDIExtractionDataset.collater's (training/me_task.py:26-52)."""
+    rng = np.random.default_rng(seed)
+    units = (rng.standard_normal((B, T, 80)) * 1.5 - 4.0).astype(np.float32)
+    unit2note = np.zeros((B, T), dtype=np.int64)
+    for b in range(B):
+        valid = T if b == 0 else T - 26
+        edges = np.sort(rng.choice(np.arange(1, valid), size=6, replace=False))
+        unit2note[b, :valid] = 1 + np.searchsorted(edges, np.arange(valid), side='right')
+    units[unit2note == 0] = 0.0                                   # collate_nd pads with zeros
+    centers = rng.uniform(40, 80, (B, 8))
+    idx = np.arange(nb, dtype=np.float32)[None, None, :]
+    probs = np.exp(-0.5 * (idx - centers[np.arange(B)[:, None], np.clip(unit2note, 0, 7)][..., None]) ** 2).astype(np.float32)
+    probs *= (unit2note > 0)[..., None]
+    bounds = (np.diff(unit2note, axis=1, prepend=0) > 0).astype(np.float32)
+    return {'units': units, 'unit2note': unit2note, 'probs': probs, 'bounds': bounds}

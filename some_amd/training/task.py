@@ -1,0 +1,83 @@
+"""Losses, optimiser, schedule and the training step of ``MIDIExtractionTask`` (training/me_task.py:57-111,
+training/base_task.py optimiser wiring, lr_scheduler/scheduler.py:42-59, configs/two_head_model.yaml:38-52) on the HIP
+training operators.  Data-parallel: one process per GPU, gradients summed with ONE all-reduce of the flat gradient
+buffer (RCCL over xGMI on the GPUs, gloo in the CPU tests) and averaged inside the fused AdamW launch."""
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from ..engine import ClipBatch, Engine
+from .model import TrainableMidiConforms
+from .ops import TrainOps
+
+
+def warmup_lr(step: int, base_lr: float, warmup_steps: int, min_lr: float) -> float:
+    """lr_scheduler.scheduler.WarmupLR: linear warm-up to ``base_lr`` over ``warmup_steps``, then base_lr *
+    (warmup_steps / step) ** 0.5 floored at ``min_lr`` (step counts optimiser updates from 1)."""
+    step = max(step, 1)
+    if warmup_steps == 0:
+        return max(base_lr * step ** -0.5, min_lr)
+    lr = base_lr * warmup_steps ** 0.5 * min(step ** -0.5, step * warmup_steps ** -1.5)
+    return min_lr if (lr < min_lr and step > warmup_steps) else lr
+
+
+class MIDIExtractionTrainer:
+    def __init__(self, config: dict, device='cuda', seed: int = 114514, process_group=None):
+        self.config = config
+        self.engine = Engine(config, device=device)
+        self.ops = TrainOps(self.engine)
+        self.model = TrainableMidiConforms(config, self.ops, seed=seed)
+        oa = config.get('optimizer_args', {})
+        self.base_lr = oa.get('lr', 1e-4)
+        self.betas = (oa.get('beta1', 0.9), oa.get('beta2', 0.98))
+        self.weight_decay = oa.get('weight_decay', 0.0)
+        self.eps = oa.get('eps', 1e-8)
+        sa = config.get('lr_scheduler_args', {})
+        self.warmup_steps, self.min_lr = sa.get('warmup_steps', 5000), sa.get('min_lr', 1e-5)
+        n = self.model.params.numel
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.ops.device)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.ops.device)
+        self.global_step = 0
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+            torch.distributed.broadcast(self.model.params.flat, src=0, group=process_group)      # identical replicas
+
+    # ---- me_task.py:79-111 ------------------------------------------------------------------------------------
+    def run_model(self, sample: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """sample: 'units' [B, T, 80], 'unit2note' [B, T] int, 'probs' [B, T, N], 'bounds' [B, T] (the collater's
+        batch, me_task.py:26-52).  Returns the loss dict of run_model(infer=False)."""
+        units = sample['units']
+        B, T = units.shape[0], units.shape[1]
+        batch = ClipBatch([T] * B, self.ops.device)
+        mask = sample['unit2note'] > 0
+        probs, bounds = self.model(units.reshape(B * T, -1), batch, mask=mask)
+        losses = {}
+        if self.config.get('use_bound_loss', True):
+            losses['bound_loss'] = self.ops.binary_emd(bounds, sample['bounds'].reshape(-1).float(), B, T)
+        if self.config.get('use_midi_loss', True):
+            losses['midi_loss'] = self.ops.bce_with_logits(probs, sample['probs'].reshape(B * T, -1).float())
+        return losses
+
+    def training_step(self, sample: Dict[str, torch.Tensor]) -> Dict[str, float]:
+        """One optimiser update: forward, losses, backward, gradient all-reduce, AdamW with the WarmupLR rate."""
+        P = self.model.params
+        P.zero_grad()
+        self.model.train()
+        losses = self.run_model(sample)
+        total = sum(losses.values())
+        total.backward()
+        if self.world > 1:
+            torch.distributed.all_reduce(P.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        self.global_step += 1
+        lr = warmup_lr(self.global_step, self.base_lr, self.warmup_steps, self.min_lr)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        self.ops.check(self.ops.lib.some_train_adamw(self.ops.h, p(P.flat), p(P.grad), p(self.exp_avg), p(self.exp_avg_sq), P.numel, lr,
+                                                     self.betas[0], self.betas[1], self.eps, self.weight_decay, self.global_step,
+                                                     1.0 / self.world, self.ops.stream()))
+        out = {k: v.detach() for k, v in losses.items()}
+        out['total_loss'] = total.detach()
+        out['lr'] = lr
+        return out

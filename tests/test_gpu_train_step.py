@@ -1,0 +1,85 @@
+"""One full training step of the HIP training path against the REFERENCE's own model + losses + torch.optim.AdamW
+(tests/golden/train_step.npz, produced by oracle/make_golden.py:gen_train from /root/reference with torch autograd):
+losses, every parameter gradient (digest: head values, sums, norm, a seeded projection), BatchNorm running statistics
+and the parameters after the update.  fp32 kernels vs fp32 torch-CPU: 2e-4 of each tensor's gradient norm."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from some_amd import synth
+from some_amd.configs import get_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg():
+    cfg = get_config('two_head_model', lay=1)
+    for k in ('conv_drop', 'ffn_latent_drop', 'ffn_out_drop', 'attention_drop'):
+        cfg['midi_extractor_args'][k] = 0.0
+    return cfg
+
+
+def _sample(device='cuda'):
+    return {k: torch.from_numpy(v).to(device) for k, v in synth.synth_train_batch().items()}
+
+
+def test_training_step_matches_reference(golden_dir):
+    from some_amd.training.task import MIDIExtractionTrainer
+    g = np.load(golden_dir / 'train_step.npz')
+    tr = MIDIExtractionTrainer(_cfg(), device='cuda')
+    tr.model.params.load_state_dict(synth.synth_state_dict(_cfg(), 31))
+    out = tr.training_step(_sample())
+    assert abs(out['bound_loss'].item() - float(g['bound_loss'])) < 2e-5 * abs(float(g['bound_loss']))
+    assert abs(out['midi_loss'].item() - float(g['midi_loss'])) < 2e-5 * abs(float(g['midi_loss']))
+    assert out['lr'] == pytest.approx(1e-4 / 5000)
+    P = tr.model.params
+    worst = 0.0
+    for name in g['names']:
+        key = str(name)                                           # reference parameter name == state-dict key
+        ref = g['grad.' + key]
+        mine = P.views[key].grad.detach().double().cpu().numpy().reshape(-1)
+        proj = np.random.default_rng(zlib.crc32(key.encode())).standard_normal(mine.size)
+        digest = np.array(list(mine[:8]) + [0.0] * max(0, 8 - mine.size) + [mine.sum(), np.abs(mine).sum(), np.sqrt((mine * mine).sum()),
+                                                                           (mine * proj).sum()])
+        if ref[10] < 1e-6:
+            # the depthwise-conv bias feeds BatchNorm(train), which removes it: its true gradient is 0 and both sides
+            # hold only rounding noise
+            assert digest[10] < 1e-5, (key, digest[10])
+            continue
+        norm = ref[10]
+        scale = np.array([norm] * 8 + [norm * np.sqrt(mine.size), max(ref[9], norm), norm, norm * np.sqrt(mine.size)])
+        err = np.abs(digest - ref) / scale
+        worst = max(worst, err.max())
+        assert err.max() < 2e-4, (key, err, digest, ref)
+    print('worst gradient digest error (relative to the tensor norm):', worst)
+    for key in g.files:
+        if key.startswith('buf.'):
+            np.testing.assert_allclose(P[key[4:]].cpu().numpy(), g[key], rtol=2e-5, atol=2e-6)
+        if key.startswith('after.'):
+            v = P.views[key[6:]].detach().double().cpu().numpy().reshape(-1)
+            ref = g[key]
+            # AdamW's first step moves every weight by ~lr * sign(grad): compare at the scale of that move
+            np.testing.assert_allclose(v[:min(8, v.size)], ref[:min(8, v.size)], rtol=0, atol=2e-9 + 1e-6 * np.abs(ref[:8]).max())
+
+
+def test_training_reduces_loss_and_checkpoint_round_trip(tmp_path):
+    """A few updates on one batch lower the loss (dropout on); the trained weights load into the INFERENCE engine."""
+    from some_amd.engine import ClipBatch, Engine
+    from some_amd.training.task import MIDIExtractionTrainer
+    cfg = get_config('two_head_model', lay=1)
+    cfg['optimizer_args'] = dict(cfg.get('optimizer_args', {}), lr=3e-4)
+    cfg['lr_scheduler_args'] = dict(cfg.get('lr_scheduler_args', {}), warmup_steps=1)
+    tr = MIDIExtractionTrainer(cfg, device='cuda', seed=7)
+    sample = _sample()
+    first = tr.training_step(sample)['total_loss'].item()
+    for _ in range(14):
+        last = tr.training_step(sample)['total_loss'].item()
+    assert np.isfinite(last) and last < 0.8 * first, (first, last)
+    sd = {k: v.cpu().numpy() for k, v in tr.model.params.state_dict().items()}
+    eng = Engine(get_config('two_head_model', lay=1), device='cuda')
+    eng.load_state_dict(sd)
+    units = sample['units'][0]
+    midi, bound = eng.forward(units.contiguous(), ClipBatch([units.shape[0]], 'cuda'))
+    assert torch.isfinite(midi).all() and torch.isfinite(bound).all()
