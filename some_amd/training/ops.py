@@ -26,6 +26,7 @@ class TrainOps:
         self.engine = engine
         self.lib, self.h, self.device = engine.lib, engine.handle, engine.device
         self._scratch: Optional[torch.Tensor] = None
+        self.gemm_precision = 'f16x3' if engine.c_config.precision == _lib.PRECISION_F16X3 else 'f32'
 
     # ---- plumbing -------------------------------------------------------------------------------------------
     def stream(self):
@@ -44,20 +45,34 @@ class TrainOps:
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
     # ---- raw (non-differentiable) helpers -------------------------------------------------------------------------
+    def split_rows(self, x: torch.Tensor) -> torch.Tensor:
+        """fp32 [R, K] -> SPLIT32 rows (csrc/split.h: per 32-element k-block 32 f16 hi | 32 f16 lo; same byte size)."""
+        out = torch.empty_like(x)
+        self.check(self.lib.some_op_split_rows(self.h, _p(x), _p(out), x.shape[0], x.shape[1], self.stream()))
+        return out
+
     def gemm(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """a [M, K] @ w[N, K]^T (+ bias): exact fp32 MFMA GEMM (gemm.hip).  K is padded to a multiple of 4."""
+        """a [M, K] @ w[N, K]^T (+ bias).  ``gemm_precision`` 'f16x3' (default): both operands are split into f16
+        hi + lo halves and contracted with three f16 MFMA products, fp32 accumulation (gemm_f16x3.hip; fp32-equivalent,
+        see DESIGN.md section 4) whenever K % 32 == 0 and the problem is big enough to matter; otherwise - and with
+        'f32' - the exact fp32 MFMA kernel (gemm.hip), K padded to a multiple of 4."""
         M, K = a.shape
         N = w.shape[0]
         assert w.shape[1] == K and a.is_contiguous() and w.is_contiguous()
+        out = self.new(M, N)
+        if M == 0:
+            return out
+        epi = _lib.EPI_BIAS if bias is not None else _lib.EPI_NONE
+        if self.gemm_precision == 'f16x3' and K % 32 == 0 and N >= 64 and M >= 64:
+            a3, w3 = self.split_rows(a), self.split_rows(w)
+            self.check(self.lib.some_op_gemm(self.h, epi, _p(a3), K, _p(w3), _p(bias), None, N, _p(out), N, M, N, K, 1.0, 0, None,
+                                             _lib.GEMM_SPLIT_IN | (2 << 8), self.stream()))
+            return out
         if K % 4:
             pad = 4 - K % 4
             a = torch.nn.functional.pad(a, (0, pad))
             w = torch.nn.functional.pad(w, (0, pad))
             K += pad
-        out = self.new(M, N)
-        if M == 0:
-            return out
-        epi = _lib.EPI_BIAS if bias is not None else _lib.EPI_NONE
         self.check(self.lib.some_op_gemm(self.h, epi, _p(a), K, _p(w), _p(bias), None, N, _p(out), N, M, N, K, 1.0, 0, None, 0,
                                          self.stream()))
         return out

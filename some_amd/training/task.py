@@ -39,6 +39,13 @@ class MIDIExtractionTrainer:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.ops.device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.ops.device)
         self.global_step = 0
+        # Dynamic loss scaling (power of two; exact in fp32): the split-f16 GEMMs carry operands as f16 hi + lo, whose
+        # absolute floor is 2^-25 - activation gradients of a mean-reduced loss (~1 / (B T N)) sit below it unscaled.
+        # The scaled gradient stays in the flat buffer and is unscaled inside the fused AdamW launch; a non-finite
+        # gradient halves the scale and skips the update, `growth_interval` clean updates double it.
+        self.loss_scale = float(config.get('some_amd_loss_scale', 2.0 ** 14)) if self.ops.gemm_precision == 'f16x3' else 1.0
+        self.growth_interval = int(config.get('some_amd_loss_scale_growth_interval', 200))
+        self._clean_steps = 0
         self.pg = process_group
         self.world = 1
         if process_group is not None or torch.distributed.is_initialized():
@@ -68,16 +75,28 @@ class MIDIExtractionTrainer:
         self.model.train()
         losses = self.run_model(sample)
         total = sum(losses.values())
-        total.backward()
+        scale = self.loss_scale
+        (total * scale if scale != 1.0 else total).backward()
         if self.world > 1:
             torch.distributed.all_reduce(P.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
-        self.global_step += 1
-        lr = warmup_lr(self.global_step, self.base_lr, self.warmup_steps, self.min_lr)
-        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        self.ops.check(self.ops.lib.some_train_adamw(self.ops.h, p(P.flat), p(P.grad), p(self.exp_avg), p(self.exp_avg_sq), P.numel, lr,
-                                                     self.betas[0], self.betas[1], self.eps, self.weight_decay, self.global_step,
-                                                     1.0 / self.world, self.ops.stream()))
+        skipped = False
+        if scale != 1.0:
+            if not bool(torch.isfinite(P.grad).all()):              # the step's one host synchronisation
+                self.loss_scale, self._clean_steps, skipped = scale * 0.5, 0, True
+            else:
+                self._clean_steps += 1
+                if self._clean_steps % self.growth_interval == 0 and self.loss_scale < 2.0 ** 24:
+                    self.loss_scale = scale * 2.0
+        lr = warmup_lr(self.global_step + 1, self.base_lr, self.warmup_steps, self.min_lr)
+        if not skipped:
+            self.global_step += 1
+            p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+            self.ops.check(self.ops.lib.some_train_adamw(self.ops.h, p(P.flat), p(P.grad), p(self.exp_avg), p(self.exp_avg_sq), P.numel, lr,
+                                                         self.betas[0], self.betas[1], self.eps, self.weight_decay, self.global_step,
+                                                         1.0 / (self.world * scale), self.ops.stream()))
         out = {k: v.detach() for k, v in losses.items()}
         out['total_loss'] = total.detach()
         out['lr'] = lr
+        out['grad_scale'] = scale                # P.grad holds scale * (sum over ranks of) the gradient
+        out['skipped'] = skipped
         return out

@@ -25,10 +25,12 @@ def _sample(device='cuda'):
     return {k: torch.from_numpy(v).to(device) for k, v in synth.synth_train_batch().items()}
 
 
-def test_training_step_matches_reference(golden_dir):
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
+def test_training_step_matches_reference(golden_dir, precision):
     from some_amd.training.task import MIDIExtractionTrainer
     g = np.load(golden_dir / 'train_step.npz')
-    tr = MIDIExtractionTrainer(_cfg(), device='cuda')
+    tr = MIDIExtractionTrainer(dict(_cfg(), some_amd_precision=precision), device='cuda')
+    assert tr.ops.gemm_precision == precision and (tr.loss_scale > 1.0) == (precision == 'f16x3')
     tr.model.params.load_state_dict(synth.synth_state_dict(_cfg(), 31))
     out = tr.training_step(_sample())
     assert abs(out['bound_loss'].item() - float(g['bound_loss'])) < 2e-5 * abs(float(g['bound_loss']))
@@ -39,7 +41,7 @@ def test_training_step_matches_reference(golden_dir):
     for name in g['names']:
         key = str(name)                                           # reference parameter name == state-dict key
         ref = g['grad.' + key]
-        mine = P.views[key].grad.detach().double().cpu().numpy().reshape(-1)
+        mine = P.views[key].grad.detach().double().cpu().numpy().reshape(-1) / out['grad_scale']
         proj = np.random.default_rng(zlib.crc32(key.encode())).standard_normal(mine.size)
         digest = np.array(list(mine[:8]) + [0.0] * max(0, 8 - mine.size) + [mine.sum(), np.abs(mine).sum(), np.sqrt((mine * mine).sum()),
                                                                            (mine * proj).sum()])
@@ -53,7 +55,8 @@ def test_training_step_matches_reference(golden_dir):
         err = np.abs(digest - ref) / scale
         worst = max(worst, err.max())
         assert err.max() < 2e-4, (key, err, digest, ref)
-    print('worst gradient digest error (relative to the tensor norm):', worst)
+    print(f'{precision}: worst gradient digest error (relative to the tensor norm):', worst)
+    assert not out['skipped']
     for key in g.files:
         if key.startswith('buf.'):
             np.testing.assert_allclose(P[key[4:]].cpu().numpy(), g[key], rtol=2e-5, atol=2e-6)
@@ -83,3 +86,18 @@ def test_training_reduces_loss_and_checkpoint_round_trip(tmp_path):
     units = sample['units'][0]
     midi, bound = eng.forward(units.contiguous(), ClipBatch([units.shape[0]], 'cuda'))
     assert torch.isfinite(midi).all() and torch.isfinite(bound).all()
+
+
+def test_loss_scale_backs_off_on_overflow():
+    """An absurd loss scale overflows the f16 halves of the split GEMM operands: the update is skipped, the scale
+    halves, parameters stay untouched; the next steps recover."""
+    from some_amd.training.task import MIDIExtractionTrainer
+    cfg = dict(_cfg(), some_amd_loss_scale=2.0 ** 40)
+    tr = MIDIExtractionTrainer(cfg, device='cuda', seed=3)
+    before = tr.model.params.flat.clone()
+    out = tr.training_step(_sample())
+    assert out['skipped'] and tr.loss_scale == 2.0 ** 39 and tr.global_step == 0
+    assert torch.equal(tr.model.params.flat, before)
+    tr.loss_scale = 2.0 ** 12
+    out = tr.training_step(_sample())
+    assert not out['skipped'] and tr.global_step == 1 and not torch.equal(tr.model.params.flat, before)

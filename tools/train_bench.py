@@ -1,0 +1,64 @@
+"""Training-step timing of the HIP training path (BASELINE config 5 shape: configs/two_head_model.yaml, synthetic batch).
+
+    python tools/train_bench.py [--batch 8] [--frames 2584] [--lay 3] [--steps 5]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py ...   (data parallel)
+"""
+import argparse
+import os
+import pathlib
+import sys
+import time
+
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from some_amd.configs import get_config  # noqa: E402
+from some_amd.training.task import MIDIExtractionTrainer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--frames', type=int, default=2584)
+    ap.add_argument('--lay', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    args = ap.parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank, local = int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if world > 1:
+        torch.distributed.init_process_group(os.environ.get('SOME_AMD_DIST_BACKEND', 'nccl'))
+    cfg = get_config('two_head_model', lay=args.lay)
+    tr = MIDIExtractionTrainer(cfg, device=f'cuda:{local}', seed=1)
+    B, T = args.batch, args.frames
+    rng = np.random.default_rng(rank)
+    u2n = np.repeat(np.arange(1, T // 40 + 2), 40)[:T][None].repeat(B, 0)
+    sample = {
+        'units': torch.from_numpy((rng.standard_normal((B, T, 80)) - 4).astype(np.float32)).cuda(),
+        'unit2note': torch.from_numpy(u2n).cuda(),
+        'probs': torch.rand(B, T, 128, device='cuda') * 0.1,
+        'bounds': (torch.from_numpy(np.diff(u2n, axis=1, prepend=0)) > 0).float().cuda(),
+    }
+    for _ in range(args.warmup):
+        tr.training_step(sample)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tr.training_step(sample)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    nb = 2 * args.lay + 2
+    f_dense = nb * 12090368 + args.lay * 2097152 + 163840 + 1024 * 128 + 1024          # SURVEY.md section 8(d), per frame, forward
+    flops = 3.0 * (f_dense + nb * 2048 * T) * B * T                                     # fwd + 2x bwd
+    if rank == 0:
+        print(f'two_head_model lay {args.lay}: {B} x {T} frames/GPU x {world} GPU: {dt * 1e3:.1f} ms/step, '
+              f'{world * B * T / dt:.0f} frames/s, {world * B * T * 512 / 44100 / dt:.0f} audio-s/s trained, '
+              f'{flops / dt / 1e12:.1f} TFLOP/s/GPU (fwd+bwd model FLOPs), loss {out["total_loss"].item():.4f}')
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
