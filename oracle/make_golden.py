@@ -414,6 +414,24 @@ def gen_train():
     print('train_step.npz', len(out), 'bound_loss', bound_loss.item(), 'midi_loss', midi_loss.item())
 
 
+def gen_lr_schedule():
+    """lr_scheduler.scheduler.WarmupLR (the reference's class, on a dummy optimiser) at a few update counts."""
+    sched = _load_file('ref_scheduler', REF / 'lr_scheduler/scheduler.py')
+    out = {}
+    for warmup, min_lr in ((5000, 1e-5), (10, 2e-5), (0, 1e-5)):
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+        sc = sched.WarmupLR(opt, warmup_steps=warmup, min_lr=min_lr)
+        lrs = {}
+        for step in range(1, 30001):
+            if step in (1, 2, 9, 10, 11, 100, 4999, 5000, 5001, 20000, 30000):
+                lrs[str(step)] = opt.param_groups[0]['lr']          # the rate update number `step` is taken with
+            opt.step()
+            sc.step()
+        out[f'{warmup},{min_lr}'] = lrs
+    (OUT / 'lr_schedule.json').write_text(json.dumps(out, indent=1))
+    print('lr_schedule.json', len(out))
+
+
 def gen_e2e():
     """waveform -> notes through the reference's own front end, model and decoder (B=1, CPU)."""
     out = {}
@@ -462,4 +480,5 @@ if __name__ == '__main__':
     gen_batch_csv()
     gen_deploy()
     gen_train()
+    gen_lr_schedule()
     gen_e2e()
