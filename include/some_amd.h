@@ -195,6 +195,13 @@ int some_pcm_gather(SomeHandle* h, const void* src_dev, int32_t sample_format, c
  * bytes; column reductions are two-pass and deterministic. */
 size_t some_train_scratch_bytes(const SomeHandle* h, int64_t M, int32_t N);
 
+/* Weight-gradient GEMM  C[M, N] = A[M, K] W[N, K]^T  with a LONG contraction (K = all frames of the batch) and a small
+ * output: split-f16 kernel with the contraction cut into slices across workgroups (blockIdx.z), partial planes in
+ * partial_dev (some_train_gemm_splitk_bytes), summed in slice order - deterministic.  A_split / W_split: SPLIT32 rows
+ * (some_op_split_rows), K % 32 == 0, lda % 32 == 0. */
+size_t some_train_gemm_splitk_bytes(const SomeHandle* h, int32_t M, int32_t N, int32_t K);
+int some_train_gemm_splitk(SomeHandle* h, const float* A_split_dev, int32_t lda, const float* W_split_dev, float* C_dev,
+                           int32_t M, int32_t N, int32_t K, void* partial_dev, size_t partial_bytes, void* stream);
 /* out[n, m] = in[m, n] for m < M, 0 for M <= m < ld_out (the zero padding makes ld_out a valid contraction length). */
 int some_train_transpose(SomeHandle* h, const float* in_dev, int32_t M, int32_t N, int32_t ld_in, float* out_dev,
                          int32_t ld_out, void* stream);

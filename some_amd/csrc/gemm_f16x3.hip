@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     static_assert((BM + BN) * 8 % NT == 0, "staging must divide evenly");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    const GemmGroup g = a.g[blockIdx.y];
+    GemmGroup g = a.g[blockIdx.y];
     const int n_tiles = a.n_tiles;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int m_tile = (j / n_tiles) * 8 + xcd;
@@ -188,7 +188,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & 31, kg = lane >> 5;
-    const int nk = a.K >> 5;
+    // split-K (weight gradients: small output, contraction over all frames): slice z covers k-blocks [kt0, kt0 + nk)
+    // and writes its own partial plane; the launcher sizes the slices so that none is empty
+    int nk = a.K >> 5, kt0 = 0;
+    if (a.k_slices > 1) {
+        const int per = (nk + a.k_slices - 1) / a.k_slices;
+        kt0 = blockIdx.z * per;
+        nk = min(nk, kt0 + per) - kt0;
+        g.C += (size_t)blockIdx.z * a.slice_stride;
+    }
 
     // ---- staging roles
     const char* src[NLD];
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     auto gload = [&](int kt) {
 #pragma unroll
         for (int p = 0; p < NLD; ++p)
-            stage[p] = ok[p] ? *reinterpret_cast<const f32x4*>(src[p] + (size_t)kt * 128) : zero4;
+            stage[p] = ok[p] ? *reinterpret_cast<const f32x4*>(src[p] + (size_t)(kt0 + kt) * 128) : zero4;
     };
     auto lstore = [&](int buf) {
         float* base = lds + buf * STAGE;
@@ -445,7 +453,7 @@ hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     const int m_tiles = (a.M - a.m_begin + BM - 1) / BM, n_tiles = (n_max + BN - 1) / BN;
     GemmArgs b = a;
     b.n_tiles = n_tiles;
-    dim3 grid((unsigned)((m_tiles + 7) / 8 * 8 * n_tiles), (unsigned)a.groups, 1);
+    dim3 grid((unsigned)((m_tiles + 7) / 8 * 8 * n_tiles), (unsigned)a.groups, (unsigned)(a.k_slices > 1 ? a.k_slices : 1));
     hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), LDS_BYTES, s, b);
     return hipGetLastError();
 }
@@ -485,6 +493,10 @@ hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a_in, bool out_split, 
             if (a_in.g[g].N != 3 * kDim || !a_in.g[g].C2 || !a_in.g[g].C3 || (a_in.g[g].ldv & 255) || a_in.g[g].ldv < a_in.M) return hipErrorInvalidValue;
     GemmArgs a = a_in;
     a.m_begin = 0;
+    if (a.k_slices > 1) {
+        if (epi != EPI_NONE || out_split || tile == 3) return hipErrorInvalidValue;
+        return launch_one(epi, a, false, tile, s);
+    }
     // Wave quantisation: every workgroup of the 256-row tiles takes the same time and one fits per CU, so a grid
     // of W workgroups costs ceil(W / 256) rounds (M = 82 688, N = 512: 1292 -> 6 rounds for 5.05 rounds of work).
     // Launch the largest row range whose workgroup count is a whole number of rounds with the big tile and give

@@ -48,6 +48,8 @@ struct GemmArgs {
     float alpha;           // EPI_BIAS_RES: C = res + alpha * (acc + bias)
     int n_tiles;           // filled by launch_gemm
     int m_begin;           // first row of this launch (rows [m_begin, M) are covered); filled by the launcher
+    int k_slices;          // split-K (f16x3, EPI_NONE): blockIdx.z = slice of the contraction; 0 / 1 = off
+    size_t slice_stride;   // floats between the partial C planes of consecutive slices
 };
 
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
@@ -153,6 +155,7 @@ hipError_t launch_pcm_gather(const void* src, int is_pcm16, const int64_t* src_o
 // ---- training operators (train_ops.hip) -------------------------------------------------------------------
 size_t train_col_scratch_bytes(int M, int N);
 size_t train_dwconv_w_scratch_bytes(int M, int C);
+hipError_t launch_reduce_slices(const float* partial, int slices, size_t n, float* out, hipStream_t s);
 hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, hipStream_t s);
 hipError_t launch_colsum(const float* x, int M, int N, int ld, float* out, int accumulate, float* scratch, hipStream_t s);
 hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, hipStream_t s);

@@ -35,6 +35,37 @@ size_t some_train_scratch_bytes(const SomeHandle* h, int64_t M, int32_t N) {
     return (col > loss ? col : loss) + 256;
 }
 
+static int splitk_slices(int M, int N, int K) {
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nk = K / 32;
+    int want = (512 + tiles - 1) / tiles;                       // ~2 workgroups per CU in flight
+    if (want > nk) want = nk;
+    if (want < 1) want = 1;
+    const int per = (nk + want - 1) / want;
+    return (nk + per - 1) / per;                                // no empty slice
+}
+
+size_t some_train_gemm_splitk_bytes(const SomeHandle* h, int32_t M, int32_t N, int32_t K) {
+    (void)h;
+    if (M <= 0 || N <= 0 || K <= 0) return 256;
+    return (size_t)splitk_slices(M, N, K) * (size_t)M * N * sizeof(float) + 256;
+}
+
+int some_train_gemm_splitk(SomeHandle* h, const float* A_split_dev, int32_t lda, const float* W_split_dev, float* C_dev,
+                           int32_t M, int32_t N, int32_t K, void* partial_dev, size_t partial_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M > 0 && N > 0 && K > 0 && (K % 32) == 0 && (lda % 32) == 0 && lda >= K && (N % 4) == 0, "some_train_gemm_splitk: bad shape (K, lda % 32, N % 4)");
+    T_CHECK(h, A_split_dev && W_split_dev && C_dev && partial_dev, "some_train_gemm_splitk: null pointer");
+    T_CHECK(h, partial_bytes >= some_train_gemm_splitk_bytes(h, M, N, K), "some_train_gemm_splitk: partial buffer too small");
+    const int slices = splitk_slices(M, N, K);
+    GemmArgs a{};
+    a.g[0] = GemmGroup{A_split_dev, W_split_dev, nullptr, nullptr, slices > 1 ? static_cast<float*>(partial_dev) : C_dev, nullptr, N, 0};
+    a.groups = 1; a.M = M; a.K = K; a.lda = lda; a.ldc = N; a.ldr = N; a.alpha = 1.f;
+    a.k_slices = slices; a.slice_stride = (size_t)M * N;
+    T_TRY(h, launch_gemm_f16x3(EPI_NONE, a, false, 2, st(stream)));
+    if (slices > 1) T_TRY(h, launch_reduce_slices(static_cast<const float*>(partial_dev), slices, (size_t)M * N, C_dev, st(stream)));
+    return SOME_OK;
+}
+
 int some_train_transpose(SomeHandle* h, const float* in_dev, int32_t M, int32_t N, int32_t ld_in, float* out_dev,
                          int32_t ld_out, void* stream) {
     if (!h) return SOME_EINVAL;

@@ -418,6 +418,26 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 }  // namespace
 
+// out[i] = sum over slices of partial[s][i] (split-K partial planes), slice order
+static __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ partial, int slices, size_t n4, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(partial + i * 4);
+    for (int s = 1; s < slices; ++s) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(partial + ((size_t)s * n4 + i) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += v[k];
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = acc;
+}
+
+hipError_t launch_reduce_slices(const float* partial, int slices, size_t n, float* out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, partial, slices, n4, out);
+    return hipGetLastError();
+}
+
 // ---- launchers -----------------------------------------------------------------------------------------------------------
 static inline int n_chunks(int M) { return (M + kChunkRows - 1) / kChunkRows; }
 size_t train_col_scratch_bytes(int M, int N) { return (size_t)n_chunks(M) * 2 * N * sizeof(float); }

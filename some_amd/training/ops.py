@@ -26,6 +26,7 @@ class TrainOps:
         self.engine = engine
         self.lib, self.h, self.device = engine.lib, engine.handle, engine.device
         self._scratch: Optional[torch.Tensor] = None
+        self._partial: Optional[torch.Tensor] = None
         self.gemm_precision = 'f16x3' if engine.c_config.precision == _lib.PRECISION_F16X3 else 'f32'
 
     # ---- plumbing -------------------------------------------------------------------------------------------
@@ -75,6 +76,22 @@ class TrainOps:
             K += pad
         self.check(self.lib.some_op_gemm(self.h, epi, _p(a), K, _p(w), _p(bias), None, N, _p(out), N, M, N, K, 1.0, 0, None, 0,
                                          self.stream()))
+        return out
+
+    def gemm_long_k(self, a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """a [M, K] @ w[N, K]^T for weight gradients: K = all frames (long), M x N small.  Split-K over workgroups in
+        f16x3 mode (some_train_gemm_splitk); plain ``gemm`` otherwise."""
+        M, K = a.shape
+        N = w.shape[0]
+        if self.gemm_precision != 'f16x3' or K % 32 or N % 4 or M < 32:
+            return self.gemm(a, w)
+        a3, w3 = self.split_rows(a), self.split_rows(w)
+        out = self.new(M, N)
+        need = int(self.lib.some_train_gemm_splitk_bytes(self.h, M, N, K))
+        if self._partial is None or self._partial.numel() < need:
+            self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.check(self.lib.some_train_gemm_splitk(self.h, _p(a3), K, _p(w3), _p(out), M, N, K, _p(self._partial), self._partial.numel(),
+                                                   self.stream()))
         return out
 
     def transpose(self, x: torch.Tensor, pad_to: int = 32) -> torch.Tensor:
@@ -162,7 +179,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dx = ops.gemm(dy, ops.transpose(w2, pad_to=1))                              # dy [M, N] . W [N, K]
         if ctx.needs_input_grad[2]:
-            dw = ops.gemm(ops.transpose(dy), ops.transpose(x)).reshape(ctx.wshape)      # contraction over the (padded) rows
+            dw = ops.gemm_long_k(ops.transpose(dy), ops.transpose(x)).reshape(ctx.wshape)   # contraction over the (padded) rows
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = ops.colsum(dy)
         return None, dx, dw, db
