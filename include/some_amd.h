@@ -256,6 +256,11 @@ int some_train_bce_with_logits(SomeHandle* h, const float* logits_dev, const flo
 /* modules.losses.BinaryEMDLoss() (modules/losses/bound_loss.py:6-19, bidirectional=False) on [B, T] rows. */
 int some_train_binary_emd(SomeHandle* h, const float* pred_dev, const float* gt_dev, int32_t B, int32_t T,
                           float* dpred_dev, float* loss_dev, void* scratch_dev, size_t scratch_bytes, void* stream);
+/* out_dev[0] (double) = sum_i x[i]^2: the squared global gradient norm for clip_grad_norm (configs/base.yaml:49,
+ * train.py:88); non-finite inputs give a non-finite result, which doubles as the loss-scale overflow check.
+ * scratch_dev: 1024 doubles. */
+int some_train_sumsq(SomeHandle* h, const float* x_dev, int64_t n, double* out_dev, void* scratch_dev, size_t scratch_bytes,
+                     void* stream);
 /* torch.optim.AdamW step (configs/two_head_model.yaml:42-47) on flat arrays; step counts from 1; the gradient is
  * multiplied by grad_scale first (1 / world_size after a summing all-reduce). */
 int some_train_adamw(SomeHandle* h, float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev,

@@ -402,6 +402,8 @@ def gen_train():
         proj = np.random.default_rng(zlib.crc32(name.encode())).standard_normal(g.size)
         out['grad.' + name] = np.array(list(g[:8]) + [0.0] * max(0, 8 - g.size) + [g.sum(), np.abs(g).sum(), np.sqrt((g * g).sum()), (g * proj).sum()])
         names.append(name)
+    # Lightning's gradient_clip_val = clip_grad_norm (configs/base.yaml:49, train.py:88), algorithm 'norm'
+    out['grad_norm'] = np.array(float(torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.get('clip_grad_norm', 1.0))))
     opt.step()
     for name, p in model.named_parameters():
         v = p.detach().numpy().astype(np.float64).reshape(-1)

@@ -68,6 +68,7 @@ _CONFIGS = {
         lr_scheduler_args={'scheduler_cls': 'lr_scheduler.scheduler.WarmupLR', 'warmup_steps': 5000, 'min_lr': 0.00001},
         max_batch_size=8,
         max_batch_frames=80000,
+        clip_grad_norm=1,                 # configs/base.yaml:49 (Lightning gradient_clip_val)
     ),
     'quant_two_head_model': dict(
         _BASE,

@@ -206,6 +206,15 @@ int some_train_binary_emd(SomeHandle* h, const float* pred_dev, const float* gt_
     return SOME_OK;
 }
 
+int some_train_sumsq(SomeHandle* h, const float* x_dev, int64_t n, double* out_dev, void* scratch_dev, size_t scratch_bytes,
+                     void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, n >= 0 && out_dev && (n == 0 || x_dev), "some_train_sumsq: bad argument");
+    T_CHECK(h, scratch_dev && scratch_bytes >= 1024 * sizeof(double), "some_train_sumsq: scratch too small");
+    T_TRY(h, launch_sumsq(x_dev, n, out_dev, static_cast<double*>(scratch_dev), st(stream)));
+    return SOME_OK;
+}
+
 int some_train_adamw(SomeHandle* h, float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
                      int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                      float grad_scale, void* stream) {

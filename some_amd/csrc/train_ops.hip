@@ -352,6 +352,25 @@ __global__ void sum_partials_kernel(const double* __restrict__ partial, int P, d
     }
 }
 
+// sum of squares of a flat array (global gradient norm for clip_grad_norm); NaN / inf propagate into the result
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ partial) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const double v = x[i]; s += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sum_partials_f64_kernel(const double* __restrict__ partial, int P, double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int p = 0; p < P; ++p) s += partial[p];
+        out[0] = s;
+    }
+}
+
 // BinaryEMDLoss (bound_loss.py:12-19, bidirectional=False): mean |cumsum(pred) - cumsum(gt)| / sqrt(T) over [B, T];
 // grad pred[b, t] = sum_{t' >= t} sign(cp - cg)[t'] / (sqrt(T) B T).  One workgroup per row, one contiguous segment per
 // thread: segment sums -> exclusive scan -> per-element cumsum, |.| and sign -> suffix sums of the signs.
@@ -559,6 +578,13 @@ hipError_t launch_emd(const float* pred, const float* gt, int B, int T, float* d
     const float inv_scale = 1.0f / sqrtf((float)T), inv_n = 1.0f / ((float)B * (float)T);
     hipLaunchKernelGGL(emd_kernel, dim3((unsigned)B), dim3(256), 0, s, pred, gt, T, inv_scale, inv_n, dpred, scratch);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, scratch, B, (double)inv_n, loss);
+    return hipGetLastError();
+}
+
+hipError_t launch_sumsq(const float* x, int64_t n, double* out, double* scratch, hipStream_t s) {
+    const int blocks = n <= 0 ? 1 : (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, scratch);
+    hipLaunchKernelGGL(sum_partials_f64_kernel, dim3(1), dim3(64), 0, s, scratch, blocks, out);
     return hipGetLastError();
 }
 

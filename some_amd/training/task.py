@@ -46,6 +46,7 @@ class MIDIExtractionTrainer:
         self.loss_scale = float(config.get('some_amd_loss_scale', 2.0 ** 14)) if self.ops.gemm_precision == 'f16x3' else 1.0
         self.growth_interval = int(config.get('some_amd_loss_scale_growth_interval', 200))
         self._clean_steps = 0
+        self._sumsq = torch.zeros(1, dtype=torch.float64, device=self.ops.device)
         self.pg = process_group
         self.world = 1
         if process_group is not None or torch.distributed.is_initialized():
@@ -79,24 +80,37 @@ class MIDIExtractionTrainer:
         (total * scale if scale != 1.0 else total).backward()
         if self.world > 1:
             torch.distributed.all_reduce(P.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        # global gradient norm on the device (one double comes back: the step's only host synchronisation); it serves
+        # Lightning's gradient_clip_val = clip_grad_norm (configs/base.yaml:49, train.py:88) and the overflow check
+        sc = self.ops.scratch(1, 1)
+        self.ops.check(self.ops.lib.some_train_sumsq(self.ops.h, C.c_void_p(P.grad.data_ptr()), P.numel, C.c_void_p(self._sumsq.data_ptr()),
+                                                     C.c_void_p(sc.data_ptr()), sc.numel(), self.ops.stream()))
+        sumsq = float(self._sumsq.item())
         skipped = False
-        if scale != 1.0:
-            if not bool(torch.isfinite(P.grad).all()):              # the step's one host synchronisation
-                self.loss_scale, self._clean_steps, skipped = scale * 0.5, 0, True
-            else:
+        grad_norm = float('nan')
+        if not (sumsq == sumsq and sumsq != float('inf')):
+            if scale == 1.0:
+                raise FloatingPointError('non-finite gradient')
+            self.loss_scale, self._clean_steps, skipped = scale * 0.5, 0, True
+        else:
+            grad_norm = sumsq ** 0.5 / (scale * self.world)
+            if scale != 1.0:
                 self._clean_steps += 1
                 if self._clean_steps % self.growth_interval == 0 and self.loss_scale < 2.0 ** 24:
                     self.loss_scale = scale * 2.0
+        clip = self.config.get('clip_grad_norm', None)
+        clip_coef = min(1.0, clip / (grad_norm + 1e-6)) if (clip and not skipped) else 1.0       # torch.nn.utils.clip_grad_norm_
         lr = warmup_lr(self.global_step + 1, self.base_lr, self.warmup_steps, self.min_lr)
         if not skipped:
             self.global_step += 1
             p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
             self.ops.check(self.ops.lib.some_train_adamw(self.ops.h, p(P.flat), p(P.grad), p(self.exp_avg), p(self.exp_avg_sq), P.numel, lr,
                                                          self.betas[0], self.betas[1], self.eps, self.weight_decay, self.global_step,
-                                                         1.0 / (self.world * scale), self.ops.stream()))
+                                                         clip_coef / (self.world * scale), self.ops.stream()))
         out = {k: v.detach() for k, v in losses.items()}
         out['total_loss'] = total.detach()
         out['lr'] = lr
         out['grad_scale'] = scale                # P.grad holds scale * (sum over ranks of) the gradient
         out['skipped'] = skipped
+        out['grad_norm'] = grad_norm
         return out

@@ -36,6 +36,7 @@ def test_training_step_matches_reference(golden_dir, precision):
     assert abs(out['bound_loss'].item() - float(g['bound_loss'])) < 2e-5 * abs(float(g['bound_loss']))
     assert abs(out['midi_loss'].item() - float(g['midi_loss'])) < 2e-5 * abs(float(g['midi_loss']))
     assert out['lr'] == pytest.approx(1e-4 / 5000)
+    assert out['grad_norm'] == pytest.approx(float(g['grad_norm']), rel=2e-5)     # clip_grad_norm_'s total norm (clipping is active: > 1)
     P = tr.model.params
     worst = 0.0
     for name in g['names']:
