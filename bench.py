@@ -36,6 +36,35 @@ def flops_per_frame(lay, outdim, T):
     return dense, attn
 
 
+def _pmc_evidence(kernel_name: str) -> dict:
+    """Hardware-counter evidence for the roofline kernel from the rocprofv3 --pmc passes committed under profiles/
+    (counters cannot be collected inside this process; the passes ran this same default workload): HBM bytes per launch
+    (FETCH_SIZE x 2 - the gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md "HBM" - plus WRITE_SIZE) and
+    the MFMA-busy fraction at the power-limited clock the kernel actually ran at."""
+    import pathlib
+    prof = pathlib.Path(__file__).resolve().parent / 'profiles'
+    key = {'attention': 'attention3_kernel'}.get(kernel_name)
+    out = {}
+    if key is None:
+        return out
+    try:
+        hbm = json.loads((prof / 'r01_pmc_hbm_traffic_f16x3.json').read_text())
+        row = next(v for k, v in hbm.items() if k.startswith(key))
+        out['traffic'] = int((2 * row['FETCH_SIZE']['avg_KiB'] + row['WRITE_SIZE']['avg_KiB']) * 1024)
+        out['traffic_source'] = 'profiles/r01_pmc_hbm_traffic_f16x3.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x 2)'
+    except (OSError, StopIteration, KeyError, ValueError):
+        pass
+    try:
+        busy = json.loads((prof / 'r01_pmc_mfma_busy.json').read_text())
+        row = next(v for k, v in busy.items() if k.startswith(key))
+        out['pmc_mfma_busy_frac'] = round(row['MfmaUtil_percent'] / 100.0, 4)
+        out['pmc_effective_clock_mhz'] = round(row['effective_clock_MHz'])
+        out['pmc_source'] = 'profiles/r01_pmc_mfma_busy.json (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs))'
+    except (OSError, StopIteration, KeyError, ValueError):
+        pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -99,6 +128,8 @@ def main():
 
     # ---- synthetic clips (8 distinct per rank, tiled to the batch), resident in HBM ---------------------
     sr = cfg['audio_sample_rate']
+    default_workload = (args.config == 'midi_conformer' and args.batch == 32 and args.seconds == 30.0 and
+                        cfg['midi_extractor_args']['lay'] == 8)          # the configuration the committed PMC passes ran
     n_distinct = min(8, args.batch)
     clips = [synth.synth_clip(rank * 100 + i, args.seconds, sr) for i in range(n_distinct)]
     wave_list = [clips[i % n_distinct] for i in range(args.batch)]
@@ -186,6 +217,8 @@ def main():
                         'avg_launch_ms': dom['avg_ms'], 'logical_fp32_tflops': dom['tflops'],
                         'note': 'f16 MFMA FLOPs issued = 3 x logical (x = hi + lo split; ah*bh + ah*bl + al*bh)',
                     }
+                    if default_workload:
+                        result['roofline'].update(_pmc_evidence(dom['name']))
                 else:
                     result['roofline'] = {
                         'kernel': dom['name'], 'bound': 'mfma', 'achieved': dom['tflops'], 'peak': F32_MATRIX_PEAK_TFLOPS,
