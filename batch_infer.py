@@ -43,7 +43,7 @@ def infer(wav, infer_ins, config):
 
 def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, infer_ins, config,
                  round_midi: bool, max_batch_frames: int = 131072, io_threads: int = 8, prefetch: int = 256,
-                 flush_batches: int = 8) -> Dict[int, tuple]:
+                 flush_batches: int = 8, align_workers: int = 8) -> Dict[int, tuple]:
     """Rows ``indices`` of the CSV -> {row index: (note_seq, note_dur)}.  WAV files are read by a thread pool with a
     bounded read-ahead; up to ``flush_batches`` device batches of rows go through ``infer_files`` at a time (upload +
     RMS of batch k + 1 overlap the forward of batch k); chunks of consecutive rows share packed device batches."""
@@ -59,6 +59,12 @@ def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, 
         jobs.append((i, audio_path))
 
     slicer = Slicer(sr=config['audio_sample_rate'], max_sil_kept=1000)
+    # the word alignment (batch_infer.py:172-219) is pure-Python float / string work, ~2.5 ms per row and more with many
+    # notes: big jobs hand it to worker subprocesses (numpy + batch_logic only) so it overlaps the GPU
+    align_pool = None
+    if align_workers > 0 and len(jobs) >= 64:
+        from some_amd.align_worker import AlignPool
+        align_pool = AlignPool(align_workers)
 
     device_ingest = hasattr(infer_ins, 'infer_files')      # any other BaseInference: host Slicer + infer(), as the reference
 
@@ -74,8 +80,11 @@ def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, 
                 chunks = slicer.slice(wave)
                 per_file.append(list(zip([c['offset'] for c in chunks], infer_ins.infer([c['waveform'] for c in chunks]))))
         for (i, _), segments in zip(group, per_file):
-            notes = batch_logic.notes_from_segments([off for off, _ in segments], [seg for _, seg in segments])
-            out[i] = batch_logic.align_row(notes, rows[i]['ph_dur'], rows[i]['ph_num'], round_midi)
+            job = ([off for off, _ in segments], [seg for _, seg in segments], rows[i]['ph_dur'], rows[i]['ph_num'], round_midi)
+            if align_pool is None:
+                out[i] = batch_logic.align_job(*job)
+            else:
+                align_pool.submit(i, job)
 
     rate = config['audio_sample_rate']
     with ThreadPoolExecutor(max_workers=io_threads) as pool:
@@ -103,6 +112,8 @@ def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, 
             frames += t
         if group:
             flush(group)
+    if align_pool is not None:
+        out.update(align_pool.close())
     return out
 
 

@@ -122,3 +122,9 @@ def align_row(notes: List[dict], ph_dur_field: str, ph_num_field: str, round_mid
         dur_out.extend(durs)
     assert len(seq_out) == len(dur_out)
     return ' '.join(str(x) for x in seq_out), ' '.join(str(round(x, 6)) for x in dur_out)
+
+
+def align_job(offsets, segments, ph_dur_field: str, ph_num_field: str, round_midi: bool) -> Tuple[str, str]:
+    """One CSV row, start to finish (notes_from_segments + align_row): the unit of work batch_infer.py hands to its
+    alignment worker processes so that this pure-Python arithmetic runs beside the GPU instead of in front of it."""
+    return align_row(notes_from_segments(offsets, segments), ph_dur_field, ph_num_field, round_midi)

@@ -171,3 +171,24 @@ def test_extraction_service_dispatch_logic(tmp_path):
             svc.submit('m.ckpt', np.zeros((2, 10), dtype=np.float32))
     with pytest.raises(RuntimeError):
         svc.submit('m.ckpt', files[0])
+
+
+def test_align_pool_matches_inline(tmp_path):
+    """The alignment worker subprocesses return exactly what ``align_job`` returns in-process."""
+    import dataset_util
+    from some_amd import batch_logic
+    from some_amd.align_worker import AlignPool
+    fake = dataset_util.FakeInference()
+    jobs = {}
+    for i in range(12):
+        segs = fake.infer([np.zeros((300 + 40 * i) * 512, np.float32), np.zeros(200 * 512, np.float32)])
+        jobs[i] = ([0.0, 4.0 + i], segs, ' '.join(['0.400000'] * 20), ' '.join(['2'] * 10), bool(i % 2))
+    pool = AlignPool(3)
+    for k, a in jobs.items():
+        pool.submit(k, a)
+    got = pool.close()
+    assert got == {k: batch_logic.align_job(*a) for k, a in jobs.items()}
+    bad = AlignPool(1)
+    bad.submit('x', ([0.0], [{'note_midi': np.zeros(2, np.float32), 'note_dur': np.zeros(1), 'note_rest': np.zeros(2, bool)}], '0.5', '1', False))
+    with pytest.raises(AssertionError):
+        bad.close()
