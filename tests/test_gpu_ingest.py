@@ -118,3 +118,24 @@ def test_infer_files_equals_host_slicer_path(tmp_path, fmt):
                     np.testing.assert_array_equal(seg[k], r[k])
             pos += len(mine)
     assert n_chunks > len(files)                     # the slicer did cut something
+
+
+def test_infer_files_degenerate_lengths(tmp_path):
+    """Empty / sub-hop / exactly-one-hop files: one chunk each, T = 1 + L // hop frames, same notes as the host path."""
+    import inference
+    cfg = get_config('midi_conformer', lay=1)
+    ckpt = synth.save_checkpoint(cfg, tmp_path / 'model.ckpt', seed=5)
+    ins = inference.MIDIExtractionInference(config=cfg, model_path=ckpt)
+    slicer = Slicer(sr=44100, max_sil_kept=1000)
+    rng = np.random.default_rng(0)
+    files = [np.zeros(0, np.int16), rng.integers(-3000, 3000, 1).astype(np.int16), rng.integers(-3000, 3000, 511).astype(np.int16),
+             rng.integers(-3000, 3000, 512).astype(np.int16), rng.integers(-3000, 3000, 5000).astype(np.int16)]
+    got = ins.infer_files(files, slicer)
+    ref = ins.infer_batch([f.astype(np.float32) / np.float32(32768.0) for f in files])
+    for f, g, r in zip(files, got, ref):
+        assert len(g) == 1 and g[0][0] == 0
+        frames = 1 + len(f) // 512
+        assert abs(g[0][1]['note_dur'].sum() - frames * 512 / 44100) < 1e-9
+        for k in ('note_midi', 'note_dur', 'note_rest'):
+            np.testing.assert_array_equal(g[0][1][k], r[k])
+    assert ins.infer_files([], slicer) == []

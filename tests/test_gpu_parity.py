@@ -370,3 +370,29 @@ def test_deployment_twin(golden_dir, tmp_path):
     np.testing.assert_allclose(midi.cpu().numpy(), g['note_midi'], rtol=0, atol=2e-3)
     with pytest.raises(ValueError):
         mel(torch.zeros(1, 512).cuda())
+
+
+def test_twenty_minute_clip_both_precisions(engines):
+    """The web UI's upper bound (webui.py:43-44: 20 minutes = 103 360 frames in ONE clip, unsliced): attention over the
+    whole clip, decode beyond its LDS-resident capacity; split-f16 and exact-f32 modes agree to the logit tolerance."""
+    from some_amd import _lib
+    from some_amd.engine import ClipBatch, Engine
+    cfg = get_config('midi_conformer', lay=1)
+    sd = synth.synth_state_dict(cfg, 11)
+    T = 1 + (20 * 60 * 44100) // 512
+    rng = np.random.default_rng(2)
+    units = torch.from_numpy((rng.standard_normal((T, 80)) * 2 - 4).astype(np.float32)).cuda()
+    batch = ClipBatch([T], 'cuda')
+    outs = {}
+    for prec in ('f16x3', 'f32'):
+        e = Engine(dict(cfg, some_amd_precision=prec), device='cuda')
+        e.load_state_dict(sd)
+        midi, bound = e.forward(units, batch, head_mode=_lib.HEAD_SIGMOID)
+        assert torch.isfinite(midi).all() and torch.isfinite(bound).all()
+        outs[prec] = (midi, bound)
+        if prec == 'f16x3':
+            dec = e.decode(midi, bound, batch, quantized=False)
+            n = int(dec['n_notes'][0])
+            assert n >= 1 and int(dec['note_dur'][:n].sum()) == T
+    assert (outs['f16x3'][0] - outs['f32'][0]).abs().max().item() < LOGIT_TOL
+    assert (outs['f16x3'][1] - outs['f32'][1]).abs().max().item() < LOGIT_TOL
