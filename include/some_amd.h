@@ -202,9 +202,10 @@ size_t some_train_scratch_bytes(const SomeHandle* h, int64_t M, int32_t N);
 size_t some_train_gemm_splitk_bytes(const SomeHandle* h, int32_t M, int32_t N, int32_t K);
 int some_train_gemm_splitk(SomeHandle* h, const float* A_split_dev, int32_t lda, const float* W_split_dev, float* C_dev,
                            int32_t M, int32_t N, int32_t K, void* partial_dev, size_t partial_bytes, void* stream);
-/* out[n, m] = in[m, n] for m < M, 0 for M <= m < ld_out (the zero padding makes ld_out a valid contraction length). */
+/* out[n, m] = in[m, n] for m < M, 0 for M <= m < ld_out (the zero padding makes ld_out a valid contraction length).
+ * split_out = 1: rows are written in SPLIT32 format (ready as a split-f16 GEMM operand; ld_out % 32 == 0). */
 int some_train_transpose(SomeHandle* h, const float* in_dev, int32_t M, int32_t N, int32_t ld_in, float* out_dev,
-                         int32_t ld_out, void* stream);
+                         int32_t ld_out, int32_t split_out, void* stream);
 /* out[n] (+)= sum_m x[m, n]: bias gradient of nn.Linear / Conv1d. */
 int some_train_colsum(SomeHandle* h, const float* x_dev, int32_t M, int32_t N, int32_t ld, float* out_dev,
                       int32_t accumulate, void* scratch_dev, size_t scratch_bytes, void* stream);

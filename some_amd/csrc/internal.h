@@ -156,7 +156,7 @@ hipError_t launch_pcm_gather(const void* src, int is_pcm16, const int64_t* src_o
 size_t train_col_scratch_bytes(int M, int N);
 size_t train_dwconv_w_scratch_bytes(int M, int C);
 hipError_t launch_reduce_slices(const float* partial, int slices, size_t n, float* out, hipStream_t s);
-hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, hipStream_t s);
+hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, int split_out, hipStream_t s);
 hipError_t launch_colsum(const float* x, int M, int N, int ld, float* out, int accumulate, float* scratch, hipStream_t s);
 hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, hipStream_t s);
 hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx,

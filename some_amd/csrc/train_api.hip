@@ -67,12 +67,13 @@ int some_train_gemm_splitk(SomeHandle* h, const float* A_split_dev, int32_t lda,
 }
 
 int some_train_transpose(SomeHandle* h, const float* in_dev, int32_t M, int32_t N, int32_t ld_in, float* out_dev,
-                         int32_t ld_out, void* stream) {
+                         int32_t ld_out, int32_t split_out, void* stream) {
     if (!h) return SOME_EINVAL;
     T_CHECK(h, M >= 0 && N >= 0 && ld_in >= N && ld_out >= M, "some_train_transpose: bad shape");
+    T_CHECK(h, !split_out || (ld_out % 32) == 0, "some_train_transpose: SPLIT32 output needs ld_out % 32 == 0");
     if (M == 0 || N == 0) return SOME_OK;
     T_CHECK(h, in_dev && out_dev, "some_train_transpose: null pointer");
-    T_TRY(h, launch_transpose(in_dev, M, N, ld_in, out_dev, ld_out, st(stream)));
+    T_TRY(h, launch_transpose(in_dev, M, N, ld_in, out_dev, ld_out, split_out, st(stream)));
     return SOME_OK;
 }
 

@@ -13,6 +13,7 @@
 //   BCEWithLogits(mean) and BinaryEMDLoss with their gradients               (training/me_task.py:74-75, modules/losses/bound_loss.py:6-19)
 //   AdamW step on flat parameter / gradient / moment arrays                  (configs/two_head_model.yaml:42-47)
 #include "internal.h"
+#include "split.h"
 
 namespace {
 
@@ -27,6 +28,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---- transpose ---------------------------------------------------------------------------------------------
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int M, int N, int ld_in,
                                                          float* __restrict__ out, int ld_out) {
     __shared__ float tile[32][33];
@@ -41,7 +43,18 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + ty + 8 * i, m = m0 + tx;
-        if (n < N && m < ld_out) out[(size_t)n * ld_out + m] = tile[tx][ty + 8 * i];   // zeros beyond M
+        if (n < N && m < ld_out) {
+            const float v = tile[tx][ty + 8 * i];                                        // zeros beyond M
+            if (SPLIT) {   // SPLIT32 row (split.h): the 32 columns of this tile are exactly one k-block [32 hi | 32 lo]
+                half_t h, l;
+                split_f16(v, h, l);
+                half_t* blk = reinterpret_cast<half_t*>(out + (size_t)n * ld_out + m0);
+                blk[tx] = h;
+                blk[32 + tx] = l;
+            } else {
+                out[(size_t)n * ld_out + m] = v;
+            }
+        }
     }
 }
 
@@ -462,10 +475,11 @@ static inline int n_chunks(int M) { return (M + kChunkRows - 1) / kChunkRows; }
 size_t train_col_scratch_bytes(int M, int N) { return (size_t)n_chunks(M) * 2 * N * sizeof(float); }
 size_t train_dwconv_w_scratch_bytes(int M, int C) { return (size_t)n_chunks(M) * kTaps * C * sizeof(float); }
 
-hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, hipStream_t s) {
+hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, int split_out, hipStream_t s) {
     if (M <= 0 || N <= 0) return hipSuccess;
     dim3 grid((unsigned)((ld_out + 31) / 32), (unsigned)((N + 31) / 32));
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, M, N, ld_in, out, ld_out);
+    if (split_out) hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, s, in, M, N, ld_in, out, ld_out);
+    else hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, s, in, M, N, ld_in, out, ld_out);
     return hipGetLastError();
 }
 

@@ -52,6 +52,9 @@ class TrainOps:
         self.check(self.lib.some_op_split_rows(self.h, _p(x), _p(out), x.shape[0], x.shape[1], self.stream()))
         return out
 
+    def _use_split(self, M: int, N: int, K: int) -> bool:
+        return self.gemm_precision == 'f16x3' and K % 32 == 0 and N >= 64 and M >= 64
+
     def gemm(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         """a [M, K] @ w[N, K]^T (+ bias).  ``gemm_precision`` 'f16x3' (default): both operands are split into f16
         hi + lo halves and contracted with three f16 MFMA products, fp32 accumulation (gemm_f16x3.hip; fp32-equivalent,
@@ -64,8 +67,9 @@ class TrainOps:
         if M == 0:
             return out
         epi = _lib.EPI_BIAS if bias is not None else _lib.EPI_NONE
-        if self.gemm_precision == 'f16x3' and K % 32 == 0 and N >= 64 and M >= 64:
-            a3, w3 = self.split_rows(a), self.split_rows(w)
+        if self._use_split(M, N, K):
+            a3 = self.split_rows(a)
+            w3 = self.split_rows(w)
             self.check(self.lib.some_op_gemm(self.h, epi, _p(a3), K, _p(w3), _p(bias), None, N, _p(out), N, M, N, K, 1.0, 0, None,
                                              _lib.GEMM_SPLIT_IN | (2 << 8), self.stream()))
             return out
@@ -78,28 +82,61 @@ class TrainOps:
                                          self.stream()))
         return out
 
-    def gemm_long_k(self, a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-        """a [M, K] @ w[N, K]^T for weight gradients: K = all frames (long), M x N small.  Split-K over workgroups in
-        f16x3 mode (some_train_gemm_splitk); plain ``gemm`` otherwise."""
-        M, K = a.shape
-        N = w.shape[0]
-        if self.gemm_precision != 'f16x3' or K % 32 or N % 4 or M < 32:
-            return self.gemm(a, w)
-        a3, w3 = self.split_rows(a), self.split_rows(w)
-        out = self.new(M, N)
-        need = int(self.lib.some_train_gemm_splitk_bytes(self.h, M, N, K))
-        if self._partial is None or self._partial.numel() < need:
-            self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
-        self.check(self.lib.some_train_gemm_splitk(self.h, _p(a3), K, _p(w3), _p(out), M, N, K, _p(self._partial), self._partial.numel(),
-                                                   self.stream()))
-        return out
+    def gemm_dx(self, dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """dy [M, N] @ w [N, K]: the data gradient of ``linear`` (the weight is transposed - and split - on the fly)."""
+        M, N = dy.shape
+        K = w.shape[1]
+        if self._use_split(M, K, N):
+            wt3 = self.transpose(w, pad_to=32, split=True)
+            a3 = self.split_rows(dy)
+            out = self.new(M, K)
+            self.check(self.lib.some_op_gemm(self.h, _lib.EPI_NONE, _p(a3), N, _p(wt3), None, None, K, _p(out), K, M, K, N, 1.0, 0, None,
+                                             _lib.GEMM_SPLIT_IN | (2 << 8), self.stream()))
+            return out
+        return self.gemm(dy, self.transpose(w, pad_to=1))
 
-    def transpose(self, x: torch.Tensor, pad_to: int = 32) -> torch.Tensor:
-        """[M, N] -> [N, Mp] with Mp = M rounded up to ``pad_to`` (zero padded): a contraction operand over M."""
+    def gemm_dw(self, dy: torch.Tensor, x: torch.Tensor, with_bias: bool):
+        """Weight (and bias) gradient of ``linear``: dW [N, K] = dy^T x contracted over the M frames, db = dy^T 1 obtained
+        from the SAME GEMM by appending a row of ones to x^T.  Both operands come out of the transpose kernel already in
+        SPLIT32 form in f16x3 mode; the long contraction is cut across workgroups (split-K)."""
+        M, N = dy.shape
+        K = x.shape[1]
+        Mp = (M + 31) // 32 * 32
+        extra = 4 if with_bias else 0                                   # ones row + 3 zero rows keep (K + extra) % 4 == 0
+        use3 = self.gemm_precision == 'f16x3' and N >= 32 and K % 4 == 0
+        xt = torch.empty((K + extra, Mp), dtype=torch.float32, device=self.device)
+        self.check(self.lib.some_train_transpose(self.h, _p(x), M, K, K, _p(xt), Mp, 1 if use3 else 0, self.stream()))
+        if with_bias:
+            tail = xt[K:]
+            tail.zero_()
+            if use3:                                                    # 1.0 = f16 0x3C00 in the hi halves, lo halves 0
+                tail[0].view(torch.int32).view(-1, 32)[:, :16] = 0x3C003C00
+            else:
+                tail[0].fill_(1.0)
+        dyt = torch.empty((N, Mp), dtype=torch.float32, device=self.device)
+        self.check(self.lib.some_train_transpose(self.h, _p(dy), M, N, N, _p(dyt), Mp, 1 if use3 else 0, self.stream()))
+        Kx = K + extra
+        out = self.new(N, Kx)
+        if use3:
+            need = int(self.lib.some_train_gemm_splitk_bytes(self.h, N, Kx, Mp))
+            if self._partial is None or self._partial.numel() < need:
+                self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.check(self.lib.some_train_gemm_splitk(self.h, _p(dyt), Mp, _p(xt), _p(out), N, Kx, Mp, _p(self._partial), self._partial.numel(),
+                                                       self.stream()))
+        else:
+            self.check(self.lib.some_op_gemm(self.h, _lib.EPI_NONE, _p(dyt), Mp, _p(xt), None, None, Kx, _p(out), Kx, N, Kx, Mp, 1.0, 0, None, 0,
+                                             self.stream()))
+        if not with_bias:
+            return out, None
+        return out[:, :K].contiguous(), out[:, K].contiguous()
+
+    def transpose(self, x: torch.Tensor, pad_to: int = 32, split: bool = False) -> torch.Tensor:
+        """[M, N] -> [N, Mp] with Mp = M rounded up to ``pad_to`` (zero padded): a contraction operand over M;
+        ``split``: written directly in SPLIT32 form."""
         M, N = x.shape
         Mp = (M + pad_to - 1) // pad_to * pad_to
         out = self.new(N, Mp)
-        self.check(self.lib.some_train_transpose(self.h, _p(x), M, N, N, _p(out), Mp, self.stream()))
+        self.check(self.lib.some_train_transpose(self.h, _p(x), M, N, N, _p(out), Mp, 1 if split else 0, self.stream()))
         return out
 
     def colsum(self, x: torch.Tensor) -> torch.Tensor:
@@ -177,10 +214,11 @@ class _Linear(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
-            dx = ops.gemm(dy, ops.transpose(w2, pad_to=1))                              # dy [M, N] . W [N, K]
+            dx = ops.gemm_dx(dy, w2.contiguous())
         if ctx.needs_input_grad[2]:
-            dw = ops.gemm_long_k(ops.transpose(dy), ops.transpose(x)).reshape(ctx.wshape)   # contraction over the (padded) rows
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+            dw, db = ops.gemm_dw(dy, x.contiguous(), ctx.has_bias and ctx.needs_input_grad[3])
+            dw = dw.reshape(ctx.wshape)
+        elif ctx.has_bias and ctx.needs_input_grad[3]:
             db = ops.colsum(dy)
         return None, dx, dw, db
 
