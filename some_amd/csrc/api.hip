@@ -443,8 +443,8 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
         auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((n_max + bn - 1) / bn) * kStreams; };
         if (blocks(256, 256) >= 512) return 2;       // >= 2 waves of workgroups over 256 CUs
         if (blocks(256, 128) >= 512) return 1;
-        if (blocks(128, 128) >= 512) return 0;       // 128 x 128 tiles run two per CU
-        return 4;                                    // 64 x 128: single-clip latency regime
+        if (blocks(128, 128) >= 256) return 0;       // 128 x 128 tiles run two per CU (measured: 2 x 30 s clips 7.7 vs 8.5 ms)
+        return 4;                                    // 64 x 128: single-clip latency regime (1 x 30 s: 5.07 vs 5.13 ms)
     };
     auto launch_any = [&](GemmEpi epi, GemmArgs& a, bool out_split, int n_max) -> hipError_t {
         if (f16x3) return launch_gemm_f16x3(epi, a, out_split, pick_tile(n_max), s);
