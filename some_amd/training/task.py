@@ -114,3 +114,40 @@ class MIDIExtractionTrainer:
         out['skipped'] = skipped
         out['grad_norm'] = grad_norm
         return out
+
+    # ---- me_task.py:113-153 -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sync_eval_engine(self):
+        """Pack the current parameters (+ BatchNorm running statistics) into the inference engine: evaluation runs
+        the INFERENCE kernels - eval-mode semantics (dropout off, BatchNorm folded from running stats) for free."""
+        self.engine.load_state_dict({k: v.cpu() for k, v in self.model.params.state_dict().items()})
+
+    @torch.no_grad()
+    def validation_step(self, sample: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """_validation_step: eval-mode losses, then sigmoid probabilities -> masked decode -> frame-level MIDIAccuracy
+        counts (modules/metrics/midi_acc.py:15-41, tolerance 0.5).  Call ``sync_eval_engine()`` after the last update."""
+        from .. import _lib
+        units = sample['units']
+        B, T = units.shape[0], units.shape[1]
+        batch = ClipBatch([T] * B, self.ops.device)
+        masks = sample['unit2note'] > 0
+        flat_units = units.reshape(B * T, -1).contiguous()
+        logits, bounds = self.engine.forward(flat_units, batch, mask=masks, head_mode=_lib.HEAD_LOGITS)
+        out: Dict[str, torch.Tensor] = {}
+        if self.config.get('use_bound_loss', True):
+            out['bound_loss'] = self.ops.binary_emd(bounds, sample['bounds'].reshape(-1).float(), B, T)
+        if self.config.get('use_midi_loss', True):
+            out['midi_loss'] = self.ops.bce_with_logits(logits, sample['probs'].reshape(B * T, -1).float())
+        probs = self.ops.eltwise(_lib.ELT_SIGMOID_FWD, logits)
+        dec = self.engine.decode(probs, bounds, batch, quantized=False, mask=masks, debug=True)
+        midi_pred = dec['values'].reshape(B, T)
+        rest_pred = dec['rest'].reshape(B, T).bool()
+        note_midi_gt = sample['note_midi'].float().clone()
+        note_midi_gt[sample['note_rest'].bool()] = -torch.inf
+        midi_gt = torch.gather(torch.nn.functional.pad(note_midi_gt, [1, 0], value=-torch.inf), 1, sample['unit2note'])
+        rest_gt = midi_gt < 0
+        close = ~rest_pred & ~rest_gt & (torch.abs(midi_pred - midi_gt) <= 0.5)
+        overall = close & (rest_pred == rest_gt) & masks
+        out['midi_acc_correct'], out['midi_acc_total'] = overall.sum(), masks.sum()
+        out['notes'] = dec['n_notes']
+        return out

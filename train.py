@@ -36,7 +36,8 @@ def _load_config(config: str) -> dict:
 @click.option('--synthetic', type=int, default=0, metavar='N', help='Train on N synthetic clips with known notes')
 @click.option('--max_updates', type=int, default=None, help='Override max_updates')
 @click.option('--log_interval', type=int, default=10)
-def train(config, exp_name, work_dir, synthetic, max_updates, log_interval):
+@click.option('--val_clips', type=int, default=8, help='held-out synthetic clips for the validation pass')
+def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_clips):
     from some_amd.training import data
     from some_amd.training.task import MIDIExtractionTrainer
     cfg = _load_config(config)
@@ -58,6 +59,14 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval):
     items = [data.make_sample(trainer.engine, data.synth_note_clip(i, 4.0 + 8.0 * torch.rand((), generator=rng_len).item()), timestep)
              for i in range(synthetic)]
     lengths = [int(s['units'].shape[0]) for s in items]
+    val_items = [data.make_sample(trainer.engine, data.synth_note_clip(10 ** 6 + i, 6.0), timestep) for i in range(val_clips)]
+
+    def validate(step):
+        trainer.sync_eval_engine()
+        res = trainer.validation_step(data.collater(val_items, cfg))
+        acc = float(res['midi_acc_correct']) / max(float(res['midi_acc_total']), 1.0)
+        print(f'validation @ {step}: ' + ', '.join(f'{k}={float(v):.5f}' for k, v in res.items() if k.endswith('loss')) + f', midi_acc={acc:.4f}')
+
     total = max_updates if max_updates is not None else cfg.get('max_updates', 100000)
     keep, interval = cfg.get('num_ckpt_keep', 5), cfg.get('val_check_interval', 1000)
     saved, epoch = [], 0
@@ -74,6 +83,8 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval):
                 path = work / f'model_ckpt_steps_{step}.ckpt'
                 torch.save({'state_dict': {'model.' + k: v.cpu() for k, v in trainer.model.params.state_dict().items()}, 'global_step': step}, path)
                 saved.append(path)
+                if val_items:
+                    validate(step)
                 while len(saved) > keep:
                     saved.pop(0).unlink(missing_ok=True)
             if step >= total:
