@@ -33,19 +33,42 @@ class BaseInference:
         prefix_in_ckpt = 'model'
         import torch.distributed as dist
         sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        if sharded and hasattr(model, 'load_packed_arena'):
-            # one process per GPU: rank 0 reads + packs the checkpoint, then ONE broadcast of the flat fp32
-            # arena (RCCL over xGMI); the other ranks never touch the file
-            arena = torch.empty(model.engine.arena_numel, dtype=torch.float32, device=self.device)
-            if dist.get_rank() == 0:
-                arena.copy_(model.engine.pack_state_dict(self._read_state_dict(prefix_in_ckpt)))
-            dist.broadcast(arena, src=0)
-            model.load_packed_arena(arena)
+        self.loaded_from_cache = False
+        if hasattr(model, 'load_packed_arena'):
+            # the packed arena is cached next to the checkpoint (some_amd/arena_cache.py) and, with one process per GPU,
+            # read + packed by rank 0 only and sent with ONE broadcast (RCCL over xGMI); other ranks never touch the file
+            arena = None
+            if not sharded or dist.get_rank() == 0:
+                arena = self._packed_arena(model.engine, prefix_in_ckpt)
+            if sharded:
+                dev = torch.empty(model.engine.arena_numel, dtype=torch.float32, device=self.device)
+                if dist.get_rank() == 0:
+                    dev.copy_(arena)
+                dist.broadcast(dev, src=0)
+            else:
+                dev = arena.to(self.device)
+            model.load_packed_arena(dev)
         else:
             model.load_state_dict(self._read_state_dict(prefix_in_ckpt), strict=True)
         if not sharded or dist.get_rank() == 0:
             print(f'| load \'{prefix_in_ckpt}\' from \'{self.model_path}\'.')
         return model
+
+    def _packed_arena(self, engine, prefix_in_ckpt: str) -> torch.Tensor:
+        """Host arena of this checkpoint: from the cache file when it matches the checkpoint, else strict load + pack
+        (and the cache is written for the next start).  ``some_amd_arena_cache: false`` in the config turns it off."""
+        from .. import arena_cache
+        use_cache = bool(self.config.get('some_amd_arena_cache', True))
+        prec = int(engine.c_config.precision)
+        if use_cache:
+            hit = arena_cache.load(pathlib.Path(self.model_path), engine.arena_numel, prec, self.config)
+            if hit is not None:
+                self.loaded_from_cache = True
+                return torch.from_numpy(hit)
+        arena = engine.pack_state_dict(self._read_state_dict(prefix_in_ckpt))
+        if use_cache:
+            arena_cache.store(pathlib.Path(self.model_path), arena.numpy(), prec, self.config)
+        return arena
 
     def _read_state_dict(self, prefix_in_ckpt: str):
         state_dict = torch.load(self.model_path, map_location='cpu')['state_dict']

@@ -396,3 +396,28 @@ def test_twenty_minute_clip_both_precisions(engines):
             assert n >= 1 and int(dec['note_dur'][:n].sum()) == T
     assert (outs['f16x3'][0] - outs['f32'][0]).abs().max().item() < LOGIT_TOL
     assert (outs['f16x3'][1] - outs['f32'][1]).abs().max().item() < LOGIT_TOL
+
+
+def test_arena_cache_round_trip(tmp_path):
+    """Second construction from the same checkpoint reads the cached flat arena (no torch.load / pack) and gives
+    bit-identical outputs; touching the checkpoint invalidates the cache."""
+    import time
+    import inference
+    cfg = get_config('midi_conformer', lay=1)
+    ckpt = synth.save_checkpoint(cfg, tmp_path / 'model.ckpt', seed=4)
+    w = synth.synth_clip(9, 2.0)
+    a = inference.MIDIExtractionInference(config=cfg, model_path=ckpt)
+    assert not a.loaded_from_cache
+    b = inference.MIDIExtractionInference(config=cfg, model_path=ckpt)
+    assert b.loaded_from_cache
+    ra, rb = a.infer([w])[0], b.infer([w])[0]
+    for k in ra:
+        np.testing.assert_array_equal(ra[k], rb[k])
+    time.sleep(0.01)
+    synth.save_checkpoint(cfg, ckpt, seed=5)                       # new weights, same path
+    c = inference.MIDIExtractionInference(config=cfg, model_path=ckpt)
+    assert not c.loaded_from_cache
+    rc = c.infer([w])[0]
+    assert len(rc['note_midi']) != len(ra['note_midi']) or not np.array_equal(rc['note_midi'], ra['note_midi'])
+    d = inference.MIDIExtractionInference(config=dict(cfg, some_amd_arena_cache=False), model_path=ckpt)
+    assert not d.loaded_from_cache

@@ -192,3 +192,28 @@ def test_align_pool_matches_inline(tmp_path):
     bad.submit('x', ([0.0], [{'note_midi': np.zeros(2, np.float32), 'note_dur': np.zeros(1), 'note_rest': np.zeros(2, bool)}], '0.5', '1', False))
     with pytest.raises(AssertionError):
         bad.close()
+
+
+def test_arena_cache_file_validation(tmp_path):
+    """The cached flat weight file is used only while checkpoint size / mtime, arena size, precision and the model shape
+    keys all match; anything else (or a truncated file) reads as 'no cache'."""
+    from some_amd import arena_cache
+    from some_amd.configs import get_config
+    cfg = get_config('midi_conformer', lay=1)
+    ckpt = tmp_path / 'm.ckpt'
+    ckpt.write_bytes(b'x' * 100)
+    arena = np.arange(1000, dtype=np.float32)
+    assert arena_cache.load(ckpt, 1000, 1, cfg) is None
+    assert arena_cache.store(ckpt, arena, 1, cfg)
+    np.testing.assert_array_equal(arena_cache.load(ckpt, 1000, 1, cfg), arena)
+    assert arena_cache.load(ckpt, 1000, 0, cfg) is None                       # other precision: other file
+    assert arena_cache.load(ckpt, 999, 1, cfg) is None                        # arena size changed (library layout)
+    assert arena_cache.load(ckpt, 1000, 1, get_config('midi_conformer', lay=2)) is None
+    path = arena_cache.cache_path(ckpt, 1)
+    path.write_bytes(path.read_bytes()[:-8])                                  # truncated
+    assert arena_cache.load(ckpt, 1000, 1, cfg) is None
+    assert arena_cache.store(ckpt, arena, 1, cfg)
+    ckpt.write_bytes(b'y' * 101)                                              # checkpoint replaced
+    assert arena_cache.load(ckpt, 1000, 1, cfg) is None
+    ro = tmp_path / 'missing_dir' / 'm.ckpt'
+    assert arena_cache.store(ro, arena, 1, cfg) is False                      # unwritable: best effort

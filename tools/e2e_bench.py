@@ -30,6 +30,10 @@ def main():
         t0 = time.perf_counter()
         ins = inference.MIDIExtractionInference(config=cfg, model_path=ckpt)
         print(f'model load + pack + upload: {time.perf_counter() - t0:.2f} s')
+        t0 = time.perf_counter()
+        again = inference.MIDIExtractionInference(config=cfg, model_path=ckpt)
+        print(f'second start (cached flat arena: {again.loaded_from_cache}): {time.perf_counter() - t0:.2f} s')
+        del again
     base = [synth.synth_clip(i, args.seconds) for i in range(8)]
     waves = [base[i % 8] for i in range(args.clips)]
     ins.infer(waves[:32])                      # warm-up (allocations, pinned buffers)
