@@ -252,4 +252,21 @@ int some_train_attention_bwd(SomeHandle* h, const float* qkv_dev, const float* o
     return SOME_OK;
 }
 
+int some_train_attention_bwd_f16x3(SomeHandle* h, const float* qkv_split_dev, const float* qkv_t_split_dev,
+                                   const float* dout_split_dev, const float* dout_t_split_dev, const float* out_dev,
+                                   const float* dout_dev, const float* lse_dev, const int32_t* frame_offsets_dev,
+                                   int32_t B, int32_t max_frames, int32_t M, int32_t Mp, float* dqkv_dev,
+                                   float* dsum_scratch_dev, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, B >= 0 && max_frames >= 0 && M >= 0, "some_train_attention_bwd_f16x3: negative size");
+    if (B == 0 || M == 0) return SOME_OK;
+    T_CHECK(h, Mp >= M && (Mp % 32) == 0, "some_train_attention_bwd_f16x3: Mp must be M rounded up to a multiple of 32");
+    T_CHECK(h, qkv_split_dev && qkv_t_split_dev && dout_split_dev && dout_t_split_dev && out_dev && dout_dev && lse_dev && frame_offsets_dev &&
+                   dqkv_dev && dsum_scratch_dev, "some_train_attention_bwd_f16x3: null pointer");
+    T_TRY(h, launch_attention_dsum(out_dev, dout_dev, dsum_scratch_dev, M, st(stream)));
+    T_TRY(h, launch_attention_bwd_f16x3(qkv_split_dev, qkv_t_split_dev, dout_split_dev, dout_t_split_dev, lse_dev, dsum_scratch_dev,
+                                        frame_offsets_dev, B, max_frames, M, Mp, dqkv_dev, st(stream)));
+    return SOME_OK;
+}
+
 }  // extern "C"

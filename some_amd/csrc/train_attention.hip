@@ -330,6 +330,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs a, int 
 
 }  // namespace
 
+hipError_t launch_attention_dsum(const float* out, const float* dout, float* dsum, int M, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, out, dout, dsum, M);
+    return hipGetLastError();
+}
+
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.max_frames <= 0 || a.M <= 0) return hipSuccess;
     static bool attr_set = false;

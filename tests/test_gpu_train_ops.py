@@ -157,10 +157,13 @@ def test_adamw_matches_torch(ops):
         _close(p, p_ref, tol=2e-6)
 
 
-@pytest.mark.parametrize('lens', [[64], [1], [33, 130], [257, 5, 128], [700]])
-def test_attention_fwd_bwd(ops, lens):
-    """Flash attention forward (with saved log-sum-exp) and its two-kernel backward vs torch SDPA autograd."""
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
+@pytest.mark.parametrize('lens', [[64], [1], [33, 130], [257, 5, 128], [700], [31, 1, 2, 64, 95]])
+def test_attention_fwd_bwd(ops, lens, precision):
+    """Flash attention forward (with saved log-sum-exp) and its two-kernel backward - split-f16 and exact-f32 MFMA
+    variants - vs torch SDPA autograd."""
     from some_amd.engine import ClipBatch
+    ops.attention_precision = precision
     batch = ClipBatch(lens, 'cuda')
     M = sum(lens)
     qkv = _rand(M, 1536, seed=20 + M)
@@ -177,4 +180,7 @@ def test_attention_fwd_bwd(ops, lens):
             pos += t
         return torch.cat(outs)
 
-    _pair(lambda qkv: ops.attention(qkv, batch), ref, [qkv], tol=3e-5)
+    try:
+        _pair(lambda qkv: ops.attention(qkv, batch), ref, [qkv], tol=3e-5)
+    finally:
+        ops.attention_precision = ops.gemm_precision
