@@ -278,6 +278,12 @@ int some_train_attention_bwd(SomeHandle* h, const float* qkv_dev, const float* o
                              const float* lse_dev, const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames,
                              int32_t M, float* dqkv_dev, float* dsum_scratch_dev, void* stream);
 
+/* The forward on the f16 matrix pipe with 3-term split operands (fp32-equivalent): qkv_split = some_op_split_rows(qkv),
+ * qkv_t_split = some_train_transpose(qkv, split_out = 1) with Mp = M rounded up to a multiple of 64.  Writes fp32 out
+ * [M, 512] and lse [8, M]; the same two split tensors feed some_train_attention_bwd_f16x3. */
+int some_train_attention_fwd_f16x3(SomeHandle* h, const float* qkv_split_dev, const float* qkv_t_split_dev,
+                                   const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, int32_t M,
+                                   int32_t Mp, float* out_dev, float* lse_dev, void* stream);
 /* The same backward on the f16 matrix pipe with 3-term split operands (fp32-equivalent).  qkv_split / dout_split:
  * some_op_split_rows of qkv [M, 1536] / dout [M, 512]; qkv_t_split / dout_t_split: some_train_transpose(split_out = 1)
  * of the same tensors ([1536, Mp] / [512, Mp], Mp = M rounded up to 32).  out_dev / dout_dev (fp32) are only used for

@@ -75,6 +75,10 @@ __device__ __forceinline__ void split8(const f32x16& p, int base, half8& h, half
     }
 }
 
+// TRAIN = true: the training forward (train_api: some_train_attention_fwd_f16x3) - Q / K rows come straight from
+// split_rows(qkv) (row stride 6144 B), V^T from transpose(qkv, split) (SPLIT32 over frames: 32-frame blocks [32 hi | 32 lo]),
+// the output is fp32 and the base-2 log-sum-exp is stored for the backward.
+template <bool TRAIN>
 __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -90,17 +94,18 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
-    const char* __restrict__ Qp = reinterpret_cast<const char*>(a.q[g]) + head * 256;     // row stride 2048 B
+    constexpr size_t ROW_B = TRAIN ? 6144 : 2048;       // bytes between consecutive frames of Q / K
+    const char* __restrict__ Qp = reinterpret_cast<const char*>(a.q[g]) + head * 256;
     const char* __restrict__ Kp = reinterpret_cast<const char*>(a.k[g]) + head * 256;
-    const char* __restrict__ Vh = reinterpret_cast<const char*>(a.vt[g]) + (size_t)head * kHeadDim * a.ldv * 2;
-    const char* __restrict__ Vl = Vh + (size_t)kDim * a.ldv * 2;
+    const char* __restrict__ Vh = reinterpret_cast<const char*>(a.vt[g]) + (size_t)head * kHeadDim * a.ldv * (TRAIN ? 4 : 2);
+    const char* __restrict__ Vl = Vh + (size_t)kDim * a.ldv * 2;                          // (planes format only)
 
     // ---- Q fragments (B operand of S^T): slab s covers d = 16 s .. 16 s + 15; lane half kg holds 8 of them
     half8 qh[4], ql[4];
     {
         const int q = q0 + wave * 32 + l31;
         const bool qv = q < T;
-        const char* row = Qp + (size_t)(f0 + (qv ? q : 0)) * 2048;
+        const char* row = Qp + (size_t)(f0 + (qv ? q : 0)) * ROW_B;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int off = (s >> 1) * 128 + (s & 1) * 32 + kg * 16;
@@ -124,14 +129,15 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int key = g0 + srow + 16 * p;
-            rk[p] = key < a.M ? *reinterpret_cast<const f32x4*>(Kp + (size_t)key * 2048 + sc * 16) : zero4;
+            rk[p] = key < a.M ? *reinterpret_cast<const f32x4*>(Kp + (size_t)key * ROW_B + sc * 16) : zero4;
         }
     };
     auto gload_v = [&](int i) {
         const int g0 = (gt0 + i) * KT;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const char* vsrc = (sc < 8 ? Vh : Vl) + ((size_t)(srow + 16 * p) * a.ldv + g0) * 2 + (sc & 7) * 16;
+            const char* vsrc = TRAIN ? Vh + ((size_t)(srow + 16 * p) * a.ldv + g0) * 4 + sc * 16      // two 32-frame blocks of hi | lo
+                                     : (sc < 8 ? Vh : Vl) + ((size_t)(srow + 16 * p) * a.ldv + g0) * 2 + (sc & 7) * 16;
             rv[p] = *reinterpret_cast<const f32x4*>(vsrc);
         }
     };
@@ -257,15 +263,18 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
             for (int sp = 0; sp < 2; ++sp) {
                 half8 ph, pl;
                 split8(sub == 0 ? s0 : s1, 8 * sp, ph, pl);
-                const int kd = 16 * sub + 8 * sp;                     // dword offset of key 32 sub + 16 s'
+                // dword offset of key 32 sub + 16 s' and of its lo half: row = [64 hi | 64 lo] (planes) or
+                // [32 hi | 32 lo][32 hi | 32 lo] (SPLIT32 over frames)
+                constexpr int LO = TRAIN ? 16 : 32;
+                const int kd = (TRAIN ? 32 : 16) * sub + 8 * sp;
                 const half4 a0 = *reinterpret_cast<const half4*>(vp + kd);
                 const half4 a1 = *reinterpret_cast<const half4*>(vp + kd + 4);
-                const half4 b0 = *reinterpret_cast<const half4*>(vp + 32 + kd);
-                const half4 b1 = *reinterpret_cast<const half4*>(vp + 32 + kd + 4);
+                const half4 b0 = *reinterpret_cast<const half4*>(vp + LO + kd);
+                const half4 b1 = *reinterpret_cast<const half4*>(vp + LO + kd + 4);
                 const half4 c0 = *reinterpret_cast<const half4*>(vp + 32 * LDR + kd);
                 const half4 c1 = *reinterpret_cast<const half4*>(vp + 32 * LDR + kd + 4);
-                const half4 d0 = *reinterpret_cast<const half4*>(vp + 32 * LDR + 32 + kd);
-                const half4 d1 = *reinterpret_cast<const half4*>(vp + 32 * LDR + 32 + kd + 4);
+                const half4 d0 = *reinterpret_cast<const half4*>(vp + 32 * LDR + LO + kd);
+                const half4 d1 = *reinterpret_cast<const half4*>(vp + 32 * LDR + LO + kd + 4);
                 const half8 vh0 = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const half8 vl0 = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const half8 vh1 = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -337,14 +346,22 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
         const int q = q0 + wave * 32 + ql_;
         if (q < T) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(patch + ql_ * LDR + ocol);
-            half4 hh, ll;
+            if (TRAIN) {
+                *reinterpret_cast<f32x4*>(a.out32[g] + (size_t)(f0 + q) * kDim + head * kHeadDim + ocol) = v;
+            } else {
+                half4 hh, ll;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { half_t h, l; split_f16(v[i], h, l); hh[i] = h; ll[i] = l; }
-            char* row = reinterpret_cast<char*>(a.out[g]) + ((size_t)(f0 + q) * kDim + head * kHeadDim) * 4 +
-                        (ocol >> 5) * 128 + (ocol & 31) * 2;
-            *reinterpret_cast<half4*>(row) = hh;
-            *reinterpret_cast<half4*>(row + 64) = ll;
+                for (int i = 0; i < 4; ++i) { half_t h, l; split_f16(v[i], h, l); hh[i] = h; ll[i] = l; }
+                char* row = reinterpret_cast<char*>(a.out[g]) + ((size_t)(f0 + q) * kDim + head * kHeadDim) * 4 +
+                            (ocol >> 5) * 128 + (ocol & 31) * 2;
+                *reinterpret_cast<half4*>(row) = hh;
+                *reinterpret_cast<half4*>(row + 64) = ll;
+            }
         }
+    }
+    if (TRAIN && kg == 0) {       // P was carried as 2^kPShift p: lse2 = max + log2(sum p)
+        const int q = q0 + wave * 32 + l31;
+        if (q < T) a.lse[g][(size_t)head * a.M + f0 + q] = m_run + __log2f(l_tot) - kPShift;
     }
 }
 
@@ -354,14 +371,17 @@ hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
     if (a.B <= 0 || a.max_frames <= 0) return hipSuccess;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int nqb = (a.max_frames + QB - 1) / QB;
     const int units = a.B * kHeads * a.groups;
     const int slots = (units + 7) / 8;
-    hipLaunchKernelGGL(attention3_kernel, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    if (a.out32[0] != nullptr) hipLaunchKernelGGL(attention3_kernel<true>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    else hipLaunchKernelGGL(attention3_kernel<false>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     return hipGetLastError();
 }

@@ -107,6 +107,10 @@ struct Attn3Args {
     float* out[kStreams];          // [M, 512] SPLIT32
     const int32_t* frame_offsets;
     int groups, B, max_frames, M, ldv;
+    // training forward (out32 != nullptr): q / k point into split_rows(qkv) (row stride 1536 floats), vt into the V rows of
+    // transpose(qkv, split) ([.., ldv] SPLIT32 over frames, ldv % 64 == 0); fp32 output + base-2 log-sum-exp [8, M]
+    float* out32[kStreams];
+    float* lse[kStreams];
 };
 hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s);
 inline int vt_ld(int64_t M) { return (int)((M + 255) / 256 * 256); }

@@ -252,6 +252,23 @@ int some_train_attention_bwd(SomeHandle* h, const float* qkv_dev, const float* o
     return SOME_OK;
 }
 
+int some_train_attention_fwd_f16x3(SomeHandle* h, const float* qkv_split_dev, const float* qkv_t_split_dev,
+                                   const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, int32_t M,
+                                   int32_t Mp, float* out_dev, float* lse_dev, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, B >= 0 && max_frames >= 0 && M >= 0, "some_train_attention_fwd_f16x3: negative size");
+    if (B == 0 || M == 0) return SOME_OK;
+    T_CHECK(h, Mp >= M && (Mp % 64) == 0, "some_train_attention_fwd_f16x3: Mp must be M rounded up to a multiple of 64");
+    T_CHECK(h, qkv_split_dev && qkv_t_split_dev && frame_offsets_dev && out_dev && lse_dev, "some_train_attention_fwd_f16x3: null pointer");
+    Attn3Args a{};
+    a.q[0] = qkv_split_dev; a.k[0] = qkv_split_dev + kDim;
+    a.vt[0] = qkv_t_split_dev + (size_t)2 * kDim * Mp;            // V rows of the frame-major split tensor
+    a.out32[0] = out_dev; a.lse[0] = lse_dev;
+    a.frame_offsets = frame_offsets_dev; a.groups = 1; a.B = B; a.max_frames = max_frames; a.M = M; a.ldv = Mp;
+    T_TRY(h, launch_attention_f16x3(a, st(stream)));
+    return SOME_OK;
+}
+
 int some_train_attention_bwd_f16x3(SomeHandle* h, const float* qkv_split_dev, const float* qkv_t_split_dev,
                                    const float* dout_split_dev, const float* dout_t_split_dev, const float* out_dev,
                                    const float* dout_dev, const float* lse_dev, const int32_t* frame_offsets_dev,

@@ -28,7 +28,7 @@ class TrainOps:
         self._scratch: Optional[torch.Tensor] = None
         self._partial: Optional[torch.Tensor] = None
         self.gemm_precision = 'f16x3' if engine.c_config.precision == _lib.PRECISION_F16X3 else 'f32'
-        self.attention_precision = self.gemm_precision      # backward: split-f16 or exact-f32 MFMA (forward: exact f32)
+        self.attention_precision = self.gemm_precision      # forward + backward: split-f16 or exact-f32 MFMA kernels
 
     # ---- plumbing -------------------------------------------------------------------------------------------
     def stream(self):
@@ -404,37 +404,47 @@ class _BatchNorm(torch.autograd.Function):
 
 
 class _Attention(torch.autograd.Function):
+    """Exact-f32 MFMA kernels (attention.hip / train_attention.hip) or, in f16x3 mode, the split-f16 kernels for forward
+    AND backward: the two operand tensors R = split_rows(qkv) and Rt = transpose(qkv, split) are made once in the forward
+    and kept for the backward instead of qkv itself."""
+
     @staticmethod
     def forward(ctx, ops, qkv, batch):
         qkv = qkv.contiguous()
         M = qkv.shape[0]
         assert qkv.shape[1] == 1536 and M == batch.total_frames
         out, lse = ops.new(M, 512), ops.new(8, M)
-        ops.check(ops.lib.some_train_attention_fwd(ops.h, _p(qkv), _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M, _p(out), _p(lse),
-                                                   ops.stream()))
-        ctx.ops, ctx.batch = ops, batch
-        ctx.save_for_backward(qkv, out, lse)
+        ctx.ops, ctx.batch, ctx.prec = ops, batch, ops.attention_precision
+        if ctx.prec == 'f16x3':
+            R, Rt = ops.split_rows(qkv), ops.transpose(qkv, pad_to=64, split=True)
+            ops.check(ops.lib.some_train_attention_fwd_f16x3(ops.h, _p(R), _p(Rt), _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M,
+                                                             Rt.shape[1], _p(out), _p(lse), ops.stream()))
+            ctx.save_for_backward(R, Rt, out, lse)
+        else:
+            ops.check(ops.lib.some_train_attention_fwd(ops.h, _p(qkv), _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M, _p(out),
+                                                       _p(lse), ops.stream()))
+            ctx.save_for_backward(qkv, out, lse)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         ops, batch = ctx.ops, ctx.batch
-        qkv, out, lse = ctx.saved_tensors
-        M = qkv.shape[0]
-        dqkv, dsum = torch.empty_like(qkv), ops.new(8, M)
         dout = dout.contiguous()
-        if ops.attention_precision == 'f16x3':
+        M = dout.shape[0]
+        dqkv, dsum = ops.new(M, 1536), ops.new(8, M)
+        if ctx.prec == 'f16x3':
+            R, Rt, out, lse = ctx.saved_tensors
             # dO is carried as f16 hi + lo halves whose absolute floor is 2^-25: bring its largest element to ~2^10 with a
             # power-of-two factor computed on the device (exact; no host sync) and take the factor out of dqkv again
             scale = torch.exp2(torch.floor(10.0 - torch.log2(dout.abs().amax().clamp_min(1e-30))))
             dout = dout * scale
-            R, Rt = ops.split_rows(qkv), ops.transpose(qkv, pad_to=32, split=True)
-            D, Dt = ops.split_rows(dout), ops.transpose(dout, pad_to=32, split=True)
+            D, Dt = ops.split_rows(dout), ops.transpose(dout, pad_to=64, split=True)
             ops.check(ops.lib.some_train_attention_bwd_f16x3(ops.h, _p(R), _p(Rt), _p(D), _p(Dt), _p(out), _p(dout), _p(lse),
                                                              _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M, Rt.shape[1], _p(dqkv),
                                                              _p(dsum), ops.stream()))
             dqkv.mul_(1.0 / scale)
         else:
+            qkv, out, lse = ctx.saved_tensors
             ops.check(ops.lib.some_train_attention_bwd(ops.h, _p(qkv), _p(out), _p(dout), _p(lse), _p(batch.frame_offsets_dev), batch.B,
                                                        batch.max_frames, M, _p(dqkv), _p(dsum), ops.stream()))
         return None, dqkv, None
