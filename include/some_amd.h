@@ -198,10 +198,11 @@ size_t some_train_scratch_bytes(const SomeHandle* h, int64_t M, int32_t N);
 /* Weight-gradient GEMM  C[M, N] = A[M, K] W[N, K]^T  with a LONG contraction (K = all frames of the batch) and a small
  * output: split-f16 kernel with the contraction cut into slices across workgroups (blockIdx.z), partial planes in
  * partial_dev (some_train_gemm_splitk_bytes), summed in slice order - deterministic.  A_split / W_split: SPLIT32 rows
- * (some_op_split_rows), K % 32 == 0, lda % 32 == 0. */
+ * (some_op_split_rows), K % 32 == 0, lda % 32 == 0.  hi_only = 1: plain f16 operands (one product instead of three). */
 size_t some_train_gemm_splitk_bytes(const SomeHandle* h, int32_t M, int32_t N, int32_t K);
 int some_train_gemm_splitk(SomeHandle* h, const float* A_split_dev, int32_t lda, const float* W_split_dev, float* C_dev,
-                           int32_t M, int32_t N, int32_t K, void* partial_dev, size_t partial_bytes, void* stream);
+                           int32_t M, int32_t N, int32_t K, int32_t hi_only, void* partial_dev, size_t partial_bytes,
+                           void* stream);
 /* out[n, m] = in[m, n] for m < M, 0 for M <= m < ld_out (the zero padding makes ld_out a valid contraction length).
  * split_out = 1: rows are written in SPLIT32 format (ready as a split-f16 GEMM operand; ld_out % 32 == 0). */
 int some_train_transpose(SomeHandle* h, const float* in_dev, int32_t M, int32_t N, int32_t ld_in, float* out_dev,
@@ -283,7 +284,7 @@ int some_train_attention_bwd(SomeHandle* h, const float* qkv_dev, const float* o
  * [M, 512] and lse [8, M]; the same two split tensors feed some_train_attention_bwd_f16x3. */
 int some_train_attention_fwd_f16x3(SomeHandle* h, const float* qkv_split_dev, const float* qkv_t_split_dev,
                                    const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, int32_t M,
-                                   int32_t Mp, float* out_dev, float* lse_dev, void* stream);
+                                   int32_t Mp, int32_t hi_only, float* out_dev, float* lse_dev, void* stream);
 /* The same backward on the f16 matrix pipe with 3-term split operands (fp32-equivalent).  qkv_split / dout_split:
  * some_op_split_rows of qkv [M, 1536] / dout [M, 512]; qkv_t_split / dout_t_split: some_train_transpose(split_out = 1)
  * of the same tensors ([1536, Mp] / [512, Mp], Mp = M rounded up to 32).  out_dev / dout_dev (fp32) are only used for
@@ -291,8 +292,8 @@ int some_train_attention_fwd_f16x3(SomeHandle* h, const float* qkv_split_dev, co
 int some_train_attention_bwd_f16x3(SomeHandle* h, const float* qkv_split_dev, const float* qkv_t_split_dev,
                                    const float* dout_split_dev, const float* dout_t_split_dev, const float* out_dev,
                                    const float* dout_dev, const float* lse_dev, const int32_t* frame_offsets_dev,
-                                   int32_t B, int32_t max_frames, int32_t M, int32_t Mp, float* dqkv_dev,
-                                   float* dsum_scratch_dev, void* stream);
+                                   int32_t B, int32_t max_frames, int32_t M, int32_t Mp, int32_t hi_only,
+                                   float* dqkv_dev, float* dsum_scratch_dev, void* stream);
 
 /* ---- single-operator entry points (kernel-level parity tests and micro-benchmarks) ------------------ */
 
@@ -307,6 +308,7 @@ int some_train_attention_bwd_f16x3(SomeHandle* h, const float* qkv_split_dev, co
  * For the GLU epilogues N counts the packed rows (2 x output width) and C gets N/2 columns. */
 #define SOME_GEMM_SPLIT_IN 1    /* A and W are in SPLIT32 format -> 3-term split-f16 kernel (K % 32 == 0)            */
 #define SOME_GEMM_SPLIT_OUT 2   /* C written in SPLIT32 format (SOME_EPI_BIAS_SILU only)                            */
+#define SOME_GEMM_HI_ONLY 4      /* with SPLIT_IN: use the f16 hi halves only - plain f16 x f16 -> fp32 (mixed-precision training); EPI_NONE / EPI_BIAS */
 #define SOME_GEMM_TILE(t) (((t) & 7) << 8)   /* split kernel tile: 0 = 128x128, 1 = 256x128, 2 = 256x256, 3 = DMA ring 128x256, 4 = 64x128 */
 int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t lda, const float* W_dev,
                  const float* bias_dev, const float* res_dev, int32_t ldr, float* C_dev, int32_t ldc,

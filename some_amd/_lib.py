@@ -17,7 +17,7 @@ PRECISION_F32, PRECISION_F16X3 = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
 SAMPLE_F32, SAMPLE_PCM16 = 0, 1
 ELT_SILU_FWD, ELT_SILU_BWD, ELT_SIGMOID_FWD, ELT_SIGMOID_BWD, ELT_AXPY, ELT_DROPOUT = range(6)
-GEMM_SPLIT_IN, GEMM_SPLIT_OUT = 1, 2
+GEMM_SPLIT_IN, GEMM_SPLIT_OUT, GEMM_HI_ONLY = 1, 2, 4
 
 
 class SomeConfig(C.Structure):
@@ -63,7 +63,7 @@ SYMBOLS = {
     'some_pcm_gather': (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int64, _P, _P]),
     'some_train_scratch_bytes': (C.c_size_t, [_P, C.c_int64, C.c_int32]),
     'some_train_gemm_splitk_bytes': (C.c_size_t, [_P, C.c_int32, C.c_int32, C.c_int32]),
-    'some_train_gemm_splitk': (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
+    'some_train_gemm_splitk': (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
     'some_train_transpose': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
     'some_train_colsum': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P]),
     'some_train_layernorm_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
@@ -81,8 +81,8 @@ SYMBOLS = {
     'some_train_adamw': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, _P]),
     'some_train_attention_fwd': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     'some_train_attention_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
-    'some_train_attention_fwd_f16x3': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
-    'some_train_attention_bwd_f16x3': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    'some_train_attention_fwd_f16x3': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    'some_train_attention_bwd_f16x3': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     'some_op_gemm': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32,
                                C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, C.c_int32, _P]),
     'some_op_split_rows': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),

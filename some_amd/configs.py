@@ -27,6 +27,7 @@ _BASE = {
     'units_dim': 80,
     'midi_num_bins': 128,
     'seed': 114514,
+    'pl_trainer_precision': '32-true',      # configs/base.yaml:74
 }
 
 
@@ -48,6 +49,7 @@ def _extractor_args(lay):
 _CONFIGS = {
     'midi_conformer': dict(
         _BASE,
+        pl_trainer_precision='bf16',            # configs/midi_conformer.yaml:35 (training only)
         model_cls='modules.model.Gmidi_conform.midi_conforms',
         task_cls='training.MIDIExtractionTask',
         midi_prob_deviation=1.0,

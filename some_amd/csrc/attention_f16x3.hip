@@ -78,7 +78,7 @@ __device__ __forceinline__ void split8(const f32x16& p, int base, half8& h, half
 // TRAIN = true: the training forward (train_api: some_train_attention_fwd_f16x3) - Q / K rows come straight from
 // split_rows(qkv) (row stride 6144 B), V^T from transpose(qkv, split) (SPLIT32 over frames: 32-frame blocks [32 hi | 32 lo]),
 // the output is fp32 and the base-2 log-sum-exp is stored for the backward.
-template <bool TRAIN>
+template <bool TRAIN, int TERMS = 3>
 __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -167,10 +167,12 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
             const half8 kl0 = *reinterpret_cast<const half8*>(kp + off + 16);
             const half8 kh1 = *reinterpret_cast<const half8*>(kp + 32 * LDR + off);
             const half8 kl1 = *reinterpret_cast<const half8*>(kp + 32 * LDR + off + 16);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[s], s1, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[s], s1, 0, 0, 0);
+            if (TERMS == 3) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[s], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[s], s1, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[s], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[s], s1, 0, 0, 0);
+            }
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[s], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[s], s1, 0, 0, 0);
         }
@@ -279,10 +281,12 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
                 const half8 vl0 = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const half8 vh1 = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const half8 vl1 = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl0, ph, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl1, ph, o1, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, pl, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, pl, o1, 0, 0, 0);
+                if (TERMS == 3) {
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl0, ph, o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl1, ph, o1, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, pl, o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, pl, o1, 0, 0, 0);
+                }
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, ph, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, ph, o1, 0, 0, 0);
             }
@@ -376,12 +380,15 @@ hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int nqb = (a.max_frames + QB - 1) / QB;
     const int units = a.B * kHeads * a.groups;
     const int slots = (units + 7) / 8;
-    if (a.out32[0] != nullptr) hipLaunchKernelGGL(attention3_kernel<true>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    if (a.out32[0] != nullptr && a.hi_only) hipLaunchKernelGGL((attention3_kernel<true, 1>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    else if (a.out32[0] != nullptr) hipLaunchKernelGGL(attention3_kernel<true>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else hipLaunchKernelGGL(attention3_kernel<false>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     return hipGetLastError();
 }

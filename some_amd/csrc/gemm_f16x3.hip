@@ -168,7 +168,9 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const GemmGroup& g, 
     }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT>
+// TERMS = 3: x = hi + lo on both operands, three products (fp32-equivalent).  TERMS = 1: hi halves only - plain f16 operands
+// with fp32 accumulation on the same SPLIT32 layout (mixed-precision training, some_train_gemm_f16).
+template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs a) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -269,16 +271,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
                 bl[jn] = *reinterpret_cast<const half8*>(Ws + jn * 32 * LDT + 16 + s * 8);
             }
             // three sweeps over the accumulator tiles: consecutive MFMAs never share an accumulator
+            if (TERMS == 3) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jn], acc[i][jn], 0, 0, 0);
+                    for (int jn = 0; jn < TN; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jn], acc[i][jn], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jn], acc[i][jn], 0, 0, 0);
+                    for (int jn = 0; jn < TN; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jn], acc[i][jn], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -437,12 +441,12 @@ hipError_t launch_ring(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3>
 hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LDT * sizeof(float);
     static bool attr_set = false;
-    auto kern = &hgemm3_kernel<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT>;
+    auto kern = &hgemm3_kernel<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, TERMS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -481,6 +485,18 @@ static hipError_t launch_one(GemmEpi epi, const GemmArgs& a, bool out_split, int
         case EPI_GLU_RES: return launch_epi<EPI_GLU_RES, false>(a, tile, s);
         case EPI_QKV: return launch_epi<EPI_QKV, false>(a, tile, s);
     }
+    return hipErrorInvalidValue;
+}
+
+// Plain f16 operands (hi halves of the SPLIT32 layout), fp32 accumulate: the mixed-precision training GEMM.  256 x 256 tile,
+// EPI_NONE / EPI_BIAS, optional split-K.
+hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a_in, hipStream_t s) {
+    if (a_in.M <= 0) return hipSuccess;
+    if ((a_in.K & 31) || (a_in.lda & 31)) return hipErrorInvalidValue;
+    GemmArgs a = a_in;
+    a.m_begin = 0;
+    if (epi == EPI_NONE) return launch_cfg<4, 2, 2, 4, EPI_NONE, false, 1>(a, s);
+    if (epi == EPI_BIAS && a.k_slices <= 1) return launch_cfg<4, 2, 2, 4, EPI_BIAS, false, 1>(a, s);
     return hipErrorInvalidValue;
 }
 

@@ -56,6 +56,8 @@ hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 // 3-term split-f16 path (gemm_f16x3.hip): A and W in SPLIT32 format (split.h); out_split: C written in SPLIT32
 // (EPI_BIAS_SILU only); tile: 0 = 128x128, 1 = 256x128, 2 = 256x256.
 hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a, bool out_split, int tile, hipStream_t s);
+// hi halves only (plain f16 x f16 -> fp32): mixed-precision training; EPI_NONE (optional split-K) / EPI_BIAS, 256 x 256 tile
+hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 
 // ---- row ops --------------------------------------------------------------------------------------
 // y[g][m][:] = LayerNorm(x[g][m][:]) * gamma[g] + beta[g], eps 1e-5, rows of 512.
@@ -97,7 +99,7 @@ hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s);
 hipError_t launch_attention_dsum(const float* out, const float* dout, float* dsum, int M, hipStream_t s);
 // split-f16 backward (train_attention_f16x3.hip): R / D row-major SPLIT32, Rt / Dt SPLIT32 over frames ([C, Mp])
 hipError_t launch_attention_bwd_f16x3(const float* R, const float* Rt, const float* D, const float* Dt, const float* lse, const float* dsum,
-                                      const int32_t* frame_offsets, int B, int max_frames, int M, int Mp, float* dqkv, hipStream_t s);
+                                      const int32_t* frame_offsets, int B, int max_frames, int M, int Mp, float* dqkv, int hi_only, hipStream_t s);
 
 // split-f16 attention (attention_f16x3.hip): operands as written by the EPI_QKV GEMM epilogue; out is SPLIT32.
 struct Attn3Args {
@@ -111,6 +113,7 @@ struct Attn3Args {
     // transpose(qkv, split) ([.., ldv] SPLIT32 over frames, ldv % 64 == 0); fp32 output + base-2 log-sum-exp [8, M]
     float* out32[kStreams];
     float* lse[kStreams];
+    int hi_only;                   // training forward only: plain f16 operands (one product instead of three)
 };
 hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s);
 inline int vt_ld(int64_t M) { return (int)((M + 255) / 256 * 256); }

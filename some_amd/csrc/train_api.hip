@@ -51,7 +51,8 @@ size_t some_train_gemm_splitk_bytes(const SomeHandle* h, int32_t M, int32_t N, i
 }
 
 int some_train_gemm_splitk(SomeHandle* h, const float* A_split_dev, int32_t lda, const float* W_split_dev, float* C_dev,
-                           int32_t M, int32_t N, int32_t K, void* partial_dev, size_t partial_bytes, void* stream) {
+                           int32_t M, int32_t N, int32_t K, int32_t hi_only, void* partial_dev, size_t partial_bytes,
+                           void* stream) {
     if (!h) return SOME_EINVAL;
     T_CHECK(h, M > 0 && N > 0 && K > 0 && (K % 32) == 0 && (lda % 32) == 0 && lda >= K && (N % 4) == 0, "some_train_gemm_splitk: bad shape (K, lda % 32, N % 4)");
     T_CHECK(h, A_split_dev && W_split_dev && C_dev && partial_dev, "some_train_gemm_splitk: null pointer");
@@ -61,7 +62,8 @@ int some_train_gemm_splitk(SomeHandle* h, const float* A_split_dev, int32_t lda,
     a.g[0] = GemmGroup{A_split_dev, W_split_dev, nullptr, nullptr, slices > 1 ? static_cast<float*>(partial_dev) : C_dev, nullptr, N, 0};
     a.groups = 1; a.M = M; a.K = K; a.lda = lda; a.ldc = N; a.ldr = N; a.alpha = 1.f;
     a.k_slices = slices; a.slice_stride = (size_t)M * N;
-    T_TRY(h, launch_gemm_f16x3(EPI_NONE, a, false, 2, st(stream)));
+    if (hi_only) T_TRY(h, launch_gemm_f16x1(EPI_NONE, a, st(stream)));
+    else T_TRY(h, launch_gemm_f16x3(EPI_NONE, a, false, 2, st(stream)));
     if (slices > 1) T_TRY(h, launch_reduce_slices(static_cast<const float*>(partial_dev), slices, (size_t)M * N, C_dev, st(stream)));
     return SOME_OK;
 }
@@ -254,7 +256,7 @@ int some_train_attention_bwd(SomeHandle* h, const float* qkv_dev, const float* o
 
 int some_train_attention_fwd_f16x3(SomeHandle* h, const float* qkv_split_dev, const float* qkv_t_split_dev,
                                    const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, int32_t M,
-                                   int32_t Mp, float* out_dev, float* lse_dev, void* stream) {
+                                   int32_t Mp, int32_t hi_only, float* out_dev, float* lse_dev, void* stream) {
     if (!h) return SOME_EINVAL;
     T_CHECK(h, B >= 0 && max_frames >= 0 && M >= 0, "some_train_attention_fwd_f16x3: negative size");
     if (B == 0 || M == 0) return SOME_OK;
@@ -263,7 +265,7 @@ int some_train_attention_fwd_f16x3(SomeHandle* h, const float* qkv_split_dev, co
     Attn3Args a{};
     a.q[0] = qkv_split_dev; a.k[0] = qkv_split_dev + kDim;
     a.vt[0] = qkv_t_split_dev + (size_t)2 * kDim * Mp;            // V rows of the frame-major split tensor
-    a.out32[0] = out_dev; a.lse[0] = lse_dev;
+    a.out32[0] = out_dev; a.lse[0] = lse_dev; a.hi_only = hi_only ? 1 : 0;
     a.frame_offsets = frame_offsets_dev; a.groups = 1; a.B = B; a.max_frames = max_frames; a.M = M; a.ldv = Mp;
     T_TRY(h, launch_attention_f16x3(a, st(stream)));
     return SOME_OK;
@@ -272,8 +274,8 @@ int some_train_attention_fwd_f16x3(SomeHandle* h, const float* qkv_split_dev, co
 int some_train_attention_bwd_f16x3(SomeHandle* h, const float* qkv_split_dev, const float* qkv_t_split_dev,
                                    const float* dout_split_dev, const float* dout_t_split_dev, const float* out_dev,
                                    const float* dout_dev, const float* lse_dev, const int32_t* frame_offsets_dev,
-                                   int32_t B, int32_t max_frames, int32_t M, int32_t Mp, float* dqkv_dev,
-                                   float* dsum_scratch_dev, void* stream) {
+                                   int32_t B, int32_t max_frames, int32_t M, int32_t Mp, int32_t hi_only,
+                                   float* dqkv_dev, float* dsum_scratch_dev, void* stream) {
     if (!h) return SOME_EINVAL;
     T_CHECK(h, B >= 0 && max_frames >= 0 && M >= 0, "some_train_attention_bwd_f16x3: negative size");
     if (B == 0 || M == 0) return SOME_OK;
@@ -282,7 +284,7 @@ int some_train_attention_bwd_f16x3(SomeHandle* h, const float* qkv_split_dev, co
                    dqkv_dev && dsum_scratch_dev, "some_train_attention_bwd_f16x3: null pointer");
     T_TRY(h, launch_attention_dsum(out_dev, dout_dev, dsum_scratch_dev, M, st(stream)));
     T_TRY(h, launch_attention_bwd_f16x3(qkv_split_dev, qkv_t_split_dev, dout_split_dev, dout_t_split_dev, lse_dev, dsum_scratch_dev,
-                                        frame_offsets_dev, B, max_frames, M, Mp, dqkv_dev, st(stream)));
+                                        frame_offsets_dev, B, max_frames, M, Mp, dqkv_dev, hi_only ? 1 : 0, st(stream)));
     return SOME_OK;
 }
 

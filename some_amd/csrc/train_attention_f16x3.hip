@@ -42,10 +42,14 @@ __device__ __forceinline__ void split8(const f32x16& p, int base, half8& h, half
     }
 }
 
-// three-term product accumulate: acc += a * b with a = ah + al, b = bh + bl
+// product accumulate: acc += a * b with a = ah + al, b = bh + bl.  TERMS = 3: ah bh + ah bl + al bh (fp32-equivalent);
+// TERMS = 1: ah bh only (plain f16 operands: the mixed-precision training mode)
+template <int TERMS>
 __device__ __forceinline__ void mma3(f32x16& acc, const half8& ah, const half8& al, const half8& bh, const half8& bl) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    if (TERMS == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    }
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
 }
 
@@ -82,6 +86,7 @@ struct Bwd3Args {
 constexpr int DKV_STAGE = 2 * FT * LDR + 2 * kHeadDim * LDT + 2 * FT;          // Qr, dOr, Qt, dOt, lse2[32], D[32]
 constexpr size_t DKV_LDS = 2 * DKV_STAGE * sizeof(float);
 
+template <int TERMS>
 __global__ __launch_bounds__(256, 2) void attn3_bwd_dkv_kernel(Bwd3Args a, int nkb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -180,8 +185,8 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dkv_kernel(Bwd3Args a, int n
             half8 ah, al, bh, bl;
             frag_row(Qr + l31 * LDR, st, kg, ah, al);
             frag_row(Dr + l31 * LDR, st, kg, bh, bl);
-            mma3(s, ah, al, kh[st], kl[st]);
-            mma3(dp, bh, bl, vh[st], vl[st]);
+            mma3<TERMS>(s, ah, al, kh[st], kl[st]);
+            mma3<TERMS>(dp, bh, bl, vh[st], vl[st]);
         }
         // P = exp2(S c - lse2[q]), dS = P (dP - D[q]); register r <-> frame krow(r, kg) of the tile
 #pragma unroll
@@ -206,13 +211,13 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dkv_kernel(Bwd3Args a, int n
             split8(dp, 8 * sp, gh, gl);
             half8 ah, al;
             frag_frames(Dt + l31 * LDT, sp, kg, ah, al);
-            mma3(dv0, ah, al, ph, pl);
+            mma3<TERMS>(dv0, ah, al, ph, pl);
             frag_frames(Dt + (32 + l31) * LDT, sp, kg, ah, al);
-            mma3(dv1, ah, al, ph, pl);
+            mma3<TERMS>(dv1, ah, al, ph, pl);
             frag_frames(Qt + l31 * LDT, sp, kg, ah, al);
-            mma3(dk0, ah, al, gh, gl);
+            mma3<TERMS>(dk0, ah, al, gh, gl);
             frag_frames(Qt + (32 + l31) * LDT, sp, kg, ah, al);
-            mma3(dk1, ah, al, gh, gl);
+            mma3<TERMS>(dk1, ah, al, gh, gl);
         }
         if (i + 1 < nt) lstore(buf ^ 1);
         __syncthreads();
@@ -242,6 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dkv_kernel(Bwd3Args a, int n
 constexpr int DQ_STAGE = 2 * FT * LDR + kHeadDim * LDT;                         // Kr, Vr, Kt
 constexpr size_t DQ_LDS = 2 * DQ_STAGE * sizeof(float) > 4 * 32 * LDR * sizeof(float) ? 2 * DQ_STAGE * sizeof(float) : 4 * 32 * LDR * sizeof(float);
 
+template <int TERMS>
 __global__ __launch_bounds__(256, 2) void attn3_bwd_dq_kernel(Bwd3Args a, int nqb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -327,8 +333,8 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dq_kernel(Bwd3Args a, int nq
             half8 ah, al, bh, bl;
             frag_row(Kr + l31 * LDR, st, kg, ah, al);
             frag_row(Vr + l31 * LDR, st, kg, bh, bl);
-            mma3(s, ah, al, qh[st], ql[st]);              // S^T[key][q]
-            mma3(dp, bh, bl, oh[st], ol[st]);             // dP^T[key][q]
+            mma3<TERMS>(s, ah, al, qh[st], ql[st]);              // S^T[key][q]
+            mma3<TERMS>(dp, bh, bl, oh[st], ol[st]);             // dP^T[key][q]
         }
         const int fr0 = (g0 + i) * FT;
 #pragma unroll
@@ -342,9 +348,9 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dq_kernel(Bwd3Args a, int nq
             half8 gh, gl, ah, al;
             split8(dp, 8 * sp, gh, gl);
             frag_frames(Kt + l31 * LDT, sp, kg, ah, al);
-            mma3(o0, ah, al, gh, gl);                     // dQ^T[d][q] += K^T dS^T
+            mma3<TERMS>(o0, ah, al, gh, gl);                     // dQ^T[d][q] += K^T dS^T
             frag_frames(Kt + (32 + l31) * LDT, sp, kg, ah, al);
-            mma3(o1, ah, al, gh, gl);
+            mma3<TERMS>(o1, ah, al, gh, gl);
         }
         if (i + 1 < nt) lstore(buf ^ 1);
         __syncthreads();
@@ -370,21 +376,26 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dq_kernel(Bwd3Args a, int nq
 
 }  // namespace
 
-hipError_t launch_attention_bwd_f16x3(const float* R, const float* Rt, const float* D, const float* Dt, const float* lse, const float* dsum,
-                                      const int32_t* frame_offsets, int B, int max_frames, int M, int Mp, float* dqkv, hipStream_t s) {
-    if (B <= 0 || max_frames <= 0 || M <= 0) return hipSuccess;
+template <int TERMS>
+static hipError_t launch_bwd(const Bwd3Args& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKV_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_bwd_dkv_kernel<TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKV_LDS);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DQ_LDS);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_bwd_dq_kernel<TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DQ_LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    Bwd3Args a{R, Rt, D, Dt, lse, dsum, dqkv, frame_offsets, B, max_frames, M, Mp};
-    const int units = B * kHeads, slots = (units + 7) / 8;
-    const int nb = (max_frames + 127) / 128;
-    hipLaunchKernelGGL(attn3_bwd_dkv_kernel, dim3((unsigned)(slots * nb * 8)), dim3(256), DKV_LDS, s, a, nb);
-    hipLaunchKernelGGL(attn3_bwd_dq_kernel, dim3((unsigned)(slots * nb * 8)), dim3(256), DQ_LDS, s, a, nb);
+    const int units = a.B * kHeads, slots = (units + 7) / 8;
+    const int nb = (a.max_frames + 127) / 128;
+    hipLaunchKernelGGL(attn3_bwd_dkv_kernel<TERMS>, dim3((unsigned)(slots * nb * 8)), dim3(256), DKV_LDS, s, a, nb);
+    hipLaunchKernelGGL(attn3_bwd_dq_kernel<TERMS>, dim3((unsigned)(slots * nb * 8)), dim3(256), DQ_LDS, s, a, nb);
     return hipGetLastError();
+}
+
+hipError_t launch_attention_bwd_f16x3(const float* R, const float* Rt, const float* D, const float* Dt, const float* lse, const float* dsum,
+                                      const int32_t* frame_offsets, int B, int max_frames, int M, int Mp, float* dqkv, int hi_only, hipStream_t s) {
+    if (B <= 0 || max_frames <= 0 || M <= 0) return hipSuccess;
+    Bwd3Args a{R, Rt, D, Dt, lse, dsum, dqkv, frame_offsets, B, max_frames, M, Mp};
+    return hi_only ? launch_bwd<1>(a, s) : launch_bwd<3>(a, s);
 }

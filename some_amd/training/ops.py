@@ -29,6 +29,15 @@ class TrainOps:
         self._partial: Optional[torch.Tensor] = None
         self.gemm_precision = 'f16x3' if engine.c_config.precision == _lib.PRECISION_F16X3 else 'f32'
         self.attention_precision = self.gemm_precision      # forward + backward: split-f16 or exact-f32 MFMA kernels
+        self._hi = 0                                        # _lib.GEMM_HI_ONLY: mixed precision (set_mixed_precision)
+
+    def set_mixed_precision(self, on: bool):
+        """Mixed-precision training (the reference's pl_trainer_precision '16-mixed' / 'bf16' analogue): the matrix products
+        read only the f16 hi halves of the split operands - plain f16 x f16 with fp32 accumulation, one MFMA product instead
+        of three - while parameters, activations, reductions, softmax statistics and the optimiser stay fp32."""
+        if on and self.gemm_precision != 'f16x3':
+            raise ValueError('mixed precision runs on the split-f16 kernels: use some_amd_precision f16x3')
+        self._hi = _lib.GEMM_HI_ONLY if on else 0
 
     # ---- plumbing -------------------------------------------------------------------------------------------
     def stream(self):
@@ -72,7 +81,7 @@ class TrainOps:
             a3 = self.split_rows(a)
             w3 = self.split_rows(w)
             self.check(self.lib.some_op_gemm(self.h, epi, _p(a3), K, _p(w3), _p(bias), None, N, _p(out), N, M, N, K, 1.0, 0, None,
-                                             _lib.GEMM_SPLIT_IN | (2 << 8), self.stream()))
+                                             _lib.GEMM_SPLIT_IN | self._hi | (2 << 8), self.stream()))
             return out
         if K % 4:
             pad = 4 - K % 4
@@ -92,7 +101,7 @@ class TrainOps:
             a3 = self.split_rows(dy)
             out = self.new(M, K)
             self.check(self.lib.some_op_gemm(self.h, _lib.EPI_NONE, _p(a3), N, _p(wt3), None, None, K, _p(out), K, M, K, N, 1.0, 0, None,
-                                             _lib.GEMM_SPLIT_IN | (2 << 8), self.stream()))
+                                             _lib.GEMM_SPLIT_IN | self._hi | (2 << 8), self.stream()))
             return out
         return self.gemm(dy, self.transpose(w, pad_to=1))
 
@@ -122,7 +131,7 @@ class TrainOps:
             need = int(self.lib.some_train_gemm_splitk_bytes(self.h, N, Kx, Mp))
             if self._partial is None or self._partial.numel() < need:
                 self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
-            self.check(self.lib.some_train_gemm_splitk(self.h, _p(dyt), Mp, _p(xt), _p(out), N, Kx, Mp, _p(self._partial), self._partial.numel(),
+            self.check(self.lib.some_train_gemm_splitk(self.h, _p(dyt), Mp, _p(xt), _p(out), N, Kx, Mp, 1 if self._hi else 0, _p(self._partial), self._partial.numel(),
                                                        self.stream()))
         else:
             self.check(self.lib.some_op_gemm(self.h, _lib.EPI_NONE, _p(dyt), Mp, _p(xt), None, None, Kx, _p(out), Kx, N, Kx, Mp, 1.0, 0, None, 0,
@@ -418,7 +427,7 @@ class _Attention(torch.autograd.Function):
         if ctx.prec == 'f16x3':
             R, Rt = ops.split_rows(qkv), ops.transpose(qkv, pad_to=64, split=True)
             ops.check(ops.lib.some_train_attention_fwd_f16x3(ops.h, _p(R), _p(Rt), _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M,
-                                                             Rt.shape[1], _p(out), _p(lse), ops.stream()))
+                                                             Rt.shape[1], 1 if ops._hi else 0, _p(out), _p(lse), ops.stream()))
             ctx.save_for_backward(R, Rt, out, lse)
         else:
             ops.check(ops.lib.some_train_attention_fwd(ops.h, _p(qkv), _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M, _p(out),
@@ -440,8 +449,8 @@ class _Attention(torch.autograd.Function):
             dout = dout * scale
             D, Dt = ops.split_rows(dout), ops.transpose(dout, pad_to=64, split=True)
             ops.check(ops.lib.some_train_attention_bwd_f16x3(ops.h, _p(R), _p(Rt), _p(D), _p(Dt), _p(out), _p(dout), _p(lse),
-                                                             _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M, Rt.shape[1], _p(dqkv),
-                                                             _p(dsum), ops.stream()))
+                                                             _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M, Rt.shape[1], 1 if ops._hi else 0,
+                                                             _p(dqkv), _p(dsum), ops.stream()))
             dqkv.mul_(1.0 / scale)
         else:
             qkv, out, lse = ctx.saved_tensors

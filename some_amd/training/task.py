@@ -27,6 +27,11 @@ class MIDIExtractionTrainer:
         self.config = config
         self.engine = Engine(config, device=device)
         self.ops = TrainOps(self.engine)
+        # pl_trainer_precision (configs/base.yaml:74 '32-true'; configs/midi_conformer.yaml:35 'bf16'): any 16-bit setting
+        # selects mixed precision - f16 operands on the matrix pipe, fp32 everything else, dynamic loss scaling
+        prec = str(config.get('pl_trainer_precision', '32-true'))
+        self.mixed = bool(config.get('some_amd_mixed_precision', '16' in prec))
+        self.ops.set_mixed_precision(self.mixed)
         self.model = TrainableMidiConforms(config, self.ops, seed=seed)
         oa = config.get('optimizer_args', {})
         self.base_lr = oa.get('lr', 1e-4)

@@ -151,3 +151,28 @@ def test_validation_step_eval_mode_and_metric():
         logits, _ = tr.model(batch['units'].reshape(B * T, -1), ClipBatch([T] * B, 'cuda'), mask=batch['unit2note'] > 0)
         train_mode_loss = tr.ops.bce_with_logits(logits, batch['probs'].reshape(B * T, -1))
     assert abs(train_mode_loss.item() - res['midi_loss'].item()) > 1e-6
+
+
+def test_mixed_precision_step_close_to_reference(golden_dir):
+    """pl_trainer_precision 'bf16' / '16-mixed' -> f16 operands on the matrix pipe (one product), fp32 accumulation and
+    fp32 everything else: losses within 2e-3, gradients within 2e-2 of each tensor's norm (f16 has 3 more mantissa bits
+    than the reference's bf16 autocast)."""
+    from some_amd.training.task import MIDIExtractionTrainer
+    g = np.load(golden_dir / 'train_step.npz')
+    tr = MIDIExtractionTrainer(dict(_cfg(), pl_trainer_precision='bf16'), device='cuda')
+    assert tr.mixed and tr.loss_scale > 1.0
+    tr.model.params.load_state_dict(synth.synth_state_dict(_cfg(), 31))
+    out = tr.training_step(_sample())
+    assert not out['skipped']
+    assert abs(out['bound_loss'].item() - float(g['bound_loss'])) < 2e-3 * abs(float(g['bound_loss']))
+    assert abs(out['midi_loss'].item() - float(g['midi_loss'])) < 2e-3 * abs(float(g['midi_loss']))
+    worst = 0.0
+    for name in g['names']:
+        key = str(name)
+        ref = g['grad.' + key]
+        if ref[10] < 1e-6:
+            continue
+        mine = tr.model.params.views[key].grad.detach().double().cpu().numpy().reshape(-1) / out['grad_scale']
+        worst = max(worst, abs(np.sqrt((mine * mine).sum()) - ref[10]) / ref[10], np.abs(mine[:8] - ref[:min(8, mine.size)]).max() / ref[10])
+    print('mixed precision: worst gradient error relative to the tensor norm:', worst)
+    assert worst < 2e-2
