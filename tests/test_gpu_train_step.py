@@ -176,3 +176,54 @@ def test_mixed_precision_step_close_to_reference(golden_dir):
         worst = max(worst, abs(np.sqrt((mine * mine).sum()) - ref[10]) / ref[10], np.abs(mine[:8] - ref[:min(8, mine.size)]).max() / ref[10])
     print('mixed precision: worst gradient error relative to the tensor norm:', worst)
     assert worst < 2e-2
+
+
+_DDP_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ['REPO'])
+import torch.distributed as dist
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + os.environ['PORT'], rank=int(os.environ['RANK']), world_size=2)
+rank = dist.get_rank()
+from some_amd import synth
+from some_amd.configs import get_config
+from some_amd.training.task import MIDIExtractionTrainer
+cfg = get_config('two_head_model', lay=1)
+tr = MIDIExtractionTrainer(cfg, device='cuda:0', seed=100 + rank)        # different initial weights: rank 0's must win
+assert tr.world == 2
+sample = {k: torch.from_numpy(v).cuda() for k, v in synth.synth_train_batch(seed=21 + rank).items()}   # different data per rank
+for _ in range(2):
+    out = tr.training_step(sample)
+    assert not out['skipped']
+flat = tr.model.params.flat
+both = [torch.empty_like(flat), torch.empty_like(flat)]
+dist.all_gather(both, flat)
+assert torch.equal(both[0], both[1]), 'replicas diverged'
+torch.save({'flat': flat.cpu(), 'loss': float(out['total_loss'])}, os.environ['OUT'] + f'.{rank}')
+dist.barrier()
+dist.destroy_process_group()
+print('ok', rank)
+'''
+
+
+def test_two_rank_data_parallel_training_keeps_replicas_identical(tmp_path):
+    """Two trainer processes (gloo moving the CUDA tensors; both on this box's one GPU) with different initial weights and
+    different batches: rank 0's parameters are broadcast at start, the flat gradient is summed with one all-reduce and
+    averaged inside AdamW - after two steps the replicas hold bit-identical parameters."""
+    import os
+    import pathlib
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    script = tmp_path / 'ddp_worker.py'
+    script.write_text(_DDP_WORKER)
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = dict(os.environ, PORT=str(port), REPO=str(root), OUT=str(tmp_path / 'res'))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[-2000:] for o in outs]
+    a, b = torch.load(tmp_path / 'res.0'), torch.load(tmp_path / 'res.1')
+    assert torch.equal(a['flat'], b['flat']) and a['loss'] != b['loss']
