@@ -668,7 +668,7 @@ int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t ld
         if ((K & 31) || (lda & 31)) return fail(h, SOME_EINVAL, "some_op_gemm: SPLIT32 operands need K % 32 == 0 and lda % 32 == 0");
         if (flags & SOME_GEMM_HI_ONLY) {
             if (epilogue != EPI_NONE && epilogue != EPI_BIAS) return fail(h, SOME_EINVAL, "some_op_gemm: HI_ONLY supports EPI_NONE / EPI_BIAS");
-            HIP_TRY(h, launch_gemm_f16x1(static_cast<GemmEpi>(epilogue), a, s));
+            HIP_TRY(h, launch_gemm_f16x1(static_cast<GemmEpi>(epilogue), a, (flags >> 8) & 7, s));
         } else {
             HIP_TRY(h, launch_gemm_f16x3(static_cast<GemmEpi>(epilogue), a, (flags & SOME_GEMM_SPLIT_OUT) != 0, (flags >> 8) & 7, s));
         }

@@ -490,13 +490,15 @@ static hipError_t launch_one(GemmEpi epi, const GemmArgs& a, bool out_split, int
 
 // Plain f16 operands (hi halves of the SPLIT32 layout), fp32 accumulate: the mixed-precision training GEMM.  256 x 256 tile,
 // EPI_NONE / EPI_BIAS, optional split-K.
-hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a_in, hipStream_t s) {
+hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a_in, int tile, hipStream_t s) {
     if (a_in.M <= 0) return hipSuccess;
     if ((a_in.K & 31) || (a_in.lda & 31)) return hipErrorInvalidValue;
     GemmArgs a = a_in;
     a.m_begin = 0;
-    if (epi == EPI_NONE) return launch_cfg<4, 2, 2, 4, EPI_NONE, false, 1>(a, s);
-    if (epi == EPI_BIAS && a.k_slices <= 1) return launch_cfg<4, 2, 2, 4, EPI_BIAS, false, 1>(a, s);
+    const bool small = tile == 0;                     // 128 x 128 (two workgroups per CU) for small grids, else 256 x 256
+    if (epi == EPI_NONE) return small ? launch_cfg<2, 2, 2, 2, EPI_NONE, false, 1>(a, s) : launch_cfg<4, 2, 2, 4, EPI_NONE, false, 1>(a, s);
+    if (epi == EPI_BIAS && a.k_slices <= 1)
+        return small ? launch_cfg<2, 2, 2, 2, EPI_BIAS, false, 1>(a, s) : launch_cfg<4, 2, 2, 4, EPI_BIAS, false, 1>(a, s);
     return hipErrorInvalidValue;
 }
 

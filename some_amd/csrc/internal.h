@@ -57,7 +57,7 @@ hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 // (EPI_BIAS_SILU only); tile: 0 = 128x128, 1 = 256x128, 2 = 256x256.
 hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a, bool out_split, int tile, hipStream_t s);
 // hi halves only (plain f16 x f16 -> fp32): mixed-precision training; EPI_NONE (optional split-K) / EPI_BIAS, 256 x 256 tile
-hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a, hipStream_t s);
+hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a, int tile, hipStream_t s);
 
 // ---- row ops --------------------------------------------------------------------------------------
 // y[g][m][:] = LayerNorm(x[g][m][:]) * gamma[g] + beta[g], eps 1e-5, rows of 512.

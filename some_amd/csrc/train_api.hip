@@ -62,7 +62,7 @@ int some_train_gemm_splitk(SomeHandle* h, const float* A_split_dev, int32_t lda,
     a.g[0] = GemmGroup{A_split_dev, W_split_dev, nullptr, nullptr, slices > 1 ? static_cast<float*>(partial_dev) : C_dev, nullptr, N, 0};
     a.groups = 1; a.M = M; a.K = K; a.lda = lda; a.ldc = N; a.ldr = N; a.alpha = 1.f;
     a.k_slices = slices; a.slice_stride = (size_t)M * N;
-    if (hi_only) T_TRY(h, launch_gemm_f16x1(EPI_NONE, a, st(stream)));
+    if (hi_only) T_TRY(h, launch_gemm_f16x1(EPI_NONE, a, 2, st(stream)));
     else T_TRY(h, launch_gemm_f16x3(EPI_NONE, a, false, 2, st(stream)));
     if (slices > 1) T_TRY(h, launch_reduce_slices(static_cast<const float*>(partial_dev), slices, (size_t)M * N, C_dev, st(stream)));
     return SOME_OK;

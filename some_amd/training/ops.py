@@ -62,6 +62,12 @@ class TrainOps:
         self.check(self.lib.some_op_split_rows(self.h, _p(x), _p(out), x.shape[0], x.shape[1], self.stream()))
         return out
 
+    @staticmethod
+    def _tile(M: int, N: int) -> int:
+        """f16x3 GEMM tile selector (SOME_GEMM_TILE)."""
+        # measured at 8 x 2584 frames: 128 x 128 tiles for the N = 512 GEMMs change nothing (92.3 vs 90.9 ms/step) - keep 256 x 256
+        return 2
+
     def _use_split(self, M: int, N: int, K: int) -> bool:
         return self.gemm_precision == 'f16x3' and K % 32 == 0 and N >= 64 and M >= 64
 
@@ -81,7 +87,7 @@ class TrainOps:
             a3 = self.split_rows(a)
             w3 = self.split_rows(w)
             self.check(self.lib.some_op_gemm(self.h, epi, _p(a3), K, _p(w3), _p(bias), None, N, _p(out), N, M, N, K, 1.0, 0, None,
-                                             _lib.GEMM_SPLIT_IN | self._hi | (2 << 8), self.stream()))
+                                             _lib.GEMM_SPLIT_IN | self._hi | (self._tile(M, N) << 8), self.stream()))
             return out
         if K % 4:
             pad = 4 - K % 4
@@ -101,7 +107,7 @@ class TrainOps:
             a3 = self.split_rows(dy)
             out = self.new(M, K)
             self.check(self.lib.some_op_gemm(self.h, _lib.EPI_NONE, _p(a3), N, _p(wt3), None, None, K, _p(out), K, M, K, N, 1.0, 0, None,
-                                             _lib.GEMM_SPLIT_IN | self._hi | (2 << 8), self.stream()))
+                                             _lib.GEMM_SPLIT_IN | self._hi | (self._tile(M, K) << 8), self.stream()))
             return out
         return self.gemm(dy, self.transpose(w, pad_to=1))
 
