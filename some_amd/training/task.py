@@ -120,6 +120,34 @@ class MIDIExtractionTrainer:
         out['grad_norm'] = grad_norm
         return out
 
+    # ---- checkpoint / resume (train.py:98-108: Lightning resumes from the latest checkpoint of the work dir) ------------
+    def checkpoint(self) -> Dict[str, object]:
+        """Lightning-layout checkpoint: ``state_dict`` with the ``model.`` prefix (what the inference classes read) plus
+        everything needed to continue bit-identically: step, flat AdamW moments, loss-scale state, dropout call counter."""
+        P = self.model.params
+        return {
+            'state_dict': {'model.' + k: v.cpu() for k, v in P.state_dict().items()},
+            'global_step': self.global_step,
+            'some_amd_trainer': {
+                'exp_avg': self.exp_avg.cpu(), 'exp_avg_sq': self.exp_avg_sq.cpu(), 'loss_scale': self.loss_scale,
+                'clean_steps': self._clean_steps, 'dropout_calls': self.model._calls, 'dropout_seed': self.model._seed,
+                'param_names': list(P.param_names),
+            },
+        }
+
+    def load_checkpoint(self, ckpt: Dict[str, object]):
+        P = self.model.params
+        P.load_state_dict({(k[6:] if k.startswith('model.') else k): v for k, v in ckpt['state_dict'].items()})
+        self.global_step = int(ckpt.get('global_step', 0))
+        st = ckpt.get('some_amd_trainer')
+        if st is not None:                      # a reference / inference-only checkpoint has no optimiser state: fresh moments
+            if list(st['param_names']) != list(P.param_names):
+                raise RuntimeError('checkpoint optimiser state does not match this model')
+            self.exp_avg.copy_(st['exp_avg'])
+            self.exp_avg_sq.copy_(st['exp_avg_sq'])
+            self.loss_scale, self._clean_steps = float(st['loss_scale']), int(st['clean_steps'])
+            self.model._calls, self.model._seed = int(st['dropout_calls']), int(st['dropout_seed'])
+
     # ---- me_task.py:113-153 -----------------------------------------------------------------------------------
     @torch.no_grad()
     def sync_eval_engine(self):

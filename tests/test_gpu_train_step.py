@@ -227,3 +227,26 @@ def test_two_rank_data_parallel_training_keeps_replicas_identical(tmp_path):
     assert all(p.returncode == 0 for p in procs), [o[-2000:] for o in outs]
     a, b = torch.load(tmp_path / 'res.0'), torch.load(tmp_path / 'res.1')
     assert torch.equal(a['flat'], b['flat']) and a['loss'] != b['loss']
+
+
+def test_checkpoint_resume_is_bit_identical():
+    """3 steps + checkpoint + 3 steps in a fresh trainer == 6 steps straight (deterministic kernels; the checkpoint carries
+    the AdamW moments, the loss-scale state and the dropout call counter) - dropout ON."""
+    from some_amd.training.task import MIDIExtractionTrainer
+    cfg = get_config('two_head_model', lay=1)
+    sample = _sample()
+    a = MIDIExtractionTrainer(cfg, device='cuda', seed=11)
+    for _ in range(6):
+        a.training_step(sample)
+    b = MIDIExtractionTrainer(cfg, device='cuda', seed=11)
+    for _ in range(3):
+        b.training_step(sample)
+    ck = b.checkpoint()
+    assert all(k.startswith('model.model.') for k in ck['state_dict']) and ck['global_step'] == 3
+    c = MIDIExtractionTrainer(cfg, device='cuda', seed=999)           # different init: everything must come from the checkpoint
+    c.load_checkpoint(ck)
+    for _ in range(3):
+        c.training_step(sample)
+    assert c.global_step == a.global_step == 6
+    assert torch.equal(c.model.params.flat, a.model.params.flat)
+    assert torch.equal(c.exp_avg_sq, a.exp_avg_sq)

@@ -68,8 +68,14 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
         print(f'validation @ {step}: ' + ', '.join(f'{k}={float(v):.5f}' for k, v in res.items() if k.endswith('loss')) + f', midi_acc={acc:.4f}')
 
     total = max_updates if max_updates is not None else cfg.get('max_updates', 100000)
+    # train.py:98-108 of the reference: continue from the newest checkpoint of the experiment directory, if any
+    existing = sorted(work.glob('model_ckpt_steps_*.ckpt'), key=lambda p: int(p.stem.rsplit('_', 1)[1]))
+    if existing:
+        trainer.load_checkpoint(torch.load(existing[-1], map_location='cpu'))
+        if rank == 0:
+            print(f'resumed from {existing[-1].name} at step {trainer.global_step}')
     keep, interval = cfg.get('num_ckpt_keep', 5), cfg.get('val_check_interval', 1000)
-    saved, epoch = [], 0
+    saved, epoch = list(existing), trainer.global_step // max(1, len(data.batches(lengths, cfg.get('max_batch_frames', 80000), cfg.get('max_batch_size', 8), rank, world)))
     while trainer.global_step < total:
         plan = data.batches(lengths, cfg.get('max_batch_frames', 80000), cfg.get('max_batch_size', 8), rank, world, seed=epoch)
         epoch += 1
@@ -81,7 +87,7 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
                       f', lr={out["lr"]:.3e}, loss_scale={trainer.loss_scale:g}')
             if rank == 0 and (step % interval == 0 or step == total) and not out['skipped']:
                 path = work / f'model_ckpt_steps_{step}.ckpt'
-                torch.save({'state_dict': {'model.' + k: v.cpu() for k, v in trainer.model.params.state_dict().items()}, 'global_step': step}, path)
+                torch.save(trainer.checkpoint(), path)
                 saved.append(path)
                 if val_items:
                     validate(step)
