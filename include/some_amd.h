@@ -232,9 +232,12 @@ int some_train_batchnorm_bwd(SomeHandle* h, const float* dy_dev, const float* x_
 #define SOME_ELT_SIGMOID_FWD 2  /* out = sigmoid(a)                                   */
 #define SOME_ELT_SIGMOID_BWD 3  /* out = a * b * (1 - b)     a = dy, b = sigmoid output */
 #define SOME_ELT_AXPY 4         /* out = alpha * a + b       (x = f(x) * 0.5 + x, Gconform.py:57,60); b NULL: alpha * a */
-#define SOME_ELT_DROPOUT 5      /* out = a * keep / (1 - alpha), keep ~ Bernoulli(1 - alpha) from (seed, index) */
+#define SOME_ELT_DROPOUT 5        /* out = drop(a): a * keep / (1 - p), keep ~ Bernoulli(1 - p) from (seed, index)       */
+#define SOME_ELT_SILU_DROP_FWD 6  /* out = drop(silu(a))                       (conform_ffn: act + drop1, Gconform.py:31-32) */
+#define SOME_ELT_SILU_DROP_BWD 7  /* out = drop(a) * silu'(b)                  a = dy, b = pre-activation                    */
+#define SOME_ELT_AXPY_DROP 8      /* out = alpha * drop(a) + b (b NULL: none)  (x = drop(f(x)) * 0.5 + x, Gconform.py:57-61)  */
 int some_train_eltwise(SomeHandle* h, int32_t op, const float* a_dev, const float* b_dev, float* out_dev, int64_t n,
-                       float alpha, uint64_t seed, void* stream);
+                       float alpha, float p, uint64_t seed, void* stream);
 /* GLU over channel halves of [M, 2C] (Gconform.py:11-17, base_conv.py:7-15); backward = 1: dy [M, C], x -> dx [M, 2C]. */
 int some_train_glu(SomeHandle* h, const float* dy_dev, const float* x_dev, float* out_dev, int64_t M, int32_t C,
                    int32_t backward, void* stream);

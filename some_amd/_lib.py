@@ -16,7 +16,8 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_SILU, EPI_BIAS_RES, EPI_GLU, EPI_GLU_RES = range(6)
 PRECISION_F32, PRECISION_F16X3 = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
 SAMPLE_F32, SAMPLE_PCM16 = 0, 1
-ELT_SILU_FWD, ELT_SILU_BWD, ELT_SIGMOID_FWD, ELT_SIGMOID_BWD, ELT_AXPY, ELT_DROPOUT = range(6)
+(ELT_SILU_FWD, ELT_SILU_BWD, ELT_SIGMOID_FWD, ELT_SIGMOID_BWD, ELT_AXPY, ELT_DROPOUT, ELT_SILU_DROP_FWD, ELT_SILU_DROP_BWD,
+ ELT_AXPY_DROP) = range(9)
 GEMM_SPLIT_IN, GEMM_SPLIT_OUT, GEMM_HI_ONLY = 1, 2, 4
 
 
@@ -70,7 +71,7 @@ SYMBOLS = {
     'some_train_layernorm_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
     'some_train_batchnorm_fwd': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     'some_train_batchnorm_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),
-    'some_train_eltwise': (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int64, C.c_float, C.c_uint64, _P]),
+    'some_train_eltwise': (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_uint64, _P]),
     'some_train_glu': (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     'some_train_mask_rows': (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P]),
     'some_train_dwconv': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P]),

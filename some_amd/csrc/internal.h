@@ -176,7 +176,7 @@ hipError_t launch_bn_fwd(const float* x, const float* g, const float* b, int M, 
                          float* running_var, float* y, float* save_mean, float* save_rstd, float* scratch, hipStream_t s);
 hipError_t launch_bn_bwd(const float* dy, const float* x, const float* g, const float* save_mean, const float* save_rstd, int M, int C,
                          float* dx, float* dgamma, float* dbeta, float* scratch, hipStream_t s);
-hipError_t launch_eltwise(int op, const float* a, const float* b, float* out, int64_t n, float alpha, uint64_t seed, hipStream_t s);
+hipError_t launch_eltwise(int op, const float* a, const float* b, float* out, int64_t n, float alpha, float p, uint64_t seed, hipStream_t s);
 hipError_t launch_glu(const float* dy, const float* x, float* out, int64_t M, int C, int backward, hipStream_t s);
 hipError_t launch_mask_rows(const float* x, const uint8_t* mask, float* y, int64_t M, int C, hipStream_t s);
 hipError_t launch_dwconv_train(const float* x, const float* w, const float* bias, const int32_t* frame_offsets, int B, int max_frames, float* y,

@@ -30,7 +30,7 @@ extern "C" {
 size_t some_train_scratch_bytes(const SomeHandle* h, int64_t M, int32_t N) {
     (void)h;
     if (M <= 0 || N <= 0) return 256;
-    const size_t col = chunks(M) * (size_t)(kConvK > 2 ? kConvK : 2) * (size_t)N * sizeof(float);   // column partials / tap partials
+    const size_t col = (size_t)((M + 63) / 64) * (size_t)kConvK * (size_t)N * sizeof(float);       // tap partials (64-row chunks) >= column partials
     const size_t loss = 1024 * sizeof(double) + (size_t)M * sizeof(double) / 64 + 8192;             // loss partials (<= 1024 blocks or B rows)
     return (col > loss ? col : loss) + 256;
 }
@@ -139,14 +139,14 @@ int some_train_batchnorm_bwd(SomeHandle* h, const float* dy_dev, const float* x_
 }
 
 int some_train_eltwise(SomeHandle* h, int32_t op, const float* a_dev, const float* b_dev, float* out_dev, int64_t n,
-                       float alpha, uint64_t seed, void* stream) {
+                       float alpha, float p, uint64_t seed, void* stream) {
     if (!h) return SOME_EINVAL;
-    T_CHECK(h, op >= 0 && op <= SOME_ELT_DROPOUT && n >= 0, "some_train_eltwise: bad op or size");
+    T_CHECK(h, op >= 0 && op <= SOME_ELT_AXPY_DROP && n >= 0, "some_train_eltwise: bad op or size");
     if (n == 0) return SOME_OK;
-    const bool needs_b = op == SOME_ELT_SILU_BWD || op == SOME_ELT_SIGMOID_BWD;
+    const bool needs_b = op == SOME_ELT_SILU_BWD || op == SOME_ELT_SIGMOID_BWD || op == SOME_ELT_SILU_DROP_BWD;
     T_CHECK(h, a_dev && out_dev && (!needs_b || b_dev), "some_train_eltwise: null pointer");
-    T_CHECK(h, op != SOME_ELT_DROPOUT || (alpha >= 0.f && alpha < 1.f), "some_train_eltwise: dropout probability must be in [0, 1)");
-    T_TRY(h, launch_eltwise(op, a_dev, b_dev, out_dev, n, alpha, seed, st(stream)));
+    T_CHECK(h, p >= 0.f && p < 1.f, "some_train_eltwise: dropout probability must be in [0, 1)");
+    T_TRY(h, launch_eltwise(op, a_dev, b_dev, out_dev, n, alpha, p, seed, st(stream)));
     return SOME_OK;
 }
 

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
 }
 
 // ---- element-wise ----------------------------------------------------------------------------------------------------
-enum { ELT_SILU_FWD, ELT_SILU_BWD, ELT_SIGMOID_FWD, ELT_SIGMOID_BWD, ELT_AXPY, ELT_DROPOUT };
+enum { ELT_SILU_FWD, ELT_SILU_BWD, ELT_SIGMOID_FWD, ELT_SIGMOID_BWD, ELT_AXPY, ELT_DROPOUT, ELT_SILU_DROP_FWD, ELT_SILU_DROP_BWD, ELT_AXPY_DROP };
 
 __device__ __forceinline__ uint32_t mix32(uint64_t z) {          // splitmix64 finaliser -> 32 random bits per element
     z += 0x9E3779B97F4A7C15ull;
@@ -236,20 +236,27 @@ __device__ __forceinline__ uint32_t mix32(uint64_t z) {          // splitmix64 f
 
 template <int OP>
 __global__ __launch_bounds__(256) void eltwise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                                                       int64_t n, float alpha, uint64_t seed) {
+                                                       int64_t n, float alpha, float p, uint64_t seed) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float x = a[i];
+    // dropout factor of element i: 0 with probability p, else 1 / (1 - p); a pure function of (seed, i), so the backward
+    // regenerates the forward's mask
+    float keep = 1.f;
+    if (OP == ELT_DROPOUT || OP == ELT_SILU_DROP_FWD || OP == ELT_SILU_DROP_BWD || OP == ELT_AXPY_DROP) {
+        const float u = (float)(mix32(seed + (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
+        keep = u >= p ? 1.0f / (1.0f - p) : 0.f;
+    }
     float r;
     if (OP == ELT_SILU_FWD) r = x * sigmoid_(x);
     else if (OP == ELT_SILU_BWD) { const float u = b[i], s = sigmoid_(u); r = x * s * (1.f + u * (1.f - s)); }       // a = dy, b = pre-activation
     else if (OP == ELT_SIGMOID_FWD) r = sigmoid_(x);
     else if (OP == ELT_SIGMOID_BWD) { const float y = b[i]; r = x * y * (1.f - y); }                                 // a = dy, b = sigmoid output
     else if (OP == ELT_AXPY) r = alpha * x + (b ? b[i] : 0.f);                                                       // alpha a (+ b)
-    else {                                                                                                           // keep with prob 1 - alpha, scale 1 / (1 - alpha)
-        const float u = (float)(mix32(seed + (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
-        r = u >= alpha ? x * (1.0f / (1.0f - alpha)) : 0.f;
-    }
+    else if (OP == ELT_DROPOUT) r = x * keep;
+    else if (OP == ELT_SILU_DROP_FWD) r = x * sigmoid_(x) * keep;                                                    // dropout(silu(a))
+    else if (OP == ELT_SILU_DROP_BWD) { const float u = b[i], s = sigmoid_(u); r = x * keep * s * (1.f + u * (1.f - s)); }
+    else r = alpha * (x * keep) + (b ? b[i] : 0.f);                                                                  // alpha dropout(a) (+ b)
     out[i] = r;
 }
 
@@ -300,13 +307,15 @@ __global__ __launch_bounds__(256) void dwconv_train_kernel(const float* __restri
     *reinterpret_cast<f32x4*>(y + (size_t)(f0 + t) * C + c) = acc;
 }
 
-// tap gradients: partial[p][k][c] = sum over the chunk's rows t of dy[t, c] x[t + k - 15, c] (inside the row's clip)
+// tap gradients: partial[p][k][c] = sum over the chunk's rows t of dy[t, c] x[t + k - 15, c] (inside the row's clip).
+// Short chunks (64 rows): the per-thread work is a chain of dependent row iterations, so the grid has to be wide.
+constexpr int kDwChunk = 64;
 __global__ __launch_bounds__(256) void dwconv_bwd_w_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                     const int32_t* __restrict__ clip_of_row, const int32_t* __restrict__ frame_offsets,
                                                                     int M, int C, float* __restrict__ partial) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * kChunkRows, r1 = min(M, r0 + kChunkRows);
+    const int r0 = blockIdx.y * kDwChunk, r1 = min(M, r0 + kDwChunk);
     float acc[kTaps];
 #pragma unroll
     for (int k = 0; k < kTaps; ++k) acc[k] = 0.f;
@@ -473,7 +482,7 @@ hipError_t launch_reduce_slices(const float* partial, int slices, size_t n, floa
 // ---- launchers -----------------------------------------------------------------------------------------------------------
 static inline int n_chunks(int M) { return (M + kChunkRows - 1) / kChunkRows; }
 size_t train_col_scratch_bytes(int M, int N) { return (size_t)n_chunks(M) * 2 * N * sizeof(float); }
-size_t train_dwconv_w_scratch_bytes(int M, int C) { return (size_t)n_chunks(M) * kTaps * C * sizeof(float); }
+size_t train_dwconv_w_scratch_bytes(int M, int C) { return (size_t)((M + kDwChunk - 1) / kDwChunk) * kTaps * C * sizeof(float); }
 
 hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, int split_out, hipStream_t s) {
     if (M <= 0 || N <= 0) return hipSuccess;
@@ -532,18 +541,16 @@ hipError_t launch_bn_bwd(const float* dy, const float* x, const float* g, const 
     return hipGetLastError();
 }
 
-hipError_t launch_eltwise(int op, const float* a, const float* b, float* out, int64_t n, float alpha, uint64_t seed, hipStream_t s) {
+hipError_t launch_eltwise(int op, const float* a, const float* b, float* out, int64_t n, float alpha, float p, uint64_t seed, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const dim3 grid((unsigned)((n + 255) / 256));
+#define ELT_CASE(OP) case OP: hipLaunchKernelGGL(eltwise_kernel<OP>, grid, dim3(256), 0, s, a, b, out, n, alpha, p, seed); break;
     switch (op) {
-        case ELT_SILU_FWD: hipLaunchKernelGGL(eltwise_kernel<ELT_SILU_FWD>, grid, dim3(256), 0, s, a, b, out, n, alpha, seed); break;
-        case ELT_SILU_BWD: hipLaunchKernelGGL(eltwise_kernel<ELT_SILU_BWD>, grid, dim3(256), 0, s, a, b, out, n, alpha, seed); break;
-        case ELT_SIGMOID_FWD: hipLaunchKernelGGL(eltwise_kernel<ELT_SIGMOID_FWD>, grid, dim3(256), 0, s, a, b, out, n, alpha, seed); break;
-        case ELT_SIGMOID_BWD: hipLaunchKernelGGL(eltwise_kernel<ELT_SIGMOID_BWD>, grid, dim3(256), 0, s, a, b, out, n, alpha, seed); break;
-        case ELT_AXPY: hipLaunchKernelGGL(eltwise_kernel<ELT_AXPY>, grid, dim3(256), 0, s, a, b, out, n, alpha, seed); break;
-        case ELT_DROPOUT: hipLaunchKernelGGL(eltwise_kernel<ELT_DROPOUT>, grid, dim3(256), 0, s, a, b, out, n, alpha, seed); break;
+        ELT_CASE(ELT_SILU_FWD) ELT_CASE(ELT_SILU_BWD) ELT_CASE(ELT_SIGMOID_FWD) ELT_CASE(ELT_SIGMOID_BWD) ELT_CASE(ELT_AXPY)
+        ELT_CASE(ELT_DROPOUT) ELT_CASE(ELT_SILU_DROP_FWD) ELT_CASE(ELT_SILU_DROP_BWD) ELT_CASE(ELT_AXPY_DROP)
         default: return hipErrorInvalidValue;
     }
+#undef ELT_CASE
     return hipGetLastError();
 }
 
@@ -572,7 +579,7 @@ hipError_t launch_dwconv_train(const float* x, const float* w, const float* bias
 hipError_t launch_dwconv_bwd_w(const float* dy, const float* x, const int32_t* clip_of_row, const int32_t* frame_offsets, int M, int C, float* dw,
                                int accumulate, float* scratch, hipStream_t s) {
     if (M <= 0) return hipSuccess;
-    const int P = n_chunks(M);
+    const int P = (M + kDwChunk - 1) / kDwChunk;
     hipLaunchKernelGGL(dwconv_bwd_w_partial_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)P), dim3(256), 0, s, dy, x, clip_of_row, frame_offsets, M, C,
                        scratch);
     hipLaunchKernelGGL(dwconv_bwd_w_final_kernel, dim3((unsigned)((kTaps * C + 255) / 256)), dim3(256), 0, s, scratch, P, kTaps * C, dw, accumulate);

@@ -104,21 +104,21 @@ class TrainableMidiConforms:
         self._seed = seed
         self._calls = 0
 
-    # ---- dropout seeds: one independent stream per call site and step -------------------------------------------------
-    def _dropout(self, x, kind: str):
+    # ---- dropout: one independent (seed, counter) stream per call site and step; fused into the neighbouring pass --------
+    def _drop(self, kind: str):
         p = self.drop[kind] if self.training else 0.0
         if p <= 0.0:
-            return x
+            return 0.0, 0
         self._calls += 1
-        return self.ops.dropout(x, p, seed=(self._seed * 1000003 + self._calls) * 4294967311 % (1 << 62))
+        return p, (self._seed * 1000003 + self._calls) * 4294967311 % (1 << 62)
 
     # ---- blocks (Gconform.py) ------------------------------------------------------------------------------------------
     def _ffn(self, x, pre: str):
+        """conform_ffn.forward (Gconform.py:29-34) WITHOUT its output dropout, which the caller fuses into the residual."""
         P, o = self.params, self.ops
         h = o.linear(x, P[pre + '.ln1.weight'], P[pre + '.ln1.bias'])
-        h = self._dropout(o.silu(h), 'ffn_latent')
-        h = o.linear(h, P[pre + '.ln2.weight'], P[pre + '.ln2.bias'])
-        return self._dropout(h, 'ffn_out')
+        h = o.silu_dropout(h, *self._drop('ffn_latent'))
+        return o.linear(h, P[pre + '.ln2.weight'], P[pre + '.ln2.bias'])
 
     def _attention(self, x, pre: str, batch):
         P, o = self.params, self.ops
@@ -133,17 +133,16 @@ class TrainableMidiConforms:
         h = o.batchnorm(h, P[pre + '.norm.weight'], P[pre + '.norm.bias'], P[pre + '.norm.running_mean'], P[pre + '.norm.running_var'])
         with torch.no_grad():
             P[pre + '.norm.num_batches_tracked'].add_(1)
-        h = o.linear(o.silu(h), P[pre + '.pointwise_conv2.weight'], P[pre + '.pointwise_conv2.bias'])
-        return self._dropout(h, 'conv')
+        return o.linear(o.silu(h), P[pre + '.pointwise_conv2.weight'], P[pre + '.pointwise_conv2.bias'])   # dropout: fused by the caller
 
     def _block(self, x, pre: str, batch):
         """conform_blocke.forward (Gconform.py:56-63)."""
         P, o = self.params, self.ops
         ln = lambda t, i: o.layernorm(t, P[f'{pre}.norm{i}.weight'], P[f'{pre}.norm{i}.bias'])   # noqa: E731
-        x = o.axpy(0.5, self._ffn(ln(x, 1), pre + '.ffn1'), x)
-        x = o.axpy(1.0, self._dropout(self._attention(ln(x, 2), pre + '.att', batch), 'attention'), x)
-        x = o.axpy(1.0, self._conv(ln(x, 3), pre + '.conv', batch), x)
-        x = o.axpy(0.5, self._ffn(ln(x, 4), pre + '.ffn2'), x)
+        x = o.axpy_dropout(0.5, self._ffn(ln(x, 1), pre + '.ffn1'), x, *self._drop('ffn_out'))
+        x = o.axpy_dropout(1.0, self._attention(ln(x, 2), pre + '.att', batch), x, *self._drop('attention'))
+        x = o.axpy_dropout(1.0, self._conv(ln(x, 3), pre + '.conv', batch), x, *self._drop('conv'))
+        x = o.axpy_dropout(0.5, self._ffn(ln(x, 4), pre + '.ffn2'), x, *self._drop('ffn_out'))
         return ln(x, 5)
 
     def forward(self, units: torch.Tensor, batch: ClipBatch, mask: Optional[torch.Tensor] = None):

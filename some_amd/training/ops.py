@@ -162,9 +162,11 @@ class TrainOps:
         self.check(self.lib.some_train_colsum(self.h, _p(x), M, N, N, _p(out), 0, _p(sc), sc.numel(), self.stream()))
         return out
 
-    def eltwise(self, op: int, a: torch.Tensor, b: Optional[torch.Tensor] = None, alpha: float = 0.0, seed: int = 0) -> torch.Tensor:
+    def eltwise(self, op: int, a: torch.Tensor, b: Optional[torch.Tensor] = None, alpha: float = 0.0, seed: int = 0,
+                p: float = 0.0) -> torch.Tensor:
         out = torch.empty_like(a)
-        self.check(self.lib.some_train_eltwise(self.h, op, _p(a), _p(b), _p(out), a.numel(), float(alpha), C.c_uint64(seed), self.stream()))
+        self.check(self.lib.some_train_eltwise(self.h, op, _p(a), _p(b), _p(out), a.numel(), float(alpha), float(p), C.c_uint64(seed),
+                                               self.stream()))
         return out
 
     # ---- differentiable operators ---------------------------------------------------------------------------------------
@@ -180,6 +182,14 @@ class TrainOps:
 
     def sigmoid(self, x):
         return _Sigmoid.apply(self, x)
+
+    def silu_dropout(self, x, p: float, seed: int):
+        """dropout(silu(x)) in one pass (conform_ffn.forward: act + drop1, Gconform.py:31-32)."""
+        return _Silu.apply(self, x) if p <= 0.0 else _SiluDropout.apply(self, x, p, seed)
+
+    def axpy_dropout(self, alpha: float, y, x, p: float, seed: int):
+        """alpha * dropout(y) + x in one pass (the residual sites of conform_blocke.forward, Gconform.py:57-61)."""
+        return _Axpy.apply(self, alpha, y, x) if p <= 0.0 else _AxpyDropout.apply(self, alpha, y, x, p, seed)
 
     def glu(self, x):
         return _Glu.apply(self, x)
@@ -323,6 +333,32 @@ class _Axpy(torch.autograd.Function):
         return None, None, dy, d
 
 
+class _SiluDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, x, p, seed):
+        ctx.ops, ctx.p, ctx.seed = ops, p, seed
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.eltwise(_lib.ELT_SILU_DROP_FWD, x, p=p, seed=seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return None, ctx.ops.eltwise(_lib.ELT_SILU_DROP_BWD, dy.contiguous(), x, p=ctx.p, seed=ctx.seed), None, None
+
+
+class _AxpyDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, alpha, y, x, p, seed):
+        ctx.ops, ctx.alpha, ctx.p, ctx.seed = ops, alpha, p, seed
+        return ops.eltwise(_lib.ELT_AXPY_DROP, y.contiguous(), x.contiguous(), alpha=alpha, p=p, seed=seed)
+
+    @staticmethod
+    def backward(ctx, d):
+        dy = ctx.ops.eltwise(_lib.ELT_AXPY_DROP, d.contiguous(), None, alpha=ctx.alpha, p=ctx.p, seed=ctx.seed)
+        return None, None, dy, d, None, None
+
+
 class _MaskRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ops, x, mask_u8):
@@ -345,11 +381,11 @@ class _Dropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ops, x, p, seed):
         ctx.ops, ctx.p, ctx.seed = ops, p, seed
-        return ops.eltwise(_lib.ELT_DROPOUT, x.contiguous(), alpha=p, seed=seed)
+        return ops.eltwise(_lib.ELT_DROPOUT, x.contiguous(), p=p, seed=seed)
 
     @staticmethod
     def backward(ctx, dy):
-        return None, ctx.ops.eltwise(_lib.ELT_DROPOUT, dy.contiguous(), alpha=ctx.p, seed=ctx.seed), None, None
+        return None, ctx.ops.eltwise(_lib.ELT_DROPOUT, dy.contiguous(), p=ctx.p, seed=ctx.seed), None, None
 
 
 class _DwConv(torch.autograd.Function):

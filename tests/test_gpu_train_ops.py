@@ -92,6 +92,17 @@ def test_dropout(ops):
     y.backward(torch.ones_like(y))
     torch.testing.assert_close(x.grad, keep.float() / 0.9)
     assert ops.dropout(x, 0.0, seed=1) is x
+    # the fused passes are the same arithmetic as their compositions - forward and backward, same (seed, index) mask
+    a = x.detach().clone().requires_grad_(True)
+    b = x.detach().clone().requires_grad_(True)
+    res = _rand(400, 512, seed=10).detach()
+    f1 = ops.axpy_dropout(0.5, ops.silu_dropout(a, 0.1, 77), res, 0.2, 78)
+    f2 = ops.axpy(0.5, ops.dropout(ops.dropout(ops.silu(b), 0.1, 77), 0.2, 78), res)
+    assert torch.equal(f1, f2)
+    cot = torch.randn_like(f1)
+    f1.backward(cot)
+    f2.backward(cot)
+    assert torch.equal(a.grad, b.grad)
 
 
 def test_dwconv(ops):
