@@ -103,7 +103,7 @@ class MIDIExtractionInference(BaseInference):
         probs, bounds = self.engine.forward(units, batch, mask=None,
                                             head_mode=_lib.HEAD_SOFTMAX if self.quantized else _lib.HEAD_SIGMOID)
         out = self.engine.decode(probs, bounds, batch, quantized=self.quantized)
-        finite = torch.isfinite(bounds).all()
+        finite = torch.isfinite(bounds).all() & torch.isfinite(probs).all()      # either stream can leave the f16 range
         return out, finite, {'units': units, 'probs': probs, 'bounds': bounds, 'batch': batch}
 
     def _finish(self, out, finite, batch) -> List[Dict[str, np.ndarray]]:
@@ -219,7 +219,7 @@ class MIDIExtractionInference(BaseInference):
         probs, bounds = self.engine.forward(units, batch, mask=None,
                                             head_mode=_lib.HEAD_SOFTMAX if self.quantized else _lib.HEAD_SIGMOID)
         out = self.engine.decode(probs, bounds, batch, quantized=self.quantized)
-        finite = torch.isfinite(bounds).all()
+        finite = torch.isfinite(bounds).all() & torch.isfinite(probs).all()      # either stream can leave the f16 range
         return out, finite, batch, spans_per_file
 
     def _group_files(self, clips: List[np.ndarray]) -> List[List[int]]:

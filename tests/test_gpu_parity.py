@@ -421,3 +421,64 @@ def test_arena_cache_round_trip(tmp_path):
     assert len(rc['note_midi']) != len(ra['note_midi']) or not np.array_equal(rc['note_midi'], ra['note_midi'])
     d = inference.MIDIExtractionInference(config=dict(cfg, some_amd_arena_cache=False), model_path=ckpt)
     assert not d.loaded_from_cache
+
+
+def _heavy_state_dict(cfg, seed, qk=3.0, ffn=2.5):
+    """Random weights with trained-model traits: sharply peaked attention (q, k, v x qk), large FFN hidden activations,
+    a few LayerNorm gains of 4."""
+    sd = synth.synth_state_dict(cfg, seed)
+    rng = np.random.default_rng(seed)
+    for k in sd:
+        if k.endswith('to_q.weight') or k.endswith('to_kv.weight'):
+            sd[k] = (sd[k] * qk).astype(np.float32)
+        elif '.ln1.weight' in k or '.ln2.weight' in k:
+            sd[k] = (sd[k] * ffn).astype(np.float32)
+        elif 'norm' in k and k.endswith('weight') and 'conv.norm' not in k:
+            sd[k] = (sd[k] * (1.0 + 3.0 * (rng.uniform(size=sd[k].shape) < 0.05))).astype(np.float32)
+    return sd
+
+
+def test_heavy_tailed_weights_split_f16_is_fp32_equivalent():
+    """Peaked attention (scores x9), FFN activations x6, LayerNorm gains up to 4: the split-f16 path stays in the same
+    error class as the exact-f32 kernels and the fp32 CPU oracle itself (all measured against an fp64 oracle run)."""
+    from oracle import restate
+    from some_amd import _lib
+    from some_amd.engine import ClipBatch, Engine
+    cfg = get_config('midi_conformer', lay=2)
+    sd = _heavy_state_dict(cfg, 77)
+    rng = np.random.default_rng(3)
+    T = 700
+    units = (rng.standard_normal((T, 80)) * 3 - 4).astype(np.float32)
+    sd64 = {k: (torch.from_numpy(np.asarray(v)).double() if np.asarray(v).dtype != np.int64 else torch.from_numpy(np.asarray(v)))
+            for k, v in sd.items()}
+    r64 = restate.model_forward(sd64, cfg, torch.from_numpy(units).double())[0].numpy()
+    r32 = restate.model_forward(sd, cfg, units)[0].numpy()
+    oracle_err = np.abs(r32 - r64).max()
+    batch = ClipBatch([T], 'cuda')
+    for prec in ('f32', 'f16x3'):
+        e = Engine(dict(cfg, some_amd_precision=prec), device='cuda')
+        e.load_state_dict(sd)
+        m, _ = e.forward(torch.from_numpy(units).cuda(), batch, head_mode=_lib.HEAD_LOGITS)
+        err = np.abs(m.cpu().numpy() - r64).max()
+        print(f'{prec}: max |dlogit| vs fp64 {err:.2e} (fp32 CPU oracle: {oracle_err:.2e}, logit scale {np.abs(r64).max():.1f})')
+        assert err < 3 * oracle_err + 2e-6 and err < LOGIT_TOL
+
+
+def test_f16x3_range_overflow_is_reported_not_silent(tmp_path):
+    """GEMM inputs beyond the f16 range (here: an FFN of the LAST midi-stream block scaled x1e5 - bounds stay finite) make the split-f16 path non-finite: the inference class
+    raises and names the exact-f32 switch; the f32 mode handles the same checkpoint."""
+    import inference
+    cfg = get_config('midi_conformer', lay=1)
+    sd = synth.synth_state_dict(cfg, 5)
+    sd['model.att1.ffn1.ln1.weight'] = (sd['model.att1.ffn1.ln1.weight'] * 1e5).astype(np.float32)
+    ckpt = tmp_path / 'model.ckpt'
+    from collections import OrderedDict
+    import yaml
+    torch.save({'state_dict': OrderedDict(('model.' + k, torch.from_numpy(np.asarray(v))) for k, v in sd.items())}, ckpt)
+    with open(tmp_path / 'config.yaml', 'w', encoding='utf8') as f:
+        yaml.safe_dump(cfg, f)
+    w = synth.synth_clip(1, 2.0)
+    with pytest.raises(FloatingPointError, match='some_amd_precision'):
+        inference.MIDIExtractionInference(config=dict(cfg, some_amd_precision='f16x3'), model_path=ckpt).infer([w])
+    res = inference.MIDIExtractionInference(config=dict(cfg, some_amd_precision='f32'), model_path=ckpt).infer([w])
+    assert len(res) == 1 and np.isfinite(res[0]['note_midi']).all()
