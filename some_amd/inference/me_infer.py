@@ -55,6 +55,36 @@ class MIDIExtractionInference(BaseInference):
                                  quantized=self.quantized, mask=masks)
         return self._collect(out, batch)[0]
 
+    # ---- precision guard --------------------------------------------------------------------------------------
+    def _guarded(self, fn, *args, **kw):
+        """Run ``fn``; if the split-f16 path reports a range overflow and the precision was not pinned by the user
+        (config key / environment), rebuild the model in the exact-f32 mode ONCE, say so, and run again."""
+        import os
+        try:
+            return fn(*args, **kw)
+        except FloatingPointError:
+            pinned = self.config.get('some_amd_precision') or os.environ.get('SOME_AMD_PRECISION')
+            if pinned:
+                raise
+            print('WARNING: activations left the f16 range of the split-f16 matrix path; switching this model to the exact-f32 '
+                  'kernels (set `some_amd_precision: f32` in config.yaml to start there)')
+            self.config = dict(self.config, some_amd_precision='f32')
+            self.model = self.build_model()
+            self.engine = self.model.engine
+            return fn(*args, **kw)
+
+    def infer_batch(self, waveforms: List[np.ndarray], return_device_outputs: bool = False):
+        """All clips in ONE packed device batch.  Results equal running the clips one by one."""
+        return self._guarded(self._infer_batch_impl, waveforms, return_device_outputs)
+
+    def infer(self, waveforms: List[np.ndarray]) -> List[Dict[str, np.ndarray]]:
+        """base_infer.py:46-53 semantics on packed device batches (see ``_infer_impl``)."""
+        return self._guarded(self._infer_impl, waveforms)
+
+    def infer_files(self, clips: List[np.ndarray], slicer) -> List[List[Tuple[float, Dict[str, np.ndarray]]]]:
+        """Whole mono files -> per file [(chunk offset in seconds, notes)] (see ``_infer_files_impl``)."""
+        return self._guarded(self._infer_files_impl, clips, slicer)
+
     # ---- batched path -----------------------------------------------------------------------------
     def _collect(self, out: Dict[str, torch.Tensor], batch: ClipBatch) -> List[Dict[str, np.ndarray]]:
         n_notes = out['n_notes'].cpu().numpy()
@@ -115,7 +145,7 @@ class MIDIExtractionInference(BaseInference):
         return res
 
     @torch.no_grad()
-    def infer_batch(self, waveforms: List[np.ndarray], return_device_outputs: bool = False):
+    def _infer_batch_impl(self, waveforms: List[np.ndarray], return_device_outputs: bool = False):
         """All clips in ONE packed device batch.  Results equal running the clips one by one."""
         if not waveforms:
             return []
@@ -127,7 +157,7 @@ class MIDIExtractionInference(BaseInference):
         return res
 
     @torch.no_grad()
-    def infer(self, waveforms: List[np.ndarray]) -> List[Dict[str, np.ndarray]]:
+    def _infer_impl(self, waveforms: List[np.ndarray]) -> List[Dict[str, np.ndarray]]:
         """base_infer.py:46-53 semantics, executed as packed batches of at most ``max_batch_frames`` frames.  While
         the GPU works on batch i the host packs batch i + 1 into the other pinned buffer and its H2D copy runs on
         the copy stream; results of batch i are read back after batch i + 1 has been enqueued."""
@@ -240,7 +270,7 @@ class MIDIExtractionInference(BaseInference):
         return groups
 
     @torch.no_grad()
-    def infer_files(self, clips: List[np.ndarray], slicer) -> List[List[Tuple[float, Dict[str, np.ndarray]]]]:
+    def _infer_files_impl(self, clips: List[np.ndarray], slicer) -> List[List[Tuple[float, Dict[str, np.ndarray]]]]:
         """Whole mono files -> per file [(chunk offset in seconds, {'note_midi', 'note_dur', 'note_rest'})]: the
         ``Slicer(...).slice(waveform)`` + ``infer(chunks)`` pair of infer.py:35-38 / batch_infer.py:52-57 with the file
         uploaded once as it is stored (int16 PCM), the slicer's RMS curve and the chunk cut computed on the device and

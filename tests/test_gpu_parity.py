@@ -482,3 +482,11 @@ def test_f16x3_range_overflow_is_reported_not_silent(tmp_path):
         inference.MIDIExtractionInference(config=dict(cfg, some_amd_precision='f16x3'), model_path=ckpt).infer([w])
     res = inference.MIDIExtractionInference(config=dict(cfg, some_amd_precision='f32'), model_path=ckpt).infer([w])
     assert len(res) == 1 and np.isfinite(res[0]['note_midi']).all()
+    # precision not pinned: the class falls back to the exact-f32 kernels by itself (once, with a warning) - same result
+    import os
+    if not os.environ.get('SOME_AMD_PRECISION'):
+        auto = inference.MIDIExtractionInference(config=cfg, model_path=ckpt)
+        res2 = auto.infer([w])
+        assert auto.config['some_amd_precision'] == 'f32'
+        for k in res[0]:
+            np.testing.assert_array_equal(res2[0][k], res[0][k])
