@@ -217,3 +217,29 @@ def test_arena_cache_file_validation(tmp_path):
     assert arena_cache.load(ckpt, 1000, 1, cfg) is None
     ro = tmp_path / 'missing_dir' / 'm.ckpt'
     assert arena_cache.store(ro, arena, 1, cfg) is False                      # unwritable: best effort
+
+
+def test_http_front_of_the_service(tmp_path):
+    """/models lists checkpoints, /infer turns WAV bytes into MIDI bytes through ExtractionService (model stubbed)."""
+    import warnings
+    import dataset_util
+    from some_amd.configs import get_config
+    from some_amd.serve import build_app
+    from some_amd.serving import ExtractionService
+    from some_amd.utils.audio import save_wav
+    warnings.simplefilter('ignore')
+    from starlette.testclient import TestClient
+    (tmp_path / 'exp').mkdir()
+    (tmp_path / 'exp' / 'm.ckpt').write_bytes(b'')
+    wav = tmp_path / 'a.wav'
+    save_wav(wav, synth.synth_clip(2, 2.0), 44100)
+    with ExtractionService(work_dir=tmp_path) as svc:
+        svc._instances['exp/m.ckpt'] = (dataset_util.FakeIngestInference(), get_config('midi_conformer'))
+        client = TestClient(build_app(svc, tmp_path))
+        assert client.get('/models').json() == {'models': ['exp/m.ckpt']}
+        r = client.post('/infer', params={'model': 'exp/m.ckpt', 'tempo': 100}, content=wav.read_bytes())
+        assert r.status_code == 200 and r.content[:4] == b'MThd' and r.headers['x-some-stats'].startswith('Cost ')
+        r = client.post('/infer', params={'model': 'exp/m.ckpt'}, content=b'junk')
+        assert r.status_code == 400 and 'unsupported or corrupt' in r.json()['error']
+        r = client.post('/infer', params={'model': 'exp/m.ckpt'}, content=b'')
+        assert r.status_code == 400
