@@ -9,7 +9,6 @@ host).  No request waits for a timer: an idle service starts a lone request at o
     midi_path, stats = svc.extract_midi('some_model/model.ckpt', 'song.wav', tempo=120)      # webui.infer semantics
     fut = svc.submit('some_model/model.ckpt', pcm_int16)                                     # -> Future of [(offset_s, notes)]
 """
-import importlib
 import pathlib
 import queue
 import threading
@@ -41,18 +40,13 @@ class ExtractionService:
         """Called on the dispatcher thread only."""
         key = str(model_path)
         if key not in self._instances:
-            import inference
+            from .inference.loader import resolve_inference_class
             path = pathlib.Path(model_path)
             if self.work_dir is not None and not path.is_absolute():
                 path = self.work_dir / path
             with open(path.with_name('config.yaml'), 'r', encoding='utf8') as f:
                 config = yaml.safe_load(f)
-            cls_path = inference.task_inference_mapping[config['task_cls']]
-            pkg, cls_name = cls_path.rsplit('.', 1)
-            cls = getattr(importlib.import_module(pkg), cls_name)
-            assert issubclass(cls, inference.BaseInference), \
-                f'Inference class {cls} is not a subclass of {inference.BaseInference}.'
-            ins = cls(config=config, model_path=path, device=self.device)
+            ins = resolve_inference_class(config['task_cls'])(config=config, model_path=path, device=self.device)
             ins.max_batch_frames = self.max_batch_frames
             self._instances[key] = (ins, config)
         return self._instances[key]

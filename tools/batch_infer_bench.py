@@ -60,9 +60,8 @@ def main():
         print(f'dataset: {args.clips} x {args.seconds:g} s int16 WAVs written in {time.perf_counter() - t0:.1f} s')
     import batch_infer as bi
     import torch
-    bi.print_config = lambda *_a, **_k: None
-    import infer as infer_mod
-    infer_mod.print_config = lambda *_a, **_k: None
+    import utils.config_utils
+    utils.config_utils.print_config = lambda *_a, **_k: None          # keep the timing output readable
     if world > 1:
         time.sleep(0 if rank == 0 else 2)
     t0 = time.perf_counter()
