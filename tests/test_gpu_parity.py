@@ -490,3 +490,57 @@ def test_f16x3_range_overflow_is_reported_not_silent(tmp_path):
         assert auto.config['some_amd_precision'] == 'f32'
         for k in res[0]:
             np.testing.assert_array_equal(res2[0][k], res[0][k])
+
+
+def test_full_size_batch_size_independent_properties():
+    """BASELINE config 1 at full size (lay 8, 32 x 30 s = 82 688 frames) through log-mel -> forward -> decode; the oracle
+    cannot run this in test time, so size-independent properties stand in: (1) a clip's outputs do not depend on what
+    else is in the batch or where it sits (<= 1e-5 through 18 blocks: the packing only moves attention key-tile boundaries,
+    i.e. fp32 summation order);
+    (2) permuting the clips permutes the results; (3) every clip's note durations add up to its frame count and the
+    note count is positive; (4) both precisions agree to the logit tolerance."""
+    from some_amd import _lib
+    from some_amd.engine import ClipBatch, Engine
+    PACK_TOL = 1e-5
+    cfg = get_config('midi_conformer')
+    sd = synth.synth_state_dict(cfg, 1)
+    clips = [synth.synth_clip(i, 30.0) for i in range(4)]
+    waves = [clips[i % 4] for i in range(32)]
+    hop = cfg['hop_size']
+
+    def run(engine, wave_list):
+        batch = ClipBatch.from_sample_counts([len(w) for w in wave_list], hop, 'cuda')
+        audio = torch.from_numpy(np.concatenate(wave_list)).cuda()
+        units = engine.logmel(audio, batch)
+        probs, bounds = engine.forward(units, batch, head_mode=_lib.HEAD_SIGMOID)
+        dec = engine.decode(probs, bounds, batch, quantized=False)
+        return batch, probs, bounds, dec
+
+    e3 = Engine(cfg, device='cuda')
+    e3.load_state_dict(sd)
+    batch, probs, bounds, dec = run(e3, waves)
+    T = 1 + len(clips[0]) // hop
+    assert batch.total_frames == 32 * T == 82688
+    n = dec['n_notes'].cpu().numpy()
+    dur = dec['note_dur'].cpu().numpy()
+    for b in range(32):                                   # (3)
+        s = int(batch.frame_offsets[b])
+        assert n[b] > 0 and int(dur[s:s + n[b]].sum()) == T
+    # (1) clip 5 (= clips[1]) inside the batch vs alone
+    _, p1, b1, d1 = run(e3, [clips[1]])
+    s5 = int(batch.frame_offsets[5])
+    assert float((probs[s5:s5 + T] - p1).abs().max()) < PACK_TOL and float((bounds[s5:s5 + T] - b1).abs().max()) < PACK_TOL
+    # identical clips at different positions (5, 9, 13 are all clips[1]) give the same thing to the same tolerance
+    for other in (9, 13):
+        so = int(batch.frame_offsets[other])
+        assert float((probs[s5:s5 + T] - probs[so:so + T]).abs().max()) < PACK_TOL
+    # (2) reversed batch order: clip b moves to 31 - b
+    batch_r, probs_r, bounds_r, _ = run(e3, waves[::-1])
+    for b in (0, 7, 31):
+        sa, sb = int(batch.frame_offsets[b]), int(batch_r.frame_offsets[31 - b])
+        assert float((probs[sa:sa + T] - probs_r[sb:sb + T]).abs().max()) < PACK_TOL
+    # (4) exact-f32 mode at the same size
+    e1 = Engine(dict(cfg, some_amd_precision='f32'), device='cuda')
+    e1.load_state_dict(sd)
+    _, probs1, bounds1, _ = run(e1, waves)
+    assert float((probs - probs1).abs().max()) < LOGIT_TOL and float((bounds - bounds1).abs().max()) < LOGIT_TOL
