@@ -42,6 +42,9 @@ def main():
     ap.add_argument('--seconds', type=float, default=30.0)
     ap.add_argument('--lay', type=int, default=8)
     ap.add_argument('--dir', default=None, help='dataset directory to (re)use; default: a temporary directory')
+    ap.add_argument('--train_updates', type=int, default=0,
+                    help='train the checkpoint for this many updates on synthetic sung clips first (train.py): random weights emit ~1500 '
+                         'notes per clip, a trained model ~60, and the per-row word alignment scales with the note count')
     args = ap.parse_args()
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -56,7 +59,26 @@ def main():
     if rank == 0 and not (root / 'transcriptions.csv').exists():
         t0 = time.perf_counter()
         build_dataset(root, args.clips, args.seconds)
-        synth.save_checkpoint(get_config('midi_conformer', lay=args.lay), root / 'model' / 'model.ckpt', seed=1)
+        if args.train_updates > 0:
+            import subprocess
+            import yaml
+            cfg = get_config('midi_conformer', lay=args.lay)
+            cfg['lr_scheduler_args'] = {'scheduler_cls': 'lr_scheduler.scheduler.WarmupLR', 'warmup_steps': 40, 'min_lr': 1e-5}
+            cfg['optimizer_args'] = {'optimizer_cls': 'torch.optim.AdamW', 'lr': 3e-4, 'beta1': 0.9, 'beta2': 0.98, 'weight_decay': 0}
+            cfg.update(use_bound_loss=True, use_midi_loss=True, max_batch_size=8, max_batch_frames=80000, clip_grad_norm=1,
+                       val_check_interval=args.train_updates)
+            (root / 'train_cfg').mkdir(exist_ok=True)
+            with open(root / 'train_cfg' / 'midi_conformer.yaml', 'w') as f:
+                yaml.safe_dump(cfg, f)
+            repo = pathlib.Path(__file__).resolve().parents[1]
+            r = subprocess.run([sys.executable, str(repo / 'train.py'), '--config', str(root / 'train_cfg' / 'midi_conformer.yaml'), '--exp_name', 'model',
+                                '--work_dir', str(root), '--synthetic', '64', '--max_updates', str(args.train_updates), '--log_interval', '100'],
+                               capture_output=True, text=True, cwd=repo)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            print([ln for ln in r.stdout.splitlines() if ln.startswith('validation')][-1:])
+            (root / 'model' / f'model_ckpt_steps_{args.train_updates}.ckpt').rename(root / 'model' / 'model.ckpt')
+        else:
+            synth.save_checkpoint(get_config('midi_conformer', lay=args.lay), root / 'model' / 'model.ckpt', seed=1)
         print(f'dataset: {args.clips} x {args.seconds:g} s int16 WAVs written in {time.perf_counter() - t0:.1f} s')
     import batch_infer as bi
     import torch
