@@ -468,6 +468,59 @@ def gen_e2e():
     print('e2e.npz')
 
 
+FULL_CASES = [
+    # name, config (BASELINE.json configs[1] / configs[2]), checkpoint seed, first clip seed
+    ('full_conf', 'midi_conformer', 1, 0),
+    ('full_quant', 'quant_two_head_model', 2, 0),
+]
+FULL_CLIPS = 8          # 8 x 30 s clips per config (T = 2584 each); probs are stored for clip 0 only (1.3 MB each)
+
+
+def gen_fullsize():
+    """The BASELINE configs at their OWN size (30 s clips, T = 2584, lay 8 / lay 3): waveform ->
+    reference MelSpectrogram -> reference midi_conforms -> reference decode, B = 1 per clip as BaseInference.infer runs
+    them (inference/base_infer.py:46-53).  Stored per clip: bounds + decoded notes; probs for clip 0 (and a strided
+    sample of every clip's probs) - this is what the HIP path is gated against at the size the metric is quoted on."""
+    iu = ref_infer_utils
+    out, meta = {}, {}
+    for name, cname, seed, clip0 in FULL_CASES:
+        cfg = get_config(cname)
+        quant = cname.startswith('quant')
+        model, mel = ref_model(cfg, seed), ref_mel(cfg)
+        for ci in range(FULL_CLIPS):
+            w = synth.synth_clip(clip0 + ci, 30.0)
+            with torch.no_grad():
+                units = mel(torch.from_numpy(w)[None]).transpose(1, 2)
+                masks = torch.ones(units.shape[:2], dtype=torch.bool)
+                probs, bounds = model(x=units, f0=None, mask=masks, softmax=quant, sig=not quant)
+                k = f'{name}.clip{ci}'
+                if ci == 0:
+                    out[k + '.probs'] = probs[0].numpy().copy()
+                    out[k + '.units'] = units[0].numpy().copy()
+                out[k + '.probs_s'] = probs[0, 5::37].numpy().copy()          # every 37th frame of every clip
+                out[k + '.bounds'] = bounds[0].numpy().copy()
+                probs *= masks[..., None]
+                bounds *= masks
+                f2i = iu.decode_bounds_to_alignment(bounds) * masks
+                if quant:
+                    midi = probs.argmax(dim=-1)
+                    rest = midi == 128
+                    v = midi.clip(min=0, max=127)
+                else:
+                    v, rest = iu.decode_gaussian_blurred_probs(probs, vmin=cfg['midi_min'], vmax=cfg['midi_max'],
+                                                               deviation=cfg['midi_prob_deviation'], threshold=cfg['rest_threshold'])
+                nm, nd, nmask = iu.decode_note_sequence(f2i, v, ~rest & masks)
+            out[k + '.note_midi'] = nm[0].numpy()
+            out[k + '.note_dur_frames'] = nd[0].numpy().astype(np.int32)
+            out[k + '.note_rest'] = (~nmask)[0].numpy()
+            print(name, ci, 'T', units.shape[1], 'notes', nm.shape[1])
+        meta[name] = dict(config=cname, lay=cfg['midi_extractor_args']['lay'], seed=seed, clip0=clip0, clips=FULL_CLIPS,
+                          seconds=30.0, quant=quant)
+    np.savez_compressed(OUT / 'fullsize.npz', **out)
+    (OUT / 'fullsize.json').write_text(json.dumps(meta, indent=1))
+    print('fullsize.npz')
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -484,3 +537,4 @@ if __name__ == '__main__':
     gen_train()
     gen_lr_schedule()
     gen_e2e()
+    gen_fullsize()

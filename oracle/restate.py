@@ -41,7 +41,9 @@ def mel_filterbank(sr=44100, n_fft=2048, n_mels=80, fmin=40.0, fmax=8000.0) -> n
     Call site: reference modules/rmvpe/spec.py:22-28.  Published algorithm (librosa 0.9.x filters.py):
     n_mels+2 points equally spaced on the HTK mel scale, triangular ramps evaluated on
     ``fftfreqs = linspace(0, sr/2, 1+n_fft/2)``, each band scaled by ``2/(f[i+2]-f[i])`` (Slaney area
-    normalisation), result cast to float32.
+    normalisation).  The two fp32 roundings of librosa's own code (row assignment into a float32 array, then the
+    in-place scale) are reproduced, so the basis is librosa's bit for bit as far as its published source goes;
+    librosa itself is absent here, so this stays "parity unpinned".
     """
     if fmax is None:
         fmax = sr / 2.0
@@ -50,14 +52,16 @@ def mel_filterbank(sr=44100, n_fft=2048, n_mels=80, fmin=40.0, fmax=8000.0) -> n
     mel_f = mel_to_hz_htk(np.linspace(hz_to_mel_htk(fmin), hz_to_mel_htk(fmax), n_mels + 2))
     fdiff = np.diff(mel_f)
     ramps = np.subtract.outer(mel_f, fftfreqs)
-    weights = np.zeros((n_mels, n_bins), dtype=np.float64)
+    # librosa 0.9.x allocates the result in its `dtype` (float32) up front: every triangle row is rounded to fp32 when it
+    # is assigned, and the Slaney scale is then applied IN PLACE (fp32 row x fp64 enorm, product rounded to fp32 again)
+    weights = np.zeros((n_mels, n_bins), dtype=np.float32)
     for i in range(n_mels):
         lower = -ramps[i] / fdiff[i]
         upper = ramps[i + 2] / fdiff[i + 1]
-        weights[i] = np.maximum(0.0, np.minimum(lower, upper))
+        weights[i] = np.maximum(0, np.minimum(lower, upper))
     enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
-    weights *= enorm[:, None]
-    return weights.astype(np.float32)
+    weights *= enorm[:, np.newaxis]
+    return weights
 
 
 def logmel(audio: np.ndarray, config: dict, dtype=torch.float32) -> np.ndarray:

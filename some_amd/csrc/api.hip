@@ -83,8 +83,9 @@ void mel_basis(const SomeConfig& c, std::vector<float>& out) {
         for (int j = 0; j < n_bins; ++j) {
             const double lower = -(melf[i] - fftf[j]) / fd0;
             const double upper = (melf[i + 2] - fftf[j]) / fd1;
-            const double w = std::max(0.0, std::min(lower, upper)) * enorm;
-            out[(size_t)i * n_bins + j] = (float)w;
+            // librosa builds the triangles in a float32 array and scales them in place: two fp32 roundings
+            const float w = (float)std::max(0.0, std::min(lower, upper));
+            out[(size_t)i * n_bins + j] = (float)((double)w * enorm);
         }
     }
 }

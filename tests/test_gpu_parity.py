@@ -544,3 +544,98 @@ def test_full_size_batch_size_independent_properties():
     e1.load_state_dict(sd)
     _, probs1, bounds1, _ = run(e1, waves)
     assert float((probs - probs1).abs().max()) < LOGIT_TOL and float((bounds - bounds1).abs().max()) < LOGIT_TOL
+
+
+# ---- the BASELINE configs at their own size, against the REFERENCE's outputs ---------------------------------------
+def _boundaries(dur_frames):
+    return set(np.cumsum(np.asarray(dur_frames, dtype=np.int64))[:-1].tolist())
+
+
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
+@pytest.mark.parametrize('name', ['full_conf', 'full_quant'])
+def test_fullsize_batch_vs_reference_golden(golden_dir, name, precision):
+    """BASELINE.json configs[1] / configs[2] as bench.py runs them - ONE packed batch of 32 x 30 s clips (82 688 frames,
+    lay 8 / lay 3) through log-mel -> forward -> decode - against what the REFERENCE's own MelSpectrogram + midi_conforms +
+    decoder produced for the same 8 waveforms one by one (tests/golden/fullsize.npz, oracle/make_golden.py::gen_fullsize).
+    Every clip sits at four batch positions.  Gates: |d probs|, |d bounds| < 1e-4 (north star) at every position;
+    the reference's own probs / bounds through the GPU decoder give the reference's notes bit for bit; end-to-end
+    (waveform -> notes) note boundaries may differ from the reference's only where a bound cumsum sits within the
+    logit tolerance of a rounding boundary: bounded at 1 % of the boundaries, reported."""
+    from some_amd import _lib
+    from some_amd.engine import ClipBatch, Engine
+    meta = json.loads((golden_dir / 'fullsize.json').read_text())[name]
+    g = np.load(golden_dir / 'fullsize.npz')
+    cfg = get_config(meta['config'], some_amd_precision=precision)
+    quant = meta['quant']
+    eng = Engine(cfg, device='cuda')
+    eng.load_state_dict(synth.synth_state_dict(cfg, meta['seed']))
+    nclip = meta['clips']
+    clips = [synth.synth_clip(meta['clip0'] + i, meta['seconds']) for i in range(nclip)]
+    order = [(p + p // nclip) % nclip for p in range(32)]           # rotate each group of 8 so neighbours differ
+    waves = [clips[c] for c in order]
+    batch = ClipBatch.from_sample_counts([len(w) for w in waves], cfg['hop_size'], 'cuda')
+    assert batch.total_frames == 32 * 2584
+    units = eng.logmel(torch.from_numpy(np.concatenate(waves)).cuda(), batch)
+    probs, bounds = eng.forward(units, batch, head_mode=_lib.HEAD_SOFTMAX if quant else _lib.HEAD_SIGMOID)
+    dec = eng.decode(probs, bounds, batch, quantized=quant)
+    probs, bounds = probs.cpu().numpy(), bounds.cpu().numpy()
+    n_notes = dec['n_notes'].cpu().numpy()
+    dur = dec['note_dur'].cpu().numpy()
+    rest = dec['note_rest'].cpu().numpy().astype(bool)
+    midi = dec['note_midi'].cpu().numpy()
+    T = 2584
+    err_p = err_b = 0.0
+    n_bound_ref = n_bound_diff = n_identical = 0
+    midi_err = 0.0
+    for p, c in enumerate(order):
+        s = int(batch.frame_offsets[p])
+        k = f'{name}.clip{c}'
+        err_b = max(err_b, float(np.abs(bounds[s:s + T] - g[k + '.bounds']).max()))
+        err_p = max(err_p, float(np.abs(probs[s:s + T][5::37] - g[k + '.probs_s']).max()))
+        if c == 0:
+            err_p = max(err_p, float(np.abs(probs[s:s + T] - g[k + '.probs']).max()))
+        n = int(n_notes[p])
+        assert int(dur[s:s + n].sum()) == T
+        ref_dur = g[k + '.note_dur_frames']
+        mine, ref = _boundaries(dur[s:s + n]), _boundaries(ref_dur)
+        n_bound_ref += len(ref)
+        n_bound_diff += len(mine ^ ref)
+        if n == len(ref_dur) and np.array_equal(dur[s:s + n], ref_dur):
+            n_identical += 1
+            both = ~rest[s:s + n] & ~g[k + '.note_rest']
+            if both.any():
+                midi_err = max(midi_err, float(np.abs(midi[s:s + n][both] - g[k + '.note_midi'][both]).max()))
+    print(f'{name} [{precision}] 32 x 30 s: max|dprob|={err_p:.3e} max|dbound|={err_b:.3e}; note boundaries differing from the '
+          f'reference end to end: {n_bound_diff} of {n_bound_ref} ({100.0 * n_bound_diff / n_bound_ref:.3f} %), '
+          f'{n_identical}/32 clips with an identical duration sequence, max |d note_midi| on those {midi_err:.2e}')
+    assert err_p < LOGIT_TOL and err_b < LOGIT_TOL
+    assert n_bound_diff <= 0.01 * n_bound_ref
+    # identical inputs -> identical notes at full size: the reference's probs / bounds of clip 0 through the GPU decoder
+    k = f'{name}.clip0'
+    d0 = eng.decode(torch.from_numpy(g[k + '.probs']).cuda(), torch.from_numpy(g[k + '.bounds']).cuda(), ClipBatch([T], 'cuda'), quantized=quant)
+    n = int(d0['n_notes'][0])
+    np.testing.assert_array_equal(d0['note_dur'].cpu().numpy()[:n], g[k + '.note_dur_frames'])
+    np.testing.assert_array_equal(d0['note_rest'].cpu().numpy()[:n].astype(bool), g[k + '.note_rest'])
+    np.testing.assert_allclose(d0['note_midi'].cpu().numpy()[:n], g[k + '.note_midi'], rtol=1e-6, atol=0)
+
+
+def test_logmel_fullsize_error_budget(golden_dir):
+    """Log-mel of a whole 30 s clip against the reference's MelSpectrogram (tests/golden/fullsize.npz): the error is gated
+    separately away from the clamp floor (log(max(mel, 1e-5)): d log = d mel / mel, so the same absolute mel error is
+    amplified up to 1e5 x next to the floor) and overall."""
+    from some_amd.engine import ClipBatch, Engine
+    g = np.load(golden_dir / 'fullsize.npz')
+    want = g['full_conf.clip0.units']
+    eng = Engine(get_config('midi_conformer', lay=0), device='cuda')
+    w = synth.synth_clip(0, 30.0)
+    batch = ClipBatch.from_sample_counts([len(w)], 512, 'cuda')
+    got = eng.logmel(torch.from_numpy(w).cuda(), batch).cpu().numpy()
+    err = np.abs(got - want)
+    floor = np.log(np.float32(1e-5))
+    away = want > floor + np.log(100.0)            # mel >= 1e-3: two decades above the clamp
+    near = ~away
+    i = np.unravel_index(err.argmax(), err.shape)
+    print(f'log-mel 30 s: max|d| overall {err.max():.3e} at frame {i[0]} band {i[1]} (reference value {want[i]:.3f}); '
+          f'mel >= 1e-3 ({away.mean() * 100:.1f} % of bins): {err[away].max():.3e}; below: {err[near].max() if near.any() else 0:.3e}')
+    assert err[away].max() < 1e-5
+    assert err.max() < 2e-4

@@ -110,3 +110,24 @@ def test_end_to_end_clip(golden_dir, name):
     np.testing.assert_array_equal(dec['note_dur'], g[name + '.note_dur'])
     np.testing.assert_array_equal(dec['note_rest'], g[name + '.note_rest'])
     np.testing.assert_allclose(dec['note_midi'], g[name + '.note_midi'], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize('name', ['full_quant', 'full_conf'])
+def test_fullsize_clip_oracle_vs_reference(golden_dir, name):
+    """The oracle at the BASELINE configs' OWN size (one 30 s clip, T = 2584, lay 3 / lay 8) against the reference's
+    outputs for that clip, so the restatement that bench.py times as `cpu_baseline` is pinned where the metric is quoted."""
+    meta = json.loads((golden_dir / 'fullsize.json').read_text())[name]
+    g = np.load(golden_dir / 'fullsize.npz')
+    cfg = get_config(meta['config'])
+    sd = synth.synth_state_dict(cfg, meta['seed'])
+    w = synth.synth_clip(meta['clip0'], meta['seconds'])
+    k = name + '.clip0'
+    np.testing.assert_allclose(restate.logmel(w, cfg), g[k + '.units'], rtol=0, atol=1e-6)
+    res = restate.infer_clip(sd, cfg, w)
+    assert res['_probs'].shape == g[k + '.probs'].shape == (2584, cfg['midi_num_bins'])
+    np.testing.assert_allclose(res['_probs'], g[k + '.probs'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(res['_bounds'], g[k + '.bounds'], rtol=0, atol=2e-5)
+    dec = restate.postprocess(g[k + '.probs'], g[k + '.bounds'], cfg, quantized=meta['quant'])
+    np.testing.assert_array_equal(dec['note_dur'], g[k + '.note_dur_frames'] * (512 / 44100))
+    np.testing.assert_array_equal(dec['note_rest'], g[k + '.note_rest'])
+    np.testing.assert_allclose(dec['note_midi'], g[k + '.note_midi'], rtol=1e-6, atol=0)
