@@ -64,7 +64,7 @@ def mel_filterbank(sr=44100, n_fft=2048, n_mels=80, fmin=40.0, fmax=8000.0) -> n
     return weights
 
 
-def logmel(audio: np.ndarray, config: dict, dtype=torch.float32) -> np.ndarray:
+def logmel(audio: np.ndarray, config: dict, dtype=torch.float32, keep_dtype=False) -> np.ndarray:
     """reference modules/rmvpe/spec.py:38-72 with keyshift=0, speed=1, center=True, then the transpose of
     inference/me_infer.py:31.  audio [L] -> units [T, n_mels], T = 1 + L // hop."""
     win, hop = config['win_size'], config['hop_size']
@@ -78,7 +78,8 @@ def logmel(audio: np.ndarray, config: dict, dtype=torch.float32) -> np.ndarray:
     mag = spec.abs()                                                           # spec.py:61
     mel = torch.matmul(basis, mag)                                             # spec.py:70
     out = torch.log(torch.clamp(mel, min=1e-5))                                # spec.py:71
-    return out[0].transpose(0, 1).contiguous().to(torch.float32).numpy()
+    out = out[0].transpose(0, 1).contiguous()
+    return (out if keep_dtype else out.to(torch.float32)).numpy()       # keep_dtype: the fp64 yardstick of the error-budget test
 
 
 # --------------------------------------------------------------------------------------------------

@@ -4,7 +4,9 @@ and reused while the checkpoint file is unchanged, so a process start costs one 
 ``torch.load`` + ``some_pack_weights``.
 
 File: 64-byte header (magic, format version, arena element count, precision, checkpoint size and mtime in ns, a CRC of
-the hot-path config keys) followed by the raw little-endian fp32 arena.  Any mismatch - or any I/O error - means "no
+the hot-path config keys, a CRC of the ``libsome_amd.so`` that packed it) followed by the raw little-endian fp32 arena.
+The library CRC ties a cache file to the exact binary whose ``some_pack_weights`` laid it out: any rebuild that could
+have changed the arena layout or the folding arithmetic invalidates every cache by itself, with no version to bump.  Any mismatch - or any I/O error - means "no
 cache": the caller packs from the checkpoint as before."""
 import os
 import pathlib
@@ -15,8 +17,20 @@ from typing import Optional
 import numpy as np
 
 MAGIC = b'SOMEAMD1'
-_HEADER = struct.Struct('<8sIQIQQI20x')          # magic, version, numel, precision, ckpt size, ckpt mtime_ns, config crc
-VERSION = 2
+_HEADER = struct.Struct('<8sIQIQQII16x')         # magic, version, numel, precision, ckpt size, ckpt mtime_ns, config crc, library crc
+VERSION = 3
+_lib_crc_cache = {}
+
+
+def _library_crc() -> int:
+    from . import _lib
+    path = pathlib.Path(_lib.LIB_PATH)
+    st = path.stat()
+    key = (str(path), st.st_size, st.st_mtime_ns)
+    if key not in _lib_crc_cache:
+        _lib_crc_cache.clear()
+        _lib_crc_cache[key] = zlib.crc32(path.read_bytes())
+    return _lib_crc_cache[key]
 
 
 def _config_crc(config: dict) -> int:
@@ -38,8 +52,7 @@ def load(ckpt: pathlib.Path, numel: int, precision: int, config: dict) -> Option
             head = f.read(_HEADER.size)
             if len(head) != _HEADER.size:
                 return None
-            magic, version, n, prec, size, mtime, crc = _HEADER.unpack(head)
-            if (magic, version, n, prec, size, mtime, crc) != (MAGIC, VERSION, numel, precision, st.st_size, st.st_mtime_ns, _config_crc(config)):
+            if _HEADER.unpack(head) != (MAGIC, VERSION, numel, precision, st.st_size, st.st_mtime_ns, _config_crc(config), _library_crc()):
                 return None
             arena = np.fromfile(f, dtype='<f4', count=numel)
         return arena if arena.shape[0] == numel else None
@@ -54,7 +67,7 @@ def store(ckpt: pathlib.Path, arena: np.ndarray, precision: int, config: dict) -
     try:
         st = os.stat(ckpt)
         with open(tmp, 'wb') as f:
-            f.write(_HEADER.pack(MAGIC, VERSION, int(arena.shape[0]), precision, st.st_size, st.st_mtime_ns, _config_crc(config)))
+            f.write(_HEADER.pack(MAGIC, VERSION, int(arena.shape[0]), precision, st.st_size, st.st_mtime_ns, _config_crc(config), _library_crc()))
             np.ascontiguousarray(arena, dtype='<f4').tofile(f)
         os.replace(tmp, path)
         return True

@@ -24,15 +24,16 @@ class BaseInference:
         self.timestep = self.config['hop_size'] / self.config['audio_sample_rate']
         self.model: torch.nn.Module = self.build_model()
 
-    def build_model(self) -> nn.Module:
+    def build_model(self, local: bool = False) -> nn.Module:
         """base_infer.py:23-35: build ``model_cls``, load ``ckpt['state_dict']`` entries under ``model.``,
-        strict."""
+        strict.  ``local=True`` loads on THIS process only, with no collective - for rebuilds that a single rank of a
+        sharded job decides on its own (the precision fallback in me_infer.py): the other ranks are not in a broadcast."""
         model: nn.Module = build_object_from_class_name(
             self.config['model_cls'], nn.Module, config=self.config
         ).eval().to(self.device)
         prefix_in_ckpt = 'model'
         import torch.distributed as dist
-        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        sharded = (not local) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.loaded_from_cache = False
         if hasattr(model, 'load_packed_arena'):
             # the packed arena is cached next to the checkpoint (some_amd/arena_cache.py) and, with one process per GPU,

@@ -69,7 +69,9 @@ class MIDIExtractionInference(BaseInference):
             print('WARNING: activations left the f16 range of the split-f16 matrix path; switching this model to the exact-f32 '
                   'kernels (set `some_amd_precision: f32` in config.yaml to start there)')
             self.config = dict(self.config, some_amd_precision='f32')
-            self.model = self.build_model()
+            # a range overflow depends on the rows THIS rank was dealt: the rebuild must not enter a collective the
+            # other ranks of a sharded job never join (they are on their way to gather_object / barrier)
+            self.model = self.build_model(local=True)
             self.engine = self.model.engine
             return fn(*args, **kw)
 
@@ -199,10 +201,13 @@ class MIDIExtractionInference(BaseInference):
         view = pin.numpy()
         pos = 0
         for c, n in zip(clips, lens):
-            if dtype == np.int16:
-                view[pos:pos + n] = c
+            if c.dtype == np.int16:
+                # int16 PCM as stored in the WAV: value = x / 32768 (librosa.load's scaling); stays int16 when every file is
+                view[pos:pos + n] = c if dtype == np.int16 else c.astype(np.float32) / np.float32(32768.0)
+            elif c.dtype.kind == 'f':
+                view[pos:pos + n] = c                      # float waveforms are already in [-1, 1]: no scaling
             else:
-                view[pos:pos + n] = c if c.dtype == np.float32 else c.astype(np.float32) / np.float32(32768.0)
+                raise TypeError(f'infer_files takes int16 PCM or floating-point waveforms, got {c.dtype}')
             pos += int(n)
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=self.device)

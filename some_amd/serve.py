@@ -26,6 +26,11 @@ def build_app(service, work_dir: pathlib.Path):
 
     @app.post('/infer')
     async def infer(request: Request, model: str, tempo: float = 120.0):
+        # only names GET /models lists are served (webui.py:82-88: a closed dropdown of work_dir.rglob('*.ckpt'))
+        try:
+            service.resolve_model(model)
+        except (PermissionError, FileNotFoundError):
+            return JSONResponse({'error': f'Error: unknown model: {model}'}, status_code=404)
         body = await request.body()
         if not body:
             return JSONResponse({'error': 'Error: required inputs not specified.'}, status_code=400)

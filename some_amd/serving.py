@@ -9,6 +9,7 @@ host).  No request waits for a timer: an idle service starts a lone request at o
     midi_path, stats = svc.extract_midi('some_model/model.ckpt', 'song.wav', tempo=120)      # webui.infer semantics
     fut = svc.submit('some_model/model.ckpt', pcm_int16)                                     # -> Future of [(offset_s, notes)]
 """
+import collections
 import pathlib
 import queue
 import threading
@@ -23,11 +24,12 @@ MAX_DURATION_S = 20 * 60          # webui.py:43-44
 
 
 class ExtractionService:
-    def __init__(self, work_dir=None, device=None, max_batch_frames: int = 131072):
+    def __init__(self, work_dir=None, device=None, max_batch_frames: int = 131072, max_models: int = 4):
         self.work_dir = pathlib.Path(work_dir) if work_dir is not None else None
         self.device = device
         self.max_batch_frames = max_batch_frames
-        self._instances: Dict[str, Tuple[object, dict]] = {}
+        self.max_models = max(1, int(max_models))
+        self._instances: 'collections.OrderedDict[str, Tuple[object, dict]]' = collections.OrderedDict()
         self._queue: 'queue.Queue' = queue.Queue()
         self._closed = False
         self.batches_run = 0              # observability: device batches / requests served so far
@@ -36,19 +38,41 @@ class ExtractionService:
         self._thread.start()
 
     # ---- model cache (webui.py:24-40) -------------------------------------------------------------------
+    def resolve_model(self, model_path) -> pathlib.Path:
+        """Map a client-supplied model name to a checkpoint file.  With a ``work_dir`` (the served case) only ``*.ckpt``
+        files INSIDE it are accepted - the reference's web UI offers exactly ``work_dir.rglob('*.ckpt')`` in a closed
+        dropdown (webui.py:82-88, allow_custom_value=False) - so absolute paths, ``..`` and symlinks that leave the
+        directory are refused.  Without a ``work_dir`` (library use by trusted code) any existing checkpoint path goes."""
+        path = pathlib.Path(model_path)
+        if self.work_dir is not None:
+            root = self.work_dir.resolve()
+            if path.is_absolute():
+                raise PermissionError(f'model must be a path relative to the work directory: {model_path}')
+            path = (root / path).resolve()
+            if not path.is_relative_to(root):
+                raise PermissionError(f'model is outside the work directory: {model_path}')
+        else:
+            path = path.resolve()
+        if path.suffix != '.ckpt' or not path.is_file():
+            raise FileNotFoundError(f'no such checkpoint: {model_path}')
+        return path
+
     def _instance(self, model_path) -> Tuple[object, dict]:
-        """Called on the dispatcher thread only."""
-        key = str(model_path)
-        if key not in self._instances:
-            from .inference.loader import resolve_inference_class
-            path = pathlib.Path(model_path)
-            if self.work_dir is not None and not path.is_absolute():
-                path = self.work_dir / path
-            with open(path.with_name('config.yaml'), 'r', encoding='utf8') as f:
-                config = yaml.safe_load(f)
-            ins = resolve_inference_class(config['task_cls'])(config=config, model_path=path, device=self.device)
-            ins.max_batch_frames = self.max_batch_frames
-            self._instances[key] = (ins, config)
+        """Called on the dispatcher thread only.  Instances are cached per RESOLVED checkpoint path (different spellings
+        of one file share an instance) in a small LRU (``max_models``) so clients cannot pile models up in HBM."""
+        path = self.resolve_model(model_path)
+        key = str(path)
+        if key in self._instances:
+            self._instances.move_to_end(key)
+            return self._instances[key]
+        from .inference.loader import resolve_inference_class
+        with open(path.with_name('config.yaml'), 'r', encoding='utf8') as f:
+            config = yaml.safe_load(f)
+        ins = resolve_inference_class(config['task_cls'])(config=config, model_path=path, device=self.device)
+        ins.max_batch_frames = self.max_batch_frames
+        self._instances[key] = (ins, config)
+        while len(self._instances) > self.max_models:
+            self._instances.popitem(last=False)
         return self._instances[key]
 
     # ---- request side -------------------------------------------------------------------------------------
@@ -70,7 +94,10 @@ class ExtractionService:
         if not model_rel_path or not input_audio_path or tempo_value is None:
             return None, 'Error: required inputs not specified.'
         input_audio_path = pathlib.Path(input_audio_path)
-        _, config = self._call_on_dispatcher(lambda: self._instance(model_rel_path))
+        try:
+            _, config = self._call_on_dispatcher(lambda: self._instance(model_rel_path))
+        except (PermissionError, FileNotFoundError):
+            return None, f'Error: unknown model: {model_rel_path}'
         try:
             samples, sr = load_pcm(input_audio_path, sr=config['audio_sample_rate'])
         except Exception:  # noqa: BLE001  (webui.py:48-49: any decode failure is reported, not raised)

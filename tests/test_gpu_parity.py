@@ -620,22 +620,62 @@ def test_fullsize_batch_vs_reference_golden(golden_dir, name, precision):
 
 
 def test_logmel_fullsize_error_budget(golden_dir):
-    """Log-mel of a whole 30 s clip against the reference's MelSpectrogram (tests/golden/fullsize.npz): the error is gated
-    separately away from the clamp floor (log(max(mel, 1e-5)): d log = d mel / mel, so the same absolute mel error is
-    amplified up to 1e5 x next to the floor) and overall."""
+    """Log-mel of a whole 30 s clip against the reference's MelSpectrogram (tests/golden/fullsize.npz).
+
+    What bounds the agreement is the reference's OWN fp32 round-off, not this kernel: an fp32 FFT leaves an absolute
+    error of about eps * |frame| in EVERY bin, so a mel band 4-5 decades below the frame's loudest partial carries a
+    relative error of 1e-5..1e-4, and log() turns relative error into absolute.  Measured with the fp64 oracle as the
+    yardstick (this clip): the reference's torch.stft path is itself 2.0e-4 off at the clamp floor and 6.9e-5 off for
+    mel in [1e-3, 1e-2), 7e-6 for [1e-2, 0.1), 1e-6 above.  So the gate is per decade of mel energy: the HIP kernel
+    must be no further from fp64 than twice the reference is (+1e-6), and within 2e-4 of the reference everywhere -
+    the <= 1e-5 figure of SURVEY.md section 7 is reachable (against fp64) from mel >= 1e-2 upwards and not below, for ANY fp32 FFT."""
+    from oracle import restate
     from some_amd.engine import ClipBatch, Engine
     g = np.load(golden_dir / 'fullsize.npz')
     want = g['full_conf.clip0.units']
-    eng = Engine(get_config('midi_conformer', lay=0), device='cuda')
+    cfg = get_config('midi_conformer', lay=0)
+    eng = Engine(cfg, device='cuda')
     w = synth.synth_clip(0, 30.0)
     batch = ClipBatch.from_sample_counts([len(w)], 512, 'cuda')
     got = eng.logmel(torch.from_numpy(w).cuda(), batch).cpu().numpy()
-    err = np.abs(got - want)
-    floor = np.log(np.float32(1e-5))
-    away = want > floor + np.log(100.0)            # mel >= 1e-3: two decades above the clamp
-    near = ~away
-    i = np.unravel_index(err.argmax(), err.shape)
-    print(f'log-mel 30 s: max|d| overall {err.max():.3e} at frame {i[0]} band {i[1]} (reference value {want[i]:.3f}); '
-          f'mel >= 1e-3 ({away.mean() * 100:.1f} % of bins): {err[away].max():.3e}; below: {err[near].max() if near.any() else 0:.3e}')
-    assert err[away].max() < 1e-5
-    assert err.max() < 2e-4
+    u64 = restate.logmel(w.astype(np.float64), cfg, dtype=torch.float64, keep_dtype=True)
+    e_gpu, e_ref, e_pair = np.abs(got - u64), np.abs(want - u64), np.abs(got - want)
+    i = np.unravel_index(e_pair.argmax(), e_pair.shape)
+    print(f'log-mel 30 s vs reference: max|d| {e_pair.max():.3e} at frame {i[0]} band {i[1]} (reference value {want[i]:.3f})')
+    mel = np.exp(u64)
+    for lo, hi in [(0.0, 1e-4), (1e-4, 1e-3), (1e-3, 1e-2), (1e-2, 1e-1), (1e-1, 1.0), (1.0, 1e9)]:
+        m = (mel >= lo) & (mel < hi)
+        if not m.any():
+            continue
+        print(f'  mel in [{lo:g}, {hi:g}): {int(m.sum())} bins; vs fp64: HIP {e_gpu[m].max():.2e}, reference {e_ref[m].max():.2e}; HIP vs reference {e_pair[m].max():.2e}')
+        assert e_gpu[m].max() <= 2.0 * e_ref[m].max() + 1e-6
+    hi_energy = mel >= 1e-2
+    assert e_pair[hi_energy].max() < 2e-5            # both sides are <= 7e-6 from fp64 there
+    assert e_pair.max() < 2.5e-4
+
+
+def test_bench_two_ranks_share_the_gpu_gloo():
+    """bench.py's N > 1 path executed end to end on this box's ONE GPU: `torch.distributed.run --nproc-per-node 2`, gloo
+    standing in for RCCL (SOME_AMD_DIST_BACKEND), rank 0 packs + broadcasts the arena, both ranks run their own clips, the
+    barrier / max-over-ranks timing and the single JSON line are rank 0's.  (Real RCCL needs two GPUs: the driver's SCALE run.)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = __import__('pathlib').Path(__file__).resolve().parents[1]
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SOME_AMD_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(root / 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--lay', '1',
+           '--batch', '4', '--seconds', '5', '--no-cpu-baseline', '--no-f32-leg', '--no-latency', '--no-secondary']
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                   # rank 0 only
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['steps'] == 2
+    # whole-job value: both ranks' audio over the max-over-ranks time
+    assert abs(res['value'] - 2 * 4 * 5.0 * 2 / (res['ms_per_step'] * 2e-3)) < 0.02 * res['value']
+    assert res['notes_decoded_last_step'] > 0

@@ -36,7 +36,8 @@ def test_concurrent_requests_are_batched_and_match_direct_calls(tmp_path):
             t.join()
         assert svc.requests_served == len(files) + 1
         assert svc.batches_run < svc.requests_served                      # some requests shared a device batch
-        ins, _ = svc._instances['exp/model.ckpt']
+        ins, _ = svc._instances[str(svc.resolve_model('exp/model.ckpt'))]
+        assert len(svc._instances) == 1                                   # './exp/../exp/model.ckpt' style spellings share it
         slicer = Slicer(sr=44100, max_sil_kept=1000)
         for i, f in enumerate(files):
             direct = ins.infer_files([f], slicer)[0]

@@ -102,8 +102,39 @@ def test_wav_roundtrip_and_rate_check(tmp_path):
     save_wav(tmp_path / 'a.wav', y, 44100)
     z, sr = load_wav(tmp_path / 'a.wav', 44100)
     assert sr == 44100 and z.dtype == np.float32 and np.abs(z - y).max() <= 1 / 32768 + 1e-7
-    with pytest.raises(NotImplementedError):
-        load_wav(tmp_path / 'a.wav', 16000)
+
+
+@pytest.mark.parametrize('file_sr', [48000, 22050, 32000])
+def test_wav_loader_resamples_like_librosa_kaiser_best(tmp_path, file_sr):
+    """librosa.load(path, sr=44100) accepts any source rate (infer.py:34, batch_infer.py:51).  The restated resampy
+    'kaiser_best' interpolation is checked against the analytic answer (a sum of sinusoids is its own band-limited
+    interpolant) and against scipy's polyphase resampler; length follows librosa's fix_length(ceil(n * ratio))."""
+    from scipy.signal import resample_poly
+    from some_amd.utils.audio import load_pcm, load_wav, resample, save_wav
+    sr, secs = 44100, 0.5
+    freqs, amps = (220.0, 1234.5, 5000.0), (0.3, 0.2, 0.1)
+
+    def tone(rate):
+        t = np.arange(int(secs * rate)) / rate
+        return sum(a * np.sin(2 * np.pi * f * t) for f, a in zip(freqs, amps)).astype(np.float32)
+
+    y = resample(tone(file_sr), file_sr, sr)
+    assert y.dtype == np.float32 and len(y) == int(np.ceil(int(secs * file_sr) * sr / file_sr))
+    want = tone(sr)
+    n = min(len(y), len(want))
+    edge = 2000                                           # the 64-zero-crossing filter is truncated at the ends
+    assert np.abs(y[edge:n - edge] - want[edge:n - edge]).max() < 2e-4
+    import math
+    g = math.gcd(sr, file_sr)
+    poly = resample_poly(tone(file_sr).astype(np.float64), sr // g, file_sr // g)
+    assert np.abs(y[edge:n - edge] - poly[edge:n - edge]).max() < 2e-3
+    # through the file loaders (int16 PCM on disk): both entry points resample, stereo is averaged first
+    save_wav(tmp_path / 'a.wav', tone(file_sr), file_sr)
+    z, got_sr = load_wav(tmp_path / 'a.wav', sr)
+    assert got_sr == sr and z.dtype == np.float32 and np.abs(z[edge:n - edge] - want[edge:n - edge]).max() < 5e-4
+    z2, _ = load_pcm(tmp_path / 'a.wav', sr)
+    np.testing.assert_array_equal(z, z2)
+    assert resample(want, sr, sr) is not None and np.array_equal(resample(want, sr, sr), want)
 
 
 def test_config_inheritance(tmp_path, monkeypatch):
@@ -144,8 +175,9 @@ def test_extraction_service_dispatch_logic(tmp_path):
     gate = threading.Event()
     files = [np.clip(np.round(synth.synth_clip(500 + i, 1.0 + i).astype(np.float64) * 32768), -32768, 32767).astype(np.int16)
              for i in range(6)]
+    (tmp_path / 'm.ckpt').write_bytes(b'')
     with ExtractionService(work_dir=tmp_path) as svc:
-        svc._instances['m.ckpt'] = (Stub(), get_config('midi_conformer'))
+        svc._instances[str(svc.resolve_model('m.ckpt'))] = (Stub(), get_config('midi_conformer'))
         futs = [svc.submit('m.ckpt', files[0])]           # occupies the dispatcher (blocked on the gate) ...
         while not calls:
             pass
@@ -194,7 +226,7 @@ def test_align_pool_matches_inline(tmp_path):
         bad.close()
 
 
-def test_arena_cache_file_validation(tmp_path):
+def test_arena_cache_file_validation(tmp_path, monkeypatch):
     """The cached flat weight file is used only while checkpoint size / mtime, arena size, precision and the model shape
     keys all match; anything else (or a truncated file) reads as 'no cache'."""
     from some_amd import arena_cache
@@ -217,6 +249,10 @@ def test_arena_cache_file_validation(tmp_path):
     assert arena_cache.load(ckpt, 1000, 1, cfg) is None
     ro = tmp_path / 'missing_dir' / 'm.ckpt'
     assert arena_cache.store(ro, arena, 1, cfg) is False                      # unwritable: best effort
+    # a rebuilt libsome_amd.so (possibly another arena layout / folding) must not be handed an old cache file
+    assert arena_cache.store(ckpt, arena, 1, cfg) and arena_cache.load(ckpt, 1000, 1, cfg) is not None
+    monkeypatch.setattr(arena_cache, '_library_crc', lambda: 0x12345678)
+    assert arena_cache.load(ckpt, 1000, 1, cfg) is None
 
 
 def test_http_front_of_the_service(tmp_path):
@@ -234,9 +270,19 @@ def test_http_front_of_the_service(tmp_path):
     wav = tmp_path / 'a.wav'
     save_wav(wav, synth.synth_clip(2, 2.0), 44100)
     with ExtractionService(work_dir=tmp_path) as svc:
-        svc._instances['exp/m.ckpt'] = (dataset_util.FakeIngestInference(), get_config('midi_conformer'))
+        svc._instances[str(svc.resolve_model('exp/m.ckpt'))] = (dataset_util.FakeIngestInference(), get_config('midi_conformer'))
         client = TestClient(build_app(svc, tmp_path))
         assert client.get('/models').json() == {'models': ['exp/m.ckpt']}
+        # only checkpoints inside the work directory are served (webui.py:82-88 offers a closed list): no absolute paths,
+        # no '..', no other suffixes - and different spellings of one file share one cached instance
+        outside = tmp_path.parent / 'outside.ckpt'
+        outside.write_bytes(b'')
+        for bad in (str(outside), '../outside.ckpt', 'exp/../../outside.ckpt', 'exp/config.yaml', 'exp/nope.ckpt', '/etc/passwd'):
+            r = client.post('/infer', params={'model': bad}, content=wav.read_bytes())
+            assert r.status_code == 404 and 'unknown model' in r.json()['error'], bad
+            assert svc.extract_midi(bad, wav, 120) == (None, f'Error: unknown model: {bad}')
+        r = client.post('/infer', params={'model': './exp/../exp/m.ckpt', 'tempo': 100}, content=wav.read_bytes())
+        assert r.status_code == 200 and len(svc._instances) == 1
         r = client.post('/infer', params={'model': 'exp/m.ckpt', 'tempo': 100}, content=wav.read_bytes())
         assert r.status_code == 200 and r.content[:4] == b'MThd' and r.headers['x-some-stats'].startswith('Cost ')
         r = client.post('/infer', params={'model': 'exp/m.ckpt'}, content=b'junk')
