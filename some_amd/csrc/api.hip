@@ -195,6 +195,7 @@ int some_create(const SomeConfig* cfg, SomeHandle** out) {
     h->precision = cfg->precision;
     h->tile = -1;                                    // -1: pick per launch from the grid size
     if (const char* t = getenv("SOME_AMD_TILE")) h->tile = atoi(t);
+    if (const char* t = getenv("SOME_AMD_GEMM_FLAGS")) h->gemm_flags = atoi(t);
     build_layout(h->cfg, h->lay);
     *out = h;
     return SOME_OK;
@@ -452,7 +453,7 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
         return launch_gemm(epi, a, s);
     };
     auto gemm = [&](const char* name, GemmEpi epi, GemmArgs& a, int n_out_total, bool out_split = false) -> int {
-        a.groups = kStreams; a.M = M;
+        a.groups = kStreams; a.M = M; a.flags = h->gemm_flags;
         const double flops = 2.0 * Md * a.K * n_out_total;
         Scope sc(h, s, name, flops, 0.0);
         hipError_t e = launch_any(epi, a, out_split, n_out_total / kStreams);
@@ -662,7 +663,7 @@ int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t ld
     if ((epilogue == EPI_GLU || epilogue == EPI_GLU_RES) && (N % 64)) return fail(h, SOME_EINVAL, "some_op_gemm: GLU epilogue needs N % 64 == 0");
     GemmArgs a{};
     a.g[0] = GemmGroup{A_dev, W_dev, bias_dev, res_dev, C_dev, row_mask_dev, N, act};
-    a.groups = 1; a.M = M; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.alpha = alpha;
+    a.groups = 1; a.M = M; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.alpha = alpha; a.flags = h->gemm_flags;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(h, s, "op_gemm", 2.0 * M * (double)N * K, 0.0);
     if (flags & SOME_GEMM_SPLIT_IN) {

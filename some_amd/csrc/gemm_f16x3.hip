@@ -168,9 +168,89 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const GemmGroup& g, 
     }
 }
 
+// ---- transposed accumulator layout (TR) ------------------------------------------------------------------------------
+// acc = mfma(W fragment, A fragment): D rows <- W rows (n), D columns <- activation rows (m).  A lane then owns ONE
+// output row m (= lane & 31) and, per 32-column MFMA tile, 16 CONSECUTIVE columns: the W fragment of D-row position
+// p = 4h + 8q + e is read from W row pi(p) = 16h + 4q + e (conflict-free like the identity: the rows of one ds_read_b128
+// lane group stay distinct mod 16), so accumulator register r of lane-half h is column 16h + r.  The epilogue therefore
+// moves 64 contiguous bytes per lane and tile with 16-byte buffer instructions (a quarter of the memory instructions of
+// the column-per-lane layout, no DPP exchange for SPLIT32 output, per-row quantities - residual row, mask, LayerNorm
+// statistics - are per-lane scalars), cf. cdna guide T21.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int pi32(int p) { return ((p >> 2) & 1) * 16 + (p >> 3) * 4 + (p & 3); }
+__device__ __forceinline__ void st128(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void st128h(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, half8 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
+// One row-tile x column-tile of results (16 values of one row) -> memory.  fp32: 4 x 16 B at byte 64 h of the tile's
+// 128-byte row segment; SPLIT32: hi halves 32 B at 32 h, lo halves 32 B at 64 + 32 h.
+template <bool OUT_SPLIT>
+__device__ __forceinline__ void store16(__amdgpu_buffer_rsrc_t rc, uint32_t voff, uint32_t soff, const float (&v)[16]) {
+    if constexpr (OUT_SPLIT) {
+        half8 h0, h1, l0, l1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            half_t h, l;
+            split_f16(v[e], h, l); h0[e] = h; l0[e] = l;
+            split_f16(v[8 + e], h, l); h1[e] = h; l1[e] = l;
+        }
+        st128h(rc, voff, soff, h0);
+        st128h(rc, voff, soff + 16, h1);
+        st128h(rc, voff, soff + 64, l0);
+        st128h(rc, voff, soff + 80, l1);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            st128(rc, voff, soff + 16 * q, o);
+        }
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, bool FULL>
+__device__ __forceinline__ void epilogue_tr(const GemmArgs& a, const GemmGroup& g, f32x16 (&acc)[TM][TN], int m0, int n0,
+                                            int wm, int wn, int lane) {
+    // Measured (32 x 30 s, round 2): row-per-lane 16-byte accesses win where the output is SPLIT32 (FFN1: -1.7 %, no DPP
+    // exchange, 4 instead of 16 stores per tile) and LOSE 5-20 % for fp32 outputs / residual reads, whose 16-byte pieces
+    // are partial 64-byte lines (the column-per-lane dword stores are whole 128-byte rows) - so only the SiLU epilogue
+    // uses this layout.
+    static_assert(EPI == EPI_BIAS_SILU, "the other epilogues keep the column-per-lane layout");
+    const int l31 = lane & 31, hi = lane >> 5;
+    const uint32_t row_c = (uint32_t)a.ldc * 4u;
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(g.C, (size_t)a.M * row_c);
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int nb = n0 + (wn * TN + jn) * 32;
+        if (!FULL && nb >= g.N) continue;
+        float bias[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(g.bias + nb + 16 * hi + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias[4 * q + e] = t[e];
+        }
+        const uint32_t soff = (uint32_t)nb * 4u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wm * TM + i) * 32 + l31;      // rows >= M lie past num_records: dropped by the hardware
+            const uint32_t vc = (uint32_t)m * row_c + (uint32_t)hi * (OUT_SPLIT ? 32u : 64u);
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = acc[i][jn][r] + bias[r];
+                v[r] = x * sigmoidf_(x);
+            }
+            store16<OUT_SPLIT>(rc, vc, soff, v);
+        }
+    }
+}
+
 // TERMS = 3: x = hi + lo on both operands, three products (fp32-equivalent).  TERMS = 1: hi halves only - plain f16 operands
 // with fp32 accumulation on the same SPLIT32 layout (mixed-precision training, some_train_gemm_f16).
-template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3, bool TR = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs a) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -249,7 +329,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     __syncthreads();
 
     const int a_off = (wm * TM * 32 + l31) * LDT + kg * 4;
-    const int w_off = (BM + wn * TN * 32 + l31) * LDT + kg * 4;
+    const int w_off = (BM + wn * TN * 32 + (TR ? pi32(l31) : l31)) * LDT + kg * 4;
+    // TR: the W fragment is the first MFMA operand (accumulator rows <- n, lane <- m), see epilogue_tr
+    auto mma = [](half8 x, half8 w, f32x16 c) {
+        return TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, c, 0, 0, 0);
+    };
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -276,18 +360,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int jn = 0; jn < TN; ++jn)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[jn], acc[i][jn], 0, 0, 0);
+                        acc[i][jn] = mma(al[i], bh[jn], acc[i][jn]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int jn = 0; jn < TN; ++jn)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[jn], acc[i][jn], 0, 0, 0);
+                        acc[i][jn] = mma(ah[i], bl[jn], acc[i][jn]);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = mma(ah[i], bh[jn], acc[i][jn]);
         }
         __syncthreads();
     }
@@ -296,10 +380,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     // Interior workgroups take the unguarded path (no per-element exec masking).  Residual values are fetched one
     // 32 x 32 MFMA tile (16 per lane) at a time BEFORE that tile's stores: C may alias res (in-place residual
     // update), which otherwise forces the compiler into load -> wait -> store per element.
-    if (m0 + BM <= a.M && n0 + BN <= g.N)
-        epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, true>(a, g, acc, m0, n0, wm, wn, lane);
-    else
-        epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane);
+    if constexpr (TR) {
+        if (n0 + BN <= g.N)      // rows beyond M fall outside the buffer descriptors (dropped by the hardware)
+            epilogue_tr<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, true>(a, g, acc, m0, n0, wm, wn, lane);
+        else
+            epilogue_tr<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane);
+    } else {
+        if (m0 + BM <= a.M && n0 + BN <= g.N)
+            epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, true>(a, g, acc, m0, n0, wm, wn, lane);
+        else
+            epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane);
+    }
 }
 
 // ---- ring variant: 128 x 256 tile, 4 waves (2 x 2, each 64 x 128), TWO workgroups per CU -----------------------
@@ -441,12 +532,12 @@ hipError_t launch_ring(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3, bool TR = false>
 hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LDT * sizeof(float);
     static bool attr_set = false;
-    auto kern = &hgemm3_kernel<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, TERMS>;
+    auto kern = &hgemm3_kernel<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, TERMS, TR>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -464,6 +555,19 @@ hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
 
 template <int EPI, bool OUT_SPLIT>
 hipError_t launch_epi(const GemmArgs& a, int tile, hipStream_t s) {
+    constexpr bool kCanTr = EPI == EPI_BIAS_SILU && OUT_SPLIT;
+    if constexpr (kCanTr) {
+        bool tr = (a.flags & GEMM_FLAG_TR) != 0 && tile != 3;
+        for (int g = 0; g < a.groups; ++g) tr = tr && (a.g[g].N % 64) == 0;
+        if (tr) {
+            switch (tile) {
+                case 4: return launch_cfg<2, 2, 1, 2, EPI, OUT_SPLIT, 3, true>(a, s);
+                case 0: return launch_cfg<2, 2, 2, 2, EPI, OUT_SPLIT, 3, true>(a, s);
+                case 1: return launch_cfg<4, 2, 2, 2, EPI, OUT_SPLIT, 3, true>(a, s);
+                default: return launch_cfg<4, 2, 2, 4, EPI, OUT_SPLIT, 3, true>(a, s);
+            }
+        }
+    }
     switch (tile) {
         case 4: return launch_cfg<2, 2, 1, 2, EPI, OUT_SPLIT>(a, s);    // 64 x 128, 4 waves (small M: more workgroups)
         case 0: return launch_cfg<2, 2, 2, 2, EPI, OUT_SPLIT>(a, s);    // 128 x 128, 4 waves

@@ -50,7 +50,9 @@ struct GemmArgs {
     int m_begin;           // first row of this launch (rows [m_begin, M) are covered); filled by the launcher
     int k_slices;          // split-K (f16x3, EPI_NONE): blockIdx.z = slice of the contraction; 0 / 1 = off
     size_t slice_stride;   // floats between the partial C planes of consecutive slices
+    int flags;             // GEMM_FLAG_* (f16x3 path)
 };
+constexpr int GEMM_FLAG_TR = 1;   // row-per-lane (transposed accumulator) epilogues where the epilogue has one (gemm_f16x3.hip)
 
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 // 3-term split-f16 path (gemm_f16x3.hip): A and W in SPLIT32 format (split.h); out_split: C written in SPLIT32
@@ -218,6 +220,7 @@ struct SomeHandle {
     bool profiling = false;
     int precision = 0;          // SOME_PRECISION_*
     int tile = 2;               // f16x3 GEMM tile selector (tuning knob)
+    int gemm_flags = GEMM_FLAG_TR;   // SOME_AMD_GEMM_FLAGS overrides (A/B runs)
     std::vector<ProfRecord> prof;
     std::vector<hipEvent_t> event_pool;
 };
