@@ -117,8 +117,13 @@ int ensure_mel_tables(SomeHandle* h) {
     // one blob: window | twiddle | mel_w | start | len | off
     const size_t o_win = 0, o_tw = o_win + kWin * 4, o_w = o_tw + tw.size() * 4;
     const size_t o_st = align_up(o_w + packed.size() * 4, 16), o_len = o_st + kMels * 4, o_off = o_len + kMels * 4;
-    const size_t total = o_off + kMels * 4;
+    constexpr int kPad = 32;
+    const size_t o_pad = align_up(o_off + kMels * 4, 16);
+    const size_t total = o_pad + (size_t)(kMels + 1) * kPad * 4;
     std::vector<char> host(total, 0);
+    for (int m = 0; m < kMels; ++m)
+        for (int i = 0; i < len[m] && i < kPad; ++i)
+            memcpy(host.data() + o_pad + ((size_t)m * kPad + i) * 4, &packed[(size_t)off[m] + i], 4);
     memcpy(host.data() + o_win, window.data(), kWin * 4);
     memcpy(host.data() + o_tw, tw.data(), tw.size() * 4);
     memcpy(host.data() + o_w, packed.data(), packed.size() * 4);
@@ -137,7 +142,10 @@ int ensure_mel_tables(SomeHandle* h) {
     h->mel.mel_start = reinterpret_cast<int32_t*>(d + o_st);
     h->mel.mel_len = reinterpret_cast<int32_t*>(d + o_len);
     h->mel.mel_off = reinterpret_cast<int32_t*>(d + o_off);
+    h->mel.mel_wpad = reinterpret_cast<float*>(d + o_pad);
     h->mel.kmax = std::min(kmax, 1024);
+    h->mel.nnz = (int)packed.size();
+    h->mel.max_len = *std::max_element(len.begin(), len.end());
     return SOME_OK;
 }
 

@@ -135,12 +135,15 @@ hipError_t launch_dwconv(const DwArgs& a, hipStream_t s);
 // ---- front end ------------------------------------------------------------------------------------
 struct LogmelTables {
     float* window;       // [2048] periodic Hann
-    float* twiddle;      // [1024] complex (cos, -sin)(2*pi*k/1024) interleaved + [1024] post-process table
+    float* twiddle;      // [2048] complex exp(-2 pi i k / 2048), interleaved (re, im)
     float* mel_w;        // packed non-zero filter weights
+    float* mel_wpad;     // [81][32]: band m's weights zero-padded to 32 (row 80 = zeros); valid when max_len <= 32
     int32_t* mel_start;  // [80] first bin of each band
     int32_t* mel_len;    // [80] number of bins
     int32_t* mel_off;    // [80] offset into mel_w
     int kmax;            // highest FFT bin any band touches
+    int nnz;             // number of packed filter weights
+    int max_len;         // longest band (bins)
 };
 hipError_t launch_logmel(const LogmelTables& t, const float* audio, const int64_t* sample_offsets,
                          const int32_t* frame_offsets, int B, int max_frames, int pad_reflect, float* units, hipStream_t s);
