@@ -6,8 +6,11 @@ fallback: if the shared object is missing or a call fails, the Python layer rais
 import ctypes as C
 import pathlib
 
+import os
+
 _HERE = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _HERE / 'libsome_amd.so'
+# SOME_AMD_LIBRARY: an alternative build of the same library (kernel A/B experiments, tools/build_variant.py)
+LIB_PATH = pathlib.Path(os.environ['SOME_AMD_LIBRARY']).resolve() if os.environ.get('SOME_AMD_LIBRARY') else _HERE / 'libsome_amd.so'
 
 SOME_OK = 0
 SOME_EINVAL, SOME_EKEY, SOME_ESHAPE, SOME_EHIP, SOME_ESTATE, SOME_ENOMEM = -1, -2, -3, -4, -5, -6

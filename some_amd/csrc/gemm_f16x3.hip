@@ -280,35 +280,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
         g.C += (size_t)blockIdx.z * a.slice_stride;
     }
 
-    // ---- staging roles
-    const char* src[NLD];
-    int dst[NLD];
-    bool ok[NLD];
+    // ---- staging roles: thread t moves chunk (row t / 8 + (NT / 8) p, 16-byte column t % 8) of every k-block, p < NLD;
+    // the first BM rows are A, the rest W.  Loads go through buffer descriptors: rows past the end of A (partial row
+    // tile) or W (partial column tile) fall outside num_records and return zeros - no per-load branch, so the whole
+    // k-iteration is ONE basic block and the scheduler interleaves the staging traffic with the MFMAs.
+    constexpr int RPP = NT / 8;                          // rows per pass
+    static_assert(BM % RPP == 0, "a pass must not straddle A and W");
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(g.A, (size_t)a.M * a.lda * 4);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(g.W, (size_t)g.N * a.K * 4);
+    const int srow = tid >> 3, scol = tid & 7;
+    uint32_t voff[NLD];
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
-        const int c = tid + p * NT;
-        const int row = c >> 3, col = c & 7;
-        dst[p] = row * LDT + col * 4;
-        if (row < BM) {
-            ok[p] = (m0 + row) < a.M;
-            src[p] = reinterpret_cast<const char*>(g.A) + ((size_t)(ok[p] ? m0 + row : 0) * a.lda) * 4 + col * 16;
-        } else {
-            const int r = row - BM;
-            ok[p] = (n0 + r) < g.N;
-            src[p] = reinterpret_cast<const char*>(g.W) + ((size_t)(ok[p] ? n0 + r : 0) * a.K) * 4 + col * 16;
-        }
+        const int row = srow + p * RPP;
+        voff[p] = row < BM ? (uint32_t)(m0 + row) * (uint32_t)a.lda * 4u + scol * 16u
+                           : (uint32_t)(n0 + row - BM) * (uint32_t)a.K * 4u + scol * 16u;
     }
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int dst0 = srow * LDT + scol * 4;
     f32x4 stage[NLD];
     auto gload = [&](int kt) {
+        const uint32_t koff = (uint32_t)(kt0 + kt) * 128u;
 #pragma unroll
         for (int p = 0; p < NLD; ++p)
-            stage[p] = ok[p] ? *reinterpret_cast<const f32x4*>(src[p] + (size_t)(kt0 + kt) * 128) : zero4;
+            stage[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p * RPP < BM ? rsa : rsw, voff[p], koff, 0));
     };
     auto lstore = [&](int buf) {
-        float* base = lds + buf * STAGE;
+        float* base = lds + buf * STAGE + dst0;
 #pragma unroll
-        for (int p = 0; p < NLD; ++p) *reinterpret_cast<f32x4*>(base + dst[p]) = stage[p];
+        for (int p = 0; p < NLD; ++p) *reinterpret_cast<f32x4*>(base + p * RPP * LDT) = stage[p];
     };
 
     f32x16 acc[TM][TN];
@@ -335,10 +334,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
         return TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, c, 0, 0, 0);
     };
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        if (kt + 2 < nk) gload(kt + 2);
+    // the MFMAs of one k-block out of LDS buffer `buf`
+    auto compute = [&](int buf) {
         const float* As = lds + buf * STAGE + a_off;
         const float* Ws = lds + buf * STAGE + w_off;
 #pragma unroll
@@ -373,8 +370,110 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
                 for (int jn = 0; jn < TN; ++jn)
                     acc[i][jn] = mma(ah[i], bh[jn], acc[i][jn]);
         }
+    };
+    // Steady state (TERMS = 3), hand-scheduled - hipcc left to itself puts all LDS writes at the head of the iteration
+    // and sinks the global loads to its end (so the next head waits on them):
+    //   * the first k = 16 slab's fragment reads go first: nothing sits in front of them in the LDS queue;
+    //   * one LDS write (k-block kt + 1) + one global load (k-block kt + 2) of the staging traffic follows each of the
+    //     first MFMAs - asynchronous instructions issued in the shadow of a 32-cycle MFMA;
+    //   * the second slab's operands are read one product ahead: al / bh (first product) while the first slab's last
+    //     product runs, ah / bl under the second slab's first product - into the registers the first slab has just
+    //     retired (al dies after product 1, bl after product 2), so the fragment set stays at 48 VGPRs.
+    // sched_barrier(0) pins that order; no condition inside the iteration, the last two k-blocks are peeled.
+    auto frag = [&](const float* base, int tile, int s, int lo) {
+        return *reinterpret_cast<const half8*>(base + tile * 32 * LDT + lo * 16 + s * 8);
+    };
+    auto compute_staged = [&](int buf, int kt_load) {
+        const float* As = lds + buf * STAGE + a_off;
+        const float* Ws = lds + buf * STAGE + w_off;
+        float* wbase = lds + (buf ^ 1) * STAGE + dst0;
+        const uint32_t koff = (uint32_t)(kt0 + kt_load) * 128u;
+        half8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) al[i] = frag(As, i, 0, 1);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) bh[jn] = frag(Ws, jn, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ah[i] = frag(As, i, 0, 0);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) bl[jn] = frag(Ws, jn, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int SLOTS = 2 * TM * TN;                       // products 1 and 2 of the first slab carry the staging
+        constexpr int OPS = (NLD + SLOTS - 1) / SLOTS;
+        auto stage_ops = [&](int slot) {
+#pragma unroll
+            for (int o = 0; o < OPS; ++o) {
+                const int q = slot * OPS + o;
+                if (q < NLD) {
+                    *reinterpret_cast<f32x4*>(wbase + q * RPP * LDT) = stage[q];
+                    stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q * RPP < BM ? rsa : rsw, voff[q], koff, 0));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                acc[i][jn] = mma(al[i], bh[jn], acc[i][jn]);
+                stage_ops(i * TN + jn);
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                acc[i][jn] = mma(ah[i], bl[jn], acc[i][jn]);
+                stage_ops(TM * TN + i * TN + jn);
+            }
+        // second slab, first-product operands
+        half8 al1[TM], bh1[TN], ah1[TM], bl1[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) al1[i] = frag(As, i, 1, 1);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) bh1[jn] = frag(Ws, jn, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mma(ah[i], bh[jn], acc[i][jn]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ah1[i] = frag(As, i, 1, 0);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) bl1[jn] = frag(Ws, jn, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mma(al1[i], bh1[jn], acc[i][jn]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mma(ah1[i], bl1[jn], acc[i][jn]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mma(ah1[i], bh1[jn], acc[i][jn]);
+    };
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+        if constexpr (TERMS == 3) {
+            compute_staged(kt & 1, kt + 2);
+        } else {
+            lstore((kt & 1) ^ 1);
+            gload(kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(kt & 1);
+        }
         __syncthreads();
     }
+    if (kt + 1 < nk) {
+        lstore((kt & 1) ^ 1);
+        compute(kt & 1);
+        __syncthreads();
+        ++kt;
+    }
+    compute(kt & 1);
 
     // ---- epilogue (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
     // Interior workgroups take the unguarded path (no per-element exec masking).  Residual values are fetched one

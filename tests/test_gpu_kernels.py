@@ -305,3 +305,33 @@ def test_qkv_attention_f16x3(eng, lens):
         ref = (torch.softmax(q @ k.transpose(1, 2) * 0.125, dim=-1) @ v).transpose(0, 1).reshape(t, 512).float()
         err = (got[s:s + t] - ref).abs().max().item()
         assert err < 1e-5, (b, t, err)
+
+
+@pytest.mark.parametrize('tile', [0, 1, 2, 4])
+@pytest.mark.parametrize('epi', ['bias_res', 'bias_silu_split', 'glu_res'])
+def test_gemm_f16x3_never_writes_past_row_m(eng, tile, epi):
+    """Partial row tiles (M not a multiple of the tile height): the epilogues rely on the buffer descriptors' range check
+    to drop rows >= M - make sure nothing lands behind the output (or the residual) buffer."""
+    from some_amd import _lib as L
+    g = torch.Generator(device='cuda').manual_seed(3)
+    M, K = 300, 512
+    guard = 64                                   # sentinel rows behind the M valid ones
+    A = _split(eng, torch.randn(M, K, device='cuda', generator=g))
+    if epi == 'glu_res':
+        N, n_out = 1024, 512
+    elif epi == 'bias_silu_split':
+        N, n_out = 2048, 2048
+    else:
+        N, n_out = 512, 512
+    W = _split(eng, (torch.randn(N, K, device='cuda', generator=g) / 20).contiguous())
+    b = torch.randn(N, device='cuda', generator=g)
+    big = torch.full((M + guard, n_out), 12345.0, device='cuda')
+    Cm = big[:M]
+    res = torch.randn(M, n_out, device='cuda', generator=g)
+    code = {'bias_res': L.EPI_BIAS_RES, 'bias_silu_split': L.EPI_BIAS_SILU, 'glu_res': L.EPI_GLU_RES}[epi]
+    flags = L.GEMM_SPLIT_IN | (tile << 8) | (L.GEMM_SPLIT_OUT if epi == 'bias_silu_split' else 0)
+    L.check(eng.handle, eng.lib.some_op_gemm(eng.handle, code, _p(A), K, _p(W), _p(b), _p(res) if 'res' in epi else None, n_out,
+                                             _p(Cm), n_out, M, N, K, 1.0, 0, None, flags, _stream()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(Cm).all()
+    assert (big[M:] == 12345.0).all()
