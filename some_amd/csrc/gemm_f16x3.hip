@@ -59,33 +59,49 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const GemmGroup& g, 
     if constexpr (EPI == EPI_GLU || EPI == EPI_GLU_RES) {
         static_assert(TN % 2 == 0, "GLU pairs adjacent 32-column tiles");
         const __amdgpu_buffer_rsrc_t rres = make_rsrc(g.res, (size_t)a.M * row_r);
+        // residual rows are fetched kPrefetch tiles ahead of the tile being finished (C may alias res, so the compiler
+        // keeps every load behind the earlier tiles' stores: without the explicit look-ahead each tile pays a full
+        // memory round trip)
+        constexpr int NTILE = (TN / 2) * TM, PF = NTILE < 3 ? NTILE : 3;
+        auto tile_np = [&](int t) { return n0 + (wn * TN + 2 * (t / TM)) * 32 + l31; };
+        auto load_res = [&](int t, float (&dst)[16]) {
+            const int np = tile_np(t);
+            const bool nv = FULL || np < g.N;
+            const int oc = (np - l31) / 2 + l31;
+            const uint32_t vr = nv ? (uint32_t)row0(t % TM) * row_r + (uint32_t)oc * 4u : kOob;
 #pragma unroll
-        for (int jp = 0; jp < TN / 2; ++jp) {
-            const int np = n0 + (wn * TN + 2 * jp) * 32 + l31;        // packed column of the `a` half
+            for (int r = 0; r < 16; ++r) dst[r] = ld32(rres, vr, rk(r) * row_r);
+        };
+        float rq[PF][16];
+        if constexpr (EPI == EPI_GLU_RES) {
+#pragma unroll
+            for (int t = 0; t < PF; ++t) load_res(t, rq[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+            const int jp = t / TM, i = t % TM;
+            const int np = tile_np(t);                                 // packed column of the `a` half
             const bool nv = FULL || np < g.N;
             const int oc = (np - l31) / 2 + l31;                       // packed 64-block -> 32 outputs
             const float ba = nv ? g.bias[np] : 0.f, bg = nv ? g.bias[np + 32] : 0.f;
+            const uint32_t vc = nv ? (uint32_t)row0(i) * row_c + (uint32_t)oc * 4u : kOob;
+            float rr[16];
+            if constexpr (EPI == EPI_GLU_RES) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const uint32_t vc = nv ? (uint32_t)row0(i) * row_c + (uint32_t)oc * 4u : kOob;
-                float rr[16];
+                for (int r = 0; r < 16; ++r) rr[r] = rq[t % PF][r];
+                if (t + PF < NTILE) load_res(t + PF, rq[t % PF]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (acc[i][2 * jp][r] + ba) * sigmoidf_(acc[i][2 * jp + 1][r] + bg);
                 if constexpr (EPI == EPI_GLU_RES) {
-                    const uint32_t vr = nv ? (uint32_t)row0(i) * row_r + (uint32_t)oc * 4u : kOob;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rr[r] = ld32(rres, vr, rk(r) * row_r);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = (acc[i][2 * jp][r] + ba) * sigmoidf_(acc[i][2 * jp + 1][r] + bg);
-                    if constexpr (EPI == EPI_GLU_RES) {
-                        v += rr[r];
-                        if (g.mask != nullptr) {
-                            const int m = row0(i) + (int)rk(r);
-                            if (m < a.M && g.mask[m] == 0) v = 0.f;
-                        }
+                    v += rr[r];
+                    if (g.mask != nullptr) {
+                        const int m = row0(i) + (int)rk(r);
+                        if (m < a.M && g.mask[m] == 0) v = 0.f;
                     }
-                    st32(rc, vc, rk(r) * row_c, __builtin_bit_cast(uint32_t, v));
                 }
+                st32(rc, vc, rk(r) * row_c, __builtin_bit_cast(uint32_t, v));
             }
         }
     } else if constexpr (EPI == EPI_QKV) {
@@ -130,39 +146,50 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const GemmGroup& g, 
         }
     } else {
         const __amdgpu_buffer_rsrc_t rres = make_rsrc(EPI == EPI_BIAS_RES ? (const void*)g.res : (const void*)g.C, (size_t)a.M * row_r);
+        constexpr int NTILE = TN * TM, PF = NTILE < 3 ? NTILE : 3;      // residual look-ahead, see the GLU path
+        auto load_res = [&](int t, float (&dst)[16]) {
+            const int n = n0 + (wn * TN + t / TM) * 32 + l31;
+            const bool nv = FULL || n < g.N;
+            const uint32_t vr = nv ? (uint32_t)row0(t % TM) * row_r + (uint32_t)n * 4u : kOob;
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
+            for (int r = 0; r < 16; ++r) dst[r] = ld32(rres, vr, rk(r) * row_r);
+        };
+        float rq[PF][16];
+        if constexpr (EPI == EPI_BIAS_RES) {
+#pragma unroll
+            for (int t = 0; t < PF; ++t) load_res(t, rq[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+            const int jn = t / TM, i = t % TM;
             const int n = n0 + (wn * TN + jn) * 32 + l31;
             const bool nv = FULL || n < g.N;
             float bias = 0.f;
             if constexpr (EPI != EPI_NONE) bias = nv ? g.bias[n] : 0.f;
             const uint32_t split_off = (uint32_t)((n - l31) >> 5) * 128u + ((lane & 1) ? 64u + (uint32_t)(l31 - 1) * 2u : (uint32_t)l31 * 2u);
+            const uint32_t vc = nv ? (uint32_t)row0(i) * row_c + (OUT_SPLIT ? split_off : (uint32_t)n * 4u) : kOob;
+            float rr[16];
+            if constexpr (EPI == EPI_BIAS_RES) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const uint32_t vc = nv ? (uint32_t)row0(i) * row_c + (OUT_SPLIT ? split_off : (uint32_t)n * 4u) : kOob;
-                float rr[16];
-                if constexpr (EPI == EPI_BIAS_RES) {
-                    const uint32_t vr = nv ? (uint32_t)row0(i) * row_r + (uint32_t)n * 4u : kOob;
+                for (int r = 0; r < 16; ++r) rr[r] = rq[t % PF][r];
+                if (t + PF < NTILE) load_res(t + PF, rq[t % PF]);
+            }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) rr[r] = ld32(rres, vr, rk(r) * row_r);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][jn][r] + bias;
-                    if constexpr (EPI == EPI_BIAS) {
-                        if (g.act == 1) v = sigmoidf_(v);
-                        if (g.mask != nullptr) {
-                            const int m = row0(i) + (int)rk(r);
-                            if (m < a.M && g.mask[m] == 0) v = 0.f;
-                        }
-                    } else if constexpr (EPI == EPI_BIAS_SILU) {
-                        v = v * sigmoidf_(v);
-                    } else if constexpr (EPI == EPI_BIAS_RES) {
-                        v = rr[r] + a.alpha * v;
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][jn][r] + bias;
+                if constexpr (EPI == EPI_BIAS) {
+                    if (g.act == 1) v = sigmoidf_(v);
+                    if (g.mask != nullptr) {
+                        const int m = row0(i) + (int)rk(r);
+                        if (m < a.M && g.mask[m] == 0) v = 0.f;
                     }
-                    if constexpr (OUT_SPLIT) st32(rc, vc, rk(r) * row_c, pack_split_pair(v, lane));
-                    else st32(rc, vc, rk(r) * row_c, __builtin_bit_cast(uint32_t, v));
+                } else if constexpr (EPI == EPI_BIAS_SILU) {
+                    v = v * sigmoidf_(v);
+                } else if constexpr (EPI == EPI_BIAS_RES) {
+                    v = rr[r] + a.alpha * v;
                 }
+                if constexpr (OUT_SPLIT) st32(rc, vc, rk(r) * row_c, pack_split_pair(v, lane));
+                else st32(rc, vc, rk(r) * row_c, __builtin_bit_cast(uint32_t, v));
             }
         }
     }
