@@ -36,6 +36,9 @@ __device__ __forceinline__ float exp2_(float x) { return __builtin_amdgcn_exp2f(
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef ATTN_PIN_STAGING
+#define ATTN_PIN_STAGING 0
+#endif
 #ifndef ATTN_PACKED_F32
 #define ATTN_PACKED_F32 0       // softmax / P split on v_pk_fma_f32 / v_pk_add_f32 (0: scalar fp32 VALU)
 #endif
@@ -123,14 +126,15 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
     const int gt0 = f0 / KT, gt1 = (f0 + T - 1) / KT;
     const int n = gt1 - gt0 + 1;                    // key tiles of this clip
     f32x4 rk[4], rv[4];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // K rows through a buffer descriptor: keys >= M (the tail of the last global tile) lie past num_records and read as
+    // zeros - no exec-masked branch in the loop
+    const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(Kp), 0, (int)((size_t)a.M * ROW_B - head * 256 > 0x7fffffffull ? 0x7fffffffull : (size_t)a.M * ROW_B - head * 256), 0x00020000);
     auto gload_k = [&](int i) {
         const int g0 = (gt0 + i) * KT;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int key = g0 + srow + 16 * p;
-            rk[p] = key < a.M ? *reinterpret_cast<const f32x4*>(Kp + (size_t)key * ROW_B + sc * 16) : zero4;
-        }
+        for (int p = 0; p < 4; ++p)
+            rk[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsk, (uint32_t)(g0 + srow + 16 * p) * (uint32_t)ROW_B + sc * 16u, 0, 0));
     };
     auto gload_v = [&](int i) {
         const int g0 = (gt0 + i) * KT;
@@ -315,9 +319,28 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
         mask_tile(i + 1, n0, n1);
         __syncthreads();
     };
+    // the same step for interior tiles (i + 3 < n): nothing conditional, tile i + 1 needs no masking - ONE basic block,
+    // so the scheduler is free to spread the staging traffic and the fragment reads between the MFMAs
+    auto step_full = [&](int i, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
+        lstore_k(i + 2);
+        lstore_v(i + 1);
+        gload_k(i + 3);
+        gload_v(i + 2);
+#if ATTN_PIN_STAGING
+        __builtin_amdgcn_sched_barrier(0);            // keep the global loads at the head (hipcc sinks them to the barrier)
+#endif
+        qk(i + 1, n0, n1);
+        softmax(c0, c1);
+        pv(i, c0, c1);
+        __syncthreads();
+    };
     qk(0, sa0, sa1);
     mask_tile(0, sa0, sa1);
     int i = 0;
+    for (; i + 4 < n; i += 2) {
+        step_full(i, sa0, sa1, sb0, sb1);
+        step_full(i + 1, sb0, sb1, sa0, sa1);
+    }
     for (; i + 2 < n; i += 2) {
         step(i, sa0, sa1, sb0, sb1);
         step(i + 1, sb0, sb1, sa0, sa1);
