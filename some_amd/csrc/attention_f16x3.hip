@@ -15,12 +15,13 @@
 // aligned however the clips are packed; keys outside the clip get score -inf (their data is another clip's
 // finite values or the zero padding the GEMM wrote, so 0 * v stays 0).
 // The softmax scale 64^-0.5 * log2(e) is folded into the exp2 argument: p = exp2(fma(s, c, -m)).
+#include <cstdlib>
+
 #include "internal.h"
 #include "split.h"
 
 namespace {
 
-constexpr int QB = 128;
 constexpr int KT = 64;
 constexpr int LDR = 68;                         // LDS row (dwords): 64 data + 4 pad
 constexpr int K_DW = KT * LDR;                  // K tile: [64 keys][hi|lo hi|lo]
@@ -81,8 +82,12 @@ __device__ __forceinline__ void split8(const f32x16& p, int base, half8& h, half
 // TRAIN = true: the training forward (train_api: some_train_attention_fwd_f16x3) - Q / K rows come straight from
 // split_rows(qkv) (row stride 6144 B), V^T from transpose(qkv, split) (SPLIT32 over frames: 32-frame blocks [32 hi | 32 lo]),
 // the output is fp32 and the base-2 log-sum-exp is stored for the backward.
-template <bool TRAIN, int TERMS = 3>
-__global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb) {
+// QT = query tiles (of 32) per wavefront.  QT = 1: 128 queries per workgroup, two workgroups per CU (two wavefronts per SIMD
+// cover each other's stalls).  QT = 2: 256 queries per workgroup, ONE wavefront per SIMD with the 512-register budget -
+// every K / V^T fragment read from LDS feeds two MFMA column tiles, staging traffic and barriers per MFMA halve.
+template <bool TRAIN, int TERMS = 3, int QT = 1>
+__global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3Args a, int nqb) {
+    constexpr int QB = 128 * QT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int slot = jj / nqb, qb = jj % nqb;
@@ -104,19 +109,20 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
     const char* __restrict__ Vl = Vh + (size_t)kDim * a.ldv * 2;                          // (planes format only)
 
     // ---- Q fragments (B operand of S^T): slab s covers d = 16 s .. 16 s + 15; lane half kg holds 8 of them
-    half8 qh[4], ql[4];
-    {
-        const int q = q0 + wave * 32 + l31;
+    half8 qh[QT][4], ql[QT][4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int q = q0 + (wave * QT + t) * 32 + l31;
         const bool qv = q < T;
         const char* row = Qp + (size_t)(f0 + (qv ? q : 0)) * ROW_B;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int off = (s >> 1) * 128 + (s & 1) * 32 + kg * 16;
-            qh[s] = *reinterpret_cast<const half8*>(row + off);
-            ql[s] = *reinterpret_cast<const half8*>(row + off + 64);
+            qh[t][s] = *reinterpret_cast<const half8*>(row + off);
+            ql[t][s] = *reinterpret_cast<const half8*>(row + off + 64);
             if (!qv) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { qh[s][i] = (half_t)0; ql[s][i] = (half_t)0; }
+                for (int i = 0; i < 8; ++i) { qh[t][s][i] = (half_t)0; ql[t][s][i] = (half_t)0; }
             }
         }
     }
@@ -160,9 +166,11 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
     };
 
     // S^T = K Q^T (raw, unscaled) for tile i, both 32-key sub-tiles, then -inf outside the clip
-    auto qk = [&](int i, f32x16& s0, f32x16& s1) {
+    auto qk = [&](int i, f32x16 (&s0)[QT], f32x16 (&s1)[QT]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0[t][r] = 0.f; s1[t][r] = 0.f; }
         const float* kp = kbuf(i) + l31 * LDR + kg * 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -172,35 +180,52 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
             const half8 kh1 = *reinterpret_cast<const half8*>(kp + 32 * LDR + off);
             const half8 kl1 = *reinterpret_cast<const half8*>(kp + 32 * LDR + off + 16);
             if (TERMS == 3) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[s], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[s], s1, 0, 0, 0);
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[s], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[s], s1, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    s0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[t][s], s0[t], 0, 0, 0);
+                    s1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[t][s], s1[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    s0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[t][s], s0[t], 0, 0, 0);
+                    s1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[t][s], s1[t], 0, 0, 0);
+                }
             }
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[s], s1, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                s0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[t][s], s0[t], 0, 0, 0);
+                s1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[t][s], s1[t], 0, 0, 0);
+            }
         }
     };
-    auto mask_tile = [&](int i, f32x16& s0, f32x16& s1) {
+    auto mask_tile = [&](int i, f32x16 (&s0)[QT], f32x16 (&s1)[QT]) {
         const int gbase = (gt0 + i) * KT;
         if (gbase < f0 || gbase + KT > f0 + T) {          // first and last global tile only
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k0 = gbase + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                if (k0 < f0 || k0 >= f0 + T) s0[r] = -INFINITY;
-                if (k0 + 32 < f0 || k0 + 32 >= f0 + T) s1[r] = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    if (k0 < f0 || k0 >= f0 + T) s0[t][r] = -INFINITY;
+                    if (k0 + 32 < f0 || k0 + 32 >= f0 + T) s1[t][r] = -INFINITY;
+                }
             }
         }
     };
 
-    f32x16 o0, o1;
+    f32x16 o0[QT], o1[QT];
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[t][r] = 0.f; o1[t][r] = 0.f; }
+        m_run[t] = -INFINITY;
+        l_run[t] = 0.f;
+    }
     const float c = 0.125f * 1.4426950408889634f;       // head_dim^-0.5 * log2(e)
 
     // online softmax of one tile's scores (lane = query; scale folded into the exponent): s0/s1 become P
-    auto softmax = [&](f32x16& s0, f32x16& s1) {
+    auto softmax1 = [&](f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m_run, float& l_run) {
         float mxa = max2_(s0[0], s1[0]), mxb = max2_(s0[1], s1[1]);
 #pragma unroll
         for (int r = 2; r < 16; r += 2) {
@@ -259,16 +284,21 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
 #endif
     };
+    auto softmax = [&](f32x16 (&s0)[QT], f32x16 (&s1)[QT]) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) softmax1(s0[t], s1[t], o0[t], o1[t], m_run[t], l_run[t]);
+    };
     // O^T += V^T P^T for tile i.  P slab (sub, s'): registers r = 8 s' .. 8 s' + 7 of the sub-tile hold keys
     // 16 s' + {0..3} + 4 kg and 16 s' + 8 + {0..3} + 4 kg  ->  two ds_read_b64 per V^T fragment
-    auto pv = [&](int i, const f32x16& s0, const f32x16& s1) {
+    auto pv = [&](int i, const f32x16 (&s0)[QT], const f32x16 (&s1)[QT]) {
         const float* vp = vbuf(i) + l31 * LDR + 2 * kg;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
-                half8 ph, pl;
-                split8(sub == 0 ? s0 : s1, 8 * sp, ph, pl);
+                half8 ph[QT], pl[QT];
+#pragma unroll
+                for (int t = 0; t < QT; ++t) split8(sub == 0 ? s0[t] : s1[t], 8 * sp, ph[t], pl[t]);
                 // dword offset of key 32 sub + 16 s' and of its lo half: row = [64 hi | 64 lo] (planes) or
                 // [32 hi | 32 lo][32 hi | 32 lo] (SPLIT32 over frames)
                 constexpr int LO = TRAIN ? 16 : 32;
@@ -286,13 +316,22 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
                 const half8 vh1 = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const half8 vl1 = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7);
                 if (TERMS == 3) {
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl0, ph, o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl1, ph, o1, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, pl, o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, pl, o1, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl0, ph[t], o0[t], 0, 0, 0);
+                        o1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl1, ph[t], o1[t], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, pl[t], o0[t], 0, 0, 0);
+                        o1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, pl[t], o1[t], 0, 0, 0);
+                    }
                 }
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, ph, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, ph, o1, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, ph[t], o0[t], 0, 0, 0);
+                    o1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, ph[t], o1[t], 0, 0, 0);
+                }
             }
         }
     };
@@ -307,8 +346,8 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
     if (n > 1) { gload_k(1); lstore_k(1); gload_v(1); }
     if (n > 2) gload_k(2);
     __syncthreads();
-    f32x16 sa0, sa1, sb0, sb1;                        // scores of even / odd tiles (ping-pong: no register copies)
-    auto step = [&](int i, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
+    f32x16 sa0[QT], sa1[QT], sb0[QT], sb1[QT];        // scores of even / odd tiles (ping-pong: no register copies)
+    auto step = [&](int i, f32x16 (&c0)[QT], f32x16 (&c1)[QT], f32x16 (&n0)[QT], f32x16 (&n1)[QT]) {
         if (i + 2 < n) lstore_k(i + 2);               // K ring slot i & 1: last read by QK(i) in the previous step
         lstore_v(i + 1);                              // V ring slot (i+1) & 1: last read by PV(i-1)
         if (i + 3 < n) gload_k(i + 3);
@@ -321,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
     };
     // the same step for interior tiles (i + 3 < n): nothing conditional, tile i + 1 needs no masking - ONE basic block,
     // so the scheduler is free to spread the staging traffic and the fragment reads between the MFMAs
-    auto step_full = [&](int i, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
+    auto step_full = [&](int i, f32x16 (&c0)[QT], f32x16 (&c1)[QT], f32x16 (&n0)[QT], f32x16 (&n1)[QT]) {
         lstore_k(i + 2);
         lstore_v(i + 1);
         gload_k(i + 3);
@@ -337,9 +376,11 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
     qk(0, sa0, sa1);
     mask_tile(0, sa0, sa1);
     int i = 0;
-    for (; i + 4 < n; i += 2) {
-        step_full(i, sa0, sa1, sb0, sb1);
-        step_full(i + 1, sb0, sb1, sa0, sa1);
+    if constexpr (!TRAIN) {       // (the training variants sit at the register limit: the extra loop body makes them spill)
+        for (; i + 4 < n; i += 2) {
+            step_full(i, sa0, sa1, sb0, sb1);
+            step_full(i + 1, sb0, sb1, sa0, sa1);
+        }
     }
     for (; i + 2 < n; i += 2) {
         step(i, sa0, sa1, sb0, sb1);
@@ -356,39 +397,43 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
     __syncthreads();
 
     // ---- normalise, transpose through LDS (wave-private 32 x 64 patch), SPLIT32 row stores
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
     float* patch = lds + wave * (32 * LDR);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int d = (r & 3) + 8 * (r >> 2) + 4 * kg;
-        patch[l31 * LDR + d] = o0[r] * inv;
-        patch[l31 * LDR + 32 + d] = o1[r] * inv;
-    }
-    __syncthreads();
-    const int orow = lane >> 4, ocol = (lane & 15) * 4;
+    for (int t = 0; t < QT; ++t) {
+        const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (t > 0) __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int ql_ = orow + 4 * p;
-        const int q = q0 + wave * 32 + ql_;
-        if (q < T) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(patch + ql_ * LDR + ocol);
-            if (TRAIN) {
-                *reinterpret_cast<f32x4*>(a.out32[g] + (size_t)(f0 + q) * kDim + head * kHeadDim + ocol) = v;
-            } else {
-                half4 hh, ll;
+        for (int r = 0; r < 16; ++r) {
+            const int d = (r & 3) + 8 * (r >> 2) + 4 * kg;
+            patch[l31 * LDR + d] = o0[t][r] * inv;
+            patch[l31 * LDR + 32 + d] = o1[t][r] * inv;
+        }
+        __syncthreads();
+        const int orow = lane >> 4, ocol = (lane & 15) * 4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { half_t h, l; split_f16(v[i], h, l); hh[i] = h; ll[i] = l; }
-                char* row = reinterpret_cast<char*>(a.out[g]) + ((size_t)(f0 + q) * kDim + head * kHeadDim) * 4 +
-                            (ocol >> 5) * 128 + (ocol & 31) * 2;
-                *reinterpret_cast<half4*>(row) = hh;
-                *reinterpret_cast<half4*>(row + 64) = ll;
+        for (int p = 0; p < 8; ++p) {
+            const int ql_ = orow + 4 * p;
+            const int q = q0 + (wave * QT + t) * 32 + ql_;
+            if (q < T) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(patch + ql_ * LDR + ocol);
+                if (TRAIN) {
+                    *reinterpret_cast<f32x4*>(a.out32[g] + (size_t)(f0 + q) * kDim + head * kHeadDim + ocol) = v;
+                } else {
+                    half4 hh, ll;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { half_t h, l; split_f16(v[i], h, l); hh[i] = h; ll[i] = l; }
+                    char* row = reinterpret_cast<char*>(a.out[g]) + ((size_t)(f0 + q) * kDim + head * kHeadDim) * 4 +
+                                (ocol >> 5) * 128 + (ocol & 31) * 2;
+                    *reinterpret_cast<half4*>(row) = hh;
+                    *reinterpret_cast<half4*>(row + 64) = ll;
+                }
             }
         }
-    }
-    if (TRAIN && kg == 0) {       // P was carried as 2^kPShift p: lse2 = max + log2(sum p)
-        const int q = q0 + wave * 32 + l31;
-        if (q < T) a.lse[g][(size_t)head * a.M + f0 + q] = m_run + __log2f(l_tot) - kPShift;
+        if (TRAIN && kg == 0) {       // P was carried as 2^kPShift p: lse2 = max + log2(sum p)
+            const int q = q0 + (wave * QT + t) * 32 + l31;
+            if (q < T) a.lse[g][(size_t)head * a.M + f0 + q] = m_run[t] + __log2f(l_tot) - kPShift;
+        }
     }
 }
 
@@ -405,13 +450,24 @@ hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<false, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
         attr_set = true;
     }
+    // The wide variant (QT = 2: 256 queries per workgroup, one wavefront per SIMD, 488 registers) measured SLOWER with a
+    // compiler-scheduled stream (32 x 2584 frames: 3.21 vs 2.62 ms - without a partner wavefront every LDS / barrier
+    // wait idles the matrix pipe); it stays selectable for A/B runs with SOME_AMD_ATTN_QT=2, the default is QT = 1.
+    static int force_qt = -1;
+    if (force_qt < 0) { const char* e = getenv("SOME_AMD_ATTN_QT"); force_qt = e ? atoi(e) : 0; }
+    const bool inference = a.out32[0] == nullptr;
+    const int qt = (inference && force_qt == 2) ? 2 : 1;
+    const int QB = 128 * qt;
     const int nqb = (a.max_frames + QB - 1) / QB;
     const int units = a.B * kHeads * a.groups;
     const int slots = (units + 7) / 8;
-    if (a.out32[0] != nullptr && a.hi_only) hipLaunchKernelGGL((attention3_kernel<true, 1>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
-    else if (a.out32[0] != nullptr) hipLaunchKernelGGL(attention3_kernel<true>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    if (!inference && a.hi_only) hipLaunchKernelGGL((attention3_kernel<true, 1>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    else if (!inference) hipLaunchKernelGGL(attention3_kernel<true>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    else if (qt == 2) hipLaunchKernelGGL((attention3_kernel<false, 3, 2>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else hipLaunchKernelGGL(attention3_kernel<false>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     return hipGetLastError();
 }
