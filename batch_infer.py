@@ -47,9 +47,12 @@ def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, 
     """Rows ``indices`` of the CSV -> {row index: (note_seq, note_dur)}.  WAV files are read by a thread pool with a
     bounded read-ahead; up to ``flush_batches`` device batches of rows go through ``infer_files`` at a time (upload +
     RMS of batch k + 1 overlap the forward of batch k); chunks of consecutive rows share packed device batches."""
+    import os
+    import time
     hop = config['hop_size']
     infer_ins.max_batch_frames = max_batch_frames
     out: Dict[int, tuple] = {}
+    stage_s = {'wav_wait': 0.0, 'device': 0.0, 'align_submit': 0.0, 'align_drain': 0.0}     # SOME_AMD_PROFILE_HOST=1 prints them
     jobs = []
     for i in indices:
         audio_path = data_path / 'wavs' / f"{rows[i]['name']}.wav"
@@ -71,6 +74,7 @@ def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, 
     def flush(group):
         # Slicer.slice + infer of batch_infer.py:52-57 for many rows at once: files go up as stored (int16 PCM), the
         # RMS curve and the chunk cut run on the device, the silence decisions on the host
+        t_dev = time.perf_counter()
         if device_ingest:
             per_file = infer_ins.infer_files([pcm for _, pcm in group], slicer)
         else:
@@ -79,12 +83,15 @@ def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, 
                 wave = pcm if pcm.dtype == np.float32 else pcm.astype(np.float32) / np.float32(32768.0)
                 chunks = slicer.slice(wave)
                 per_file.append(list(zip([c['offset'] for c in chunks], infer_ins.infer([c['waveform'] for c in chunks]))))
+        t_al = time.perf_counter()
+        stage_s['device'] += t_al - t_dev
         for (i, _), segments in zip(group, per_file):
             job = ([off for off, _ in segments], [seg for _, seg in segments], rows[i]['ph_dur'], rows[i]['ph_num'], round_midi)
             if align_pool is None:
                 out[i] = batch_logic.align_job(*job)
             else:
                 align_pool.submit(i, job)
+        stage_s['align_submit'] += time.perf_counter() - t_al
 
     rate = config['audio_sample_rate']
     with ThreadPoolExecutor(max_workers=io_threads) as pool:
@@ -103,7 +110,9 @@ def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, 
         while window:
             i, fut = window.popleft()
             refill()
+            t_w = time.perf_counter()
             pcm, _ = fut.result()
+            stage_s['wav_wait'] += time.perf_counter() - t_w
             t = 1 + pcm.shape[-1] // hop
             if group and frames + t > flush_batches * max_batch_frames:
                 flush(group)
@@ -113,7 +122,11 @@ def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, 
         if group:
             flush(group)
     if align_pool is not None:
+        t_d = time.perf_counter()
         out.update(align_pool.close())
+        stage_s['align_drain'] = time.perf_counter() - t_d
+    if os.environ.get('SOME_AMD_PROFILE_HOST'):
+        print('host stages [s]: ' + ', '.join(f'{k} {v:.2f}' for k, v in stage_s.items()) + f' ({len(jobs)} files)')
     return out
 
 

@@ -375,6 +375,10 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
     };
     qk(0, sa0, sa1);
     mask_tile(0, sa0, sa1);
+    // QK(0) read K ring slot 0, and the first step's lstore_k(2) overwrites that slot: without this barrier a fast
+    // wavefront races ahead of a slow one still reading its K(0) fragments (seen as rare large errors, run-to-run
+    // differences, on clips whose first key tile needs no masking - nothing else sat between the two)
+    __syncthreads();
     int i = 0;
     if constexpr (!TRAIN) {       // (the training variants sit at the register limit: the extra loop body makes them spill)
         for (; i + 4 < n; i += 2) {
