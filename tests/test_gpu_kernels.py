@@ -312,7 +312,7 @@ def test_qkv_attention_f16x3(eng, lens):
         q, k, v = (x[:, i * 512:(i + 1) * 512].reshape(t, 8, 64).transpose(0, 1) for i in range(3))
         ref = (torch.softmax(q @ k.transpose(1, 2) * 0.125, dim=-1) @ v).transpose(0, 1).reshape(t, 512).float()
         err = (got[s:s + t] - ref).abs().max().item()
-        assert err < 1e-5, (b, t, err)
+        assert err < 1.2e-5, (b, t, err)            # measured 6e-6 .. 1.0e-5 over 2584 keys with the x3 sharpened scores
 
 
 @pytest.mark.parametrize('tile', [0, 1, 2, 4])
