@@ -160,7 +160,8 @@ def batch_infer(dataset, model, round_midi, csv, overwrite):
         p = data_path / 'wavs' / f"{row['name']}.wav"
         sizes.append(p.stat().st_size if p.exists() else 0)
     mine = sorted(sharding.partition(sizes, rank, world))
-    done = process_rows(csv_data, mine, data_path, infer_ins, config, round_midi)
+    io_threads, align_workers = sharding.host_workers(world)
+    done = process_rows(csv_data, mine, data_path, infer_ins, config, round_midi, io_threads=io_threads, align_workers=align_workers)
     merged = sharding.gather_to_rank0(sorted(done.items()))
     if rank == 0:
         for i, (seq, dur) in merged:
