@@ -204,6 +204,7 @@ int some_create(const SomeConfig* cfg, SomeHandle** out) {
     h->tile = -1;                                    // -1: pick per launch from the grid size
     if (const char* t = getenv("SOME_AMD_TILE")) h->tile = atoi(t);
     if (const char* t = getenv("SOME_AMD_GEMM_FLAGS")) h->gemm_flags = atoi(t);
+    if (const char* t = getenv("SOME_AMD_DUAL_STREAM")) h->dual_stream = atoi(t) != 0;
     build_layout(h->cfg, h->lay);
     *out = h;
     return SOME_OK;
@@ -212,6 +213,7 @@ int some_create(const SomeConfig* cfg, SomeHandle** out) {
 void some_destroy(SomeHandle* h) {
     if (!h) return;
     if (h->mel_blob) (void)hipFree(h->mel_blob);
+    if (h->aux_stream) { (void)hipStreamDestroy(h->aux_stream); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
     for (auto& r : h->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
     delete h;
@@ -448,58 +450,160 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
     }
 
     const bool f16x3 = h->precision == SOME_PRECISION_F16X3;
-    auto pick_tile = [&](int n_max) -> int {
+    auto pick_tile = [&](int n_max, int ng) -> int {
         if (h->tile >= 0) return h->tile;
-        auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((n_max + bn - 1) / bn) * kStreams; };
+        auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((n_max + bn - 1) / bn) * ng; };
         if (blocks(256, 256) >= 512) return 2;       // >= 2 waves of workgroups over 256 CUs
         if (blocks(256, 128) >= 512) return 1;
         if (blocks(128, 128) >= 256) return 0;       // 128 x 128 tiles run two per CU (measured: 2 x 30 s clips 7.7 vs 8.5 ms)
         return 4;                                    // 64 x 128: single-clip latency regime (1 x 30 s: 5.07 vs 5.13 ms)
     };
-    auto launch_any = [&](GemmEpi epi, GemmArgs& a, bool out_split, int n_max) -> hipError_t {
-        if (f16x3) return launch_gemm_f16x3(epi, a, out_split, pick_tile(n_max), s);
-        return launch_gemm(epi, a, s);
-    };
-    auto gemm = [&](const char* name, GemmEpi epi, GemmArgs& a, int n_out_total, bool out_split = false) -> int {
-        a.groups = kStreams; a.M = M; a.flags = h->gemm_flags;
-        const double flops = 2.0 * Md * a.K * n_out_total;
-        Scope sc(h, s, name, flops, 0.0);
-        hipError_t e = launch_any(epi, a, out_split, n_out_total / kStreams);
+    // Every launch covers the model streams [g0, g0 + ng) as blockIdx.y groups: both (grouped, one HIP stream), or one
+    // model stream per HIP stream (dual-stream mode below).
+    auto gemm = [&](const char* name, GemmEpi epi, GemmArgs& a, int ng, int n_out, hipStream_t st, bool out_split = false) -> int {
+        a.groups = ng; a.M = M; a.flags = h->gemm_flags;
+        const double flops = 2.0 * Md * a.K * n_out * ng;
+        Scope sc(h, st, name, flops, 0.0);
+        hipError_t e = f16x3 ? launch_gemm_f16x3(epi, a, out_split, pick_tile(n_out, ng), st) : launch_gemm(epi, a, st);
         if (e != hipSuccess) return fail_hip(h, e, name);
         return SOME_OK;
     };
     // f32 mode: dst gets fp32.  f16x3 mode: dst gets SPLIT32 (GEMM operand) and, if dst32 != null, an fp32 copy too.
-    auto ln = [&](int layer, int idx, float* const* src, float* const* dst, float* const* dst32 = nullptr) -> int {
+    auto ln = [&](int layer, int idx, int g0, int ng, hipStream_t st, float* const* src, float* const* dst, float* const* dst32 = nullptr) -> int {
         LnArgs a{};
-        for (int g = 0; g < kStreams; ++g) {
+        for (int gi = 0; gi < ng; ++gi) {
+            const int g = g0 + gi;
             const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
-            a.x[g] = src[g]; a.gamma[g] = W + b.ln_g[idx]; a.beta[g] = W + b.ln_b[idx];
-            if (f16x3) { a.ys[g] = dst[g]; a.y[g] = dst32 ? dst32[g] : nullptr; }
-            else { a.y[g] = dst[g]; a.ys[g] = nullptr; }
+            a.x[gi] = src[g]; a.gamma[gi] = W + b.ln_g[idx]; a.beta[gi] = W + b.ln_b[idx];
+            if (f16x3) { a.ys[gi] = dst[g]; a.y[gi] = dst32 ? dst32[g] : nullptr; }
+            else { a.y[gi] = dst[g]; a.ys[gi] = nullptr; }
         }
-        a.groups = kStreams; a.M = M;
-        Scope sc(h, s, "layernorm", 0.0, 2.0 * kStreams * Md * kDim * 4);
-        hipError_t e = launch_layernorm(a, s);
+        a.groups = ng; a.M = M;
+        Scope sc(h, st, "layernorm", 0.0, 2.0 * ng * Md * kDim * 4);
+        hipError_t e = launch_layernorm(a, st);
         if (e != hipSuccess) return fail_hip(h, e, "layernorm");
         return SOME_OK;
     };
-    auto ffn = [&](int layer, int f) -> int {
+    auto ffn = [&](int layer, int f, int g0, int ng, hipStream_t st) -> int {
         GemmArgs a{};
-        for (int g = 0; g < kStreams; ++g) {
+        for (int gi = 0; gi < ng; ++gi) {
+            const int g = g0 + gi;
             const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
-            a.g[g] = GemmGroup{H[g], W + b.ffn_w1[f], W + b.ffn_b1[f], nullptr, U[g], nullptr, kFfn, 0};
+            a.g[gi] = GemmGroup{H[g], W + b.ffn_w1[f], W + b.ffn_b1[f], nullptr, U[g], nullptr, kFfn, 0};
         }
         a.K = kDim; a.lda = kDim; a.ldc = kFfn;
-        int rc = gemm("gemm_bias_silu[512->2048]", EPI_BIAS_SILU, a, kStreams * kFfn, /*out_split=*/f16x3);
+        int rc = gemm("gemm_bias_silu[512->2048]", EPI_BIAS_SILU, a, ng, kFfn, st, /*out_split=*/f16x3);
         if (rc) return rc;
         GemmArgs d{};
-        for (int g = 0; g < kStreams; ++g) {
+        for (int gi = 0; gi < ng; ++gi) {
+            const int g = g0 + gi;
             const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
-            d.g[g] = GemmGroup{U[g], W + b.ffn_w2[f], W + b.ffn_b2[f], X[g], X[g], nullptr, kDim, 0};
+            d.g[gi] = GemmGroup{U[g], W + b.ffn_w2[f], W + b.ffn_b2[f], X[g], X[g], nullptr, kDim, 0};
         }
         d.K = kFfn; d.lda = kFfn; d.ldc = kDim; d.ldr = kDim; d.alpha = 0.5f;
-        return gemm("gemm_bias_res[2048->512]", EPI_BIAS_RES, d, kStreams * kDim);
+        return gemm("gemm_bias_res[2048->512]", EPI_BIAS_RES, d, ng, kDim, st);
     };
+    // conform_blocke.forward (Gconform.py:56-63) for the model streams [g0, g0 + ng) of `layer`, enqueued on `st`
+    auto run_block = [&](int layer, int g0, int ng, hipStream_t st) -> int {
+        int rc;
+        if ((rc = ln(layer, 0, g0, ng, st, X, H))) return rc;
+        if ((rc = ffn(layer, 0, g0, ng, st))) return rc;
+        if ((rc = ln(layer, 1, g0, ng, st, X, H))) return rc;
+        if (f16x3) {
+            // QKV projection writes Q | K as SPLIT32 planes and V transposed; split-f16 attention consumes them
+            const int ldv = vt_ld(M);
+            GemmArgs a{};
+            Attn3Args t{};
+            for (int gi = 0; gi < ng; ++gi) {
+                const int g = g0 + gi;
+                float* qp = U[g];
+                float* kp = U[g] + m * kDim;
+                void* vt = U[g] + 2 * m * kDim;
+                a.g[gi] = GemmGroup{H[g], W + L.blocks[(size_t)layer * 2 + g].wqkv, nullptr, nullptr, qp, nullptr, 3 * kDim, 0, kp, vt, ldv};
+                t.q[gi] = qp; t.k[gi] = kp; t.vt[gi] = vt; t.out[gi] = H[g];
+            }
+            a.K = kDim; a.lda = kDim; a.ldc = kDim;
+            if ((rc = gemm("gemm[512->1536 qkv]", EPI_QKV, a, ng, 3 * kDim, st))) return rc;
+            t.frame_offsets = frame_offsets_dev; t.groups = ng; t.B = B; t.max_frames = max_frames; t.M = M; t.ldv = ldv;
+            Scope sc(h, st, "attention", 4.0 * kHeadDim * kHeads * ng * sumT2, 0.0);
+            HIP_TRY(h, launch_attention_f16x3(t, st));
+        } else {
+            GemmArgs a{};
+            AttnArgs t{};
+            for (int gi = 0; gi < ng; ++gi) {
+                const int g = g0 + gi;
+                a.g[gi] = GemmGroup{H[g], W + L.blocks[(size_t)layer * 2 + g].wqkv, nullptr, nullptr, U[g], nullptr, 3 * kDim, 0};
+                t.qkv[gi] = U[g]; t.out[gi] = H[g];
+            }
+            a.K = kDim; a.lda = kDim; a.ldc = 3 * kDim;
+            if ((rc = gemm("gemm[512->1536 qkv]", EPI_NONE, a, ng, 3 * kDim, st))) return rc;
+            t.frame_offsets = frame_offsets_dev; t.groups = ng; t.B = B; t.max_frames = max_frames;
+            t.out_split = 0;
+            Scope sc(h, st, "attention", 4.0 * kHeadDim * kHeads * ng * sumT2, 0.0);
+            HIP_TRY(h, launch_attention(t, st));
+        }
+        {
+            GemmArgs a{};
+            for (int gi = 0; gi < ng; ++gi) {
+                const int g = g0 + gi;
+                const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
+                a.g[gi] = GemmGroup{H[g], W + b.wo, W + b.bo, X[g], X[g], nullptr, kDim, 0};
+            }
+            a.K = kDim; a.lda = kDim; a.ldc = kDim; a.ldr = kDim; a.alpha = 1.0f;
+            if ((rc = gemm("gemm_bias_res[512->512]", EPI_BIAS_RES, a, ng, kDim, st))) return rc;
+        }
+        if ((rc = ln(layer, 2, g0, ng, st, X, H))) return rc;
+        {
+            GemmArgs a{};
+            for (int gi = 0; gi < ng; ++gi) {
+                const int g = g0 + gi;
+                const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
+                a.g[gi] = GemmGroup{H[g], W + b.pw1_w, W + b.pw1_b, nullptr, G[g], nullptr, 2 * kDim, 0};
+            }
+            a.K = kDim; a.lda = kDim; a.ldc = kDim;
+            if ((rc = gemm("gemm_glu[512->2x512]", EPI_GLU, a, ng, 2 * kDim, st))) return rc;
+        }
+        {
+            DwArgs a{};
+            for (int gi = 0; gi < ng; ++gi) {
+                const int g = g0 + gi;
+                const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
+                a.x[gi] = G[g]; a.y[gi] = H[g]; a.w[gi] = W + b.dw_w; a.b[gi] = W + b.dw_b;
+            }
+            a.frame_offsets = frame_offsets_dev; a.groups = ng; a.B = B; a.max_frames = max_frames;
+            a.out_split = f16x3 ? 1 : 0;
+            Scope sc(h, st, "dwconv_bn_silu", 0.0, 2.0 * ng * Md * kDim * 4);
+            HIP_TRY(h, launch_dwconv(a, st));
+        }
+        {
+            GemmArgs a{};
+            for (int gi = 0; gi < ng; ++gi) {
+                const int g = g0 + gi;
+                const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
+                a.g[gi] = GemmGroup{H[g], W + b.pw2_w, W + b.pw2_b, X[g], X[g], nullptr, kDim, 0};
+            }
+            a.K = kDim; a.lda = kDim; a.ldc = kDim; a.ldr = kDim; a.alpha = 1.0f;
+            if ((rc = gemm("gemm_bias_res[512->512]", EPI_BIAS_RES, a, ng, kDim, st))) return rc;
+        }
+        if ((rc = ln(layer, 3, g0, ng, st, X, H))) return rc;
+        if ((rc = ffn(layer, 1, g0, ng, st))) return rc;
+        // block output y: f32 mode keeps it in H; f16x3 mode needs it twice - SPLIT32 in H as the next GEMM's
+        // operand and fp32 in X (in place) as the exact residual of the cross gate
+        return ln(layer, 4, g0, ng, st, X, H, X);
+    };
+
+    // Dual-stream mode: the midi and the bound stream of a layer are independent until the cross gate
+    // (Gconform.py:82-87), so each runs on its own HIP stream (fork / join with events around every layer).  While one
+    // chain sits in an HBM-bound kernel (LayerNorm, depthwise conv, a GEMM's epilogue tail) the other's MFMA-bound GEMM
+    // or attention shares the CUs - LayerNorm waves fit beside a GEMM workgroup (no LDS, ~30 VGPRs).  Kernel-level
+    // HIP-event profiling needs serial execution: it uses the grouped single-stream path.
+    const bool dual = h->dual_stream && !h->profiling;
+    if (dual && !h->aux_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    hipStream_t s2 = dual ? h->aux_stream : s;
 
     int rc;
     {   // Gconform.py:124-127: the two input projections (+ masked_fill on the midi stream)
@@ -513,86 +617,16 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
         }
     }
     for (int layer = 0; layer <= c.lay; ++layer) {
-        // ---- conform_blocke.forward (Gconform.py:56-63), both streams per launch
-        if ((rc = ln(layer, 0, X, H))) return rc;
-        if ((rc = ffn(layer, 0))) return rc;
-        if ((rc = ln(layer, 1, X, H))) return rc;
-        if (f16x3) {
-            // QKV projection writes Q | K as SPLIT32 planes and V transposed; split-f16 attention consumes them
-            const int ldv = vt_ld(M);
-            GemmArgs a{};
-            Attn3Args t{};
-            for (int g = 0; g < kStreams; ++g) {
-                float* qp = U[g];
-                float* kp = U[g] + m * kDim;
-                void* vt = U[g] + 2 * m * kDim;
-                a.g[g] = GemmGroup{H[g], W + L.blocks[(size_t)layer * 2 + g].wqkv, nullptr, nullptr, qp, nullptr, 3 * kDim, 0, kp, vt, ldv};
-                t.q[g] = qp; t.k[g] = kp; t.vt[g] = vt; t.out[g] = H[g];
-            }
-            a.K = kDim; a.lda = kDim; a.ldc = kDim;
-            if ((rc = gemm("gemm[512->1536 qkv]", EPI_QKV, a, kStreams * 3 * kDim))) return rc;
-            t.frame_offsets = frame_offsets_dev; t.groups = kStreams; t.B = B; t.max_frames = max_frames; t.M = M; t.ldv = ldv;
-            Scope sc(h, s, "attention", 4.0 * kHeadDim * kHeads * kStreams * sumT2, 0.0);
-            HIP_TRY(h, launch_attention_f16x3(t, s));
-        } else {
-            GemmArgs a{};
-            for (int g = 0; g < kStreams; ++g)
-                a.g[g] = GemmGroup{H[g], W + L.blocks[(size_t)layer * 2 + g].wqkv, nullptr, nullptr, U[g], nullptr, 3 * kDim, 0};
-            a.K = kDim; a.lda = kDim; a.ldc = 3 * kDim;
-            if ((rc = gemm("gemm[512->1536 qkv]", EPI_NONE, a, kStreams * 3 * kDim))) return rc;
+        if (dual) {
+            HIP_TRY(h, hipEventRecord(h->ev_fork, s));
+            HIP_TRY(h, hipStreamWaitEvent(s2, h->ev_fork, 0));
+            if ((rc = run_block(layer, 0, 1, s))) return rc;
+            if ((rc = run_block(layer, 1, 1, s2))) return rc;
+            HIP_TRY(h, hipEventRecord(h->ev_join, s2));
+            HIP_TRY(h, hipStreamWaitEvent(s, h->ev_join, 0));
+        } else if ((rc = run_block(layer, 0, kStreams, s))) {
+            return rc;
         }
-        if (!f16x3) {
-            AttnArgs a{};
-            for (int g = 0; g < kStreams; ++g) { a.qkv[g] = U[g]; a.out[g] = H[g]; }
-            a.frame_offsets = frame_offsets_dev; a.groups = kStreams; a.B = B; a.max_frames = max_frames;
-            a.out_split = 0;
-            Scope sc(h, s, "attention", 4.0 * kHeadDim * kHeads * kStreams * sumT2, 0.0);
-            HIP_TRY(h, launch_attention(a, s));
-        }
-        {
-            GemmArgs a{};
-            for (int g = 0; g < kStreams; ++g) {
-                const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
-                a.g[g] = GemmGroup{H[g], W + b.wo, W + b.bo, X[g], X[g], nullptr, kDim, 0};
-            }
-            a.K = kDim; a.lda = kDim; a.ldc = kDim; a.ldr = kDim; a.alpha = 1.0f;
-            if ((rc = gemm("gemm_bias_res[512->512]", EPI_BIAS_RES, a, kStreams * kDim))) return rc;
-        }
-        if ((rc = ln(layer, 2, X, H))) return rc;
-        {
-            GemmArgs a{};
-            for (int g = 0; g < kStreams; ++g) {
-                const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
-                a.g[g] = GemmGroup{H[g], W + b.pw1_w, W + b.pw1_b, nullptr, G[g], nullptr, 2 * kDim, 0};
-            }
-            a.K = kDim; a.lda = kDim; a.ldc = kDim;
-            if ((rc = gemm("gemm_glu[512->2x512]", EPI_GLU, a, kStreams * 2 * kDim))) return rc;
-        }
-        {
-            DwArgs a{};
-            for (int g = 0; g < kStreams; ++g) {
-                const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
-                a.x[g] = G[g]; a.y[g] = H[g]; a.w[g] = W + b.dw_w; a.b[g] = W + b.dw_b;
-            }
-            a.frame_offsets = frame_offsets_dev; a.groups = kStreams; a.B = B; a.max_frames = max_frames;
-            a.out_split = f16x3 ? 1 : 0;
-            Scope sc(h, s, "dwconv_bn_silu", 0.0, 2.0 * kStreams * Md * kDim * 4);
-            HIP_TRY(h, launch_dwconv(a, s));
-        }
-        {
-            GemmArgs a{};
-            for (int g = 0; g < kStreams; ++g) {
-                const BlockOff& b = L.blocks[(size_t)layer * 2 + g];
-                a.g[g] = GemmGroup{H[g], W + b.pw2_w, W + b.pw2_b, X[g], X[g], nullptr, kDim, 0};
-            }
-            a.K = kDim; a.lda = kDim; a.ldc = kDim; a.ldr = kDim; a.alpha = 1.0f;
-            if ((rc = gemm("gemm_bias_res[512->512]", EPI_BIAS_RES, a, kStreams * kDim))) return rc;
-        }
-        if ((rc = ln(layer, 3, X, H))) return rc;
-        if ((rc = ffn(layer, 1))) return rc;
-        // block output y: f32 mode keeps it in H; f16x3 mode needs it twice - SPLIT32 in H as the next GEMM's
-        // operand and fp32 in X (in place) as the exact residual of the cross gate
-        if ((rc = ln(layer, 4, X, H, X))) return rc;
         if (layer < c.lay) {
             // Gcf.forward (Gconform.py:82-87): midi' = y0 + GLU(glu2(y1)), bound' = y1 + GLU(glu1(y0));
             // then masked_fill on the midi stream (Gconform.py:131-132)
@@ -602,7 +636,7 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
             a.g[0] = GemmGroup{H[1], W + L.glu_w[(size_t)layer * 2 + 1], W + L.glu_b[(size_t)layer * 2 + 1], res0, X[0], row_mask_dev, 2 * kDim, 0};
             a.g[1] = GemmGroup{H[0], W + L.glu_w[(size_t)layer * 2 + 0], W + L.glu_b[(size_t)layer * 2 + 0], res1, X[1], nullptr, 2 * kDim, 0};
             a.K = kDim; a.lda = kDim; a.ldc = kDim; a.ldr = kDim;
-            if ((rc = gemm("gemm_glu_res[512->2x512 gate]", EPI_GLU_RES, a, kStreams * 2 * kDim))) return rc;
+            if ((rc = gemm("gemm_glu_res[512->2x512 gate]", EPI_GLU_RES, a, kStreams, 2 * kDim, s))) return rc;
         }
     }
     {   // heads (Gconform.py:135-138, Gmidi_conform.py:33-37)

@@ -224,6 +224,9 @@ struct SomeHandle {
     int precision = 0;          // SOME_PRECISION_*
     int tile = 2;               // f16x3 GEMM tile selector (tuning knob)
     int gemm_flags = GEMM_FLAG_TR;   // SOME_AMD_GEMM_FLAGS overrides (A/B runs)
+    bool dual_stream = true;         // midi / bound model streams on two HIP streams (SOME_AMD_DUAL_STREAM=0: grouped launches)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<ProfRecord> prof;
     std::vector<hipEvent_t> event_pool;
 };
