@@ -185,7 +185,10 @@ def main():
                                f'44.1 kHz mono clips per GPU (lay {lay}, {outdim} bins, T={T} frames/clip), random-init weights',
                    'clips_per_gpu': args.batch, 'clip_seconds': args.seconds, 'frames_per_clip': T,
                    'gemm_precision': precision_name,
-                   'parallelism': f'utterance-sharded x{world}, RCCL weight broadcast, no data-path collective'},
+                   'parallelism': f'utterance-sharded x{world}, RCCL weight broadcast, no data-path collective',
+                   'execution': 'per GPU: the midi and bound model streams of each layer run on two HIP streams (fork / join per '
+                                'layer); the per-kernel leg below is measured with serial grouped launches (HIP events need it), so '
+                                'its kernel times sum to slightly more than ms_per_step'},
         'model_tflops': round(step_flops * world / (ms_per_step * 1e-3) / 1e12, 2),
         'notes_decoded_last_step': n_notes,
     }
