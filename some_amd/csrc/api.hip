@@ -597,7 +597,11 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
     // chain sits in an HBM-bound kernel (LayerNorm, depthwise conv, a GEMM's epilogue tail) the other's MFMA-bound GEMM
     // or attention shares the CUs - LayerNorm waves fit beside a GEMM workgroup (no LDS, ~30 VGPRs).  Kernel-level
     // HIP-event profiling needs serial execution: it uses the grouped single-stream path.
-    const bool dual = h->dual_stream && !h->profiling;
+    bool dual = h->dual_stream && !h->profiling;
+    if (dual && !h->aux_stream) {      // first use: the helper stream cannot be created while the caller's stream is being captured
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) dual = false;
+    }
     if (dual && !h->aux_stream) {
         HIP_TRY(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));

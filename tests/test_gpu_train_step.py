@@ -250,3 +250,42 @@ def test_checkpoint_resume_is_bit_identical():
     assert c.global_step == a.global_step == 6
     assert torch.equal(c.model.params.flat, a.model.params.flat)
     assert torch.equal(c.exp_avg_sq, a.exp_avg_sq)
+
+
+def test_trained_checkpoint_keeps_parity_with_the_cpu_oracle(tmp_path):
+    """Weights that have actually been TRAINED (train.py, 150 updates on synthetic sung clips: peaked attention, non-trivial
+    BatchNorm statistics, LayerNorm gains away from 1) through both GEMM precisions vs the fp32 CPU oracle, on a sung clip the
+    model never saw: probs / bounds within the logit tolerance, the same note sequence from both precisions."""
+    import pathlib
+    import subprocess
+    import sys
+    import numpy as np
+    from oracle import restate
+    root = pathlib.Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / 'train.py'), '--config', 'two_head_model', '--exp_name', 'exp', '--work_dir', str(tmp_path),
+                        '--synthetic', '32', '--max_updates', '150', '--log_interval', '50'], capture_output=True, text=True, cwd=root, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ckpt = tmp_path / 'exp' / 'model_ckpt_steps_150.ckpt'
+    sys.path.insert(0, str(root))
+    from infer import load_inference
+    from some_amd.training import data
+    wave, _, _, _ = data.synth_note_clip(4321, 8.0)
+    sd = {k[len('model.'):]: v for k, v in torch.load(ckpt, map_location='cpu')['state_dict'].items() if k.startswith('model.')}
+    notes = {}
+    for prec in ('f16x3', 'f32'):
+        import yaml
+        cfg = yaml.safe_load(open(tmp_path / 'exp' / 'config.yaml'))
+        cfg['some_amd_precision'] = prec
+        from inference import MIDIExtractionInference
+        ins = MIDIExtractionInference(config=cfg, model_path=ckpt)
+        sample = ins.preprocess(wave)
+        out = ins.forward_model(sample)
+        ref = restate.infer_clip(sd, cfg, wave)
+        ep = float(np.abs(out['probs'][0].cpu().numpy() - ref['_probs']).max())
+        eb = float(np.abs(out['bounds'][0].cpu().numpy() - ref['_bounds']).max())
+        print(f'trained checkpoint [{prec}]: max|dprob| {ep:.2e} max|dbound| {eb:.2e} vs the fp32 CPU oracle')
+        assert ep < 1e-4 and eb < 1e-4
+        notes[prec] = ins.postprocess(out)
+    assert len(notes['f16x3']['note_midi']) >= 1
+    np.testing.assert_array_equal(notes['f16x3']['note_dur'], notes['f32']['note_dur'])
+    np.testing.assert_array_equal(notes['f16x3']['note_rest'], notes['f32']['note_rest'])

@@ -131,3 +131,25 @@ def test_fullsize_clip_oracle_vs_reference(golden_dir, name):
     np.testing.assert_array_equal(dec['note_dur'], g[k + '.note_dur_frames'] * (512 / 44100))
     np.testing.assert_array_equal(dec['note_rest'], g[k + '.note_rest'])
     np.testing.assert_allclose(dec['note_midi'], g[k + '.note_midi'], rtol=1e-6, atol=0)
+
+
+def test_mel_filterbank_analytic_properties():
+    """Checks of the restated librosa.filters.mel that do NOT go through our own code path (librosa itself is absent):
+    the HTK mel formula at known points, the 82 band edges it implies, triangle peaks at the centre frequencies, and the
+    Slaney area normalisation (sum of a band's weights x bin spacing = 1 up to the discretisation of a wide triangle)."""
+    fb = restate.mel_filterbank().astype(np.float64)
+    assert abs(float(restate.hz_to_mel_htk(1000.0)) - 999.9855) < 1e-3          # 2595 log10(1 + 1000 / 700)
+    assert abs(float(restate.mel_to_hz_htk(restate.hz_to_mel_htk(4321.0))) - 4321.0) < 1e-9
+    edges = 700.0 * (10.0 ** (np.linspace(2595.0 * np.log10(1 + 40 / 700), 2595.0 * np.log10(1 + 8000 / 700), 82) / 2595.0) - 1.0)
+    df = 22050.0 / 1024
+    freqs = np.arange(1025) * df
+    for m in (10, 40, 60, 79):
+        lo, c, hi = edges[m], edges[m + 1], edges[m + 2]
+        nz = np.nonzero(fb[m])[0]
+        assert freqs[nz[0]] > lo and freqs[nz[-1]] < hi                          # support strictly inside (f_m, f_m+2)
+        assert nz[0] - 1 <= np.floor(lo / df) + 1 and nz[-1] + 1 >= np.ceil(hi / df) - 1
+        k = int(np.argmax(fb[m]))
+        assert abs(freqs[k] - c) <= df                                           # peak at the centre frequency
+        assert abs(fb[m, k] - 2.0 / (hi - lo) * (1 - abs(freqs[k] - c) / (c - lo if freqs[k] < c else hi - c))) < 1e-9 + 1e-6 * fb[m, k]
+        if hi - lo > 8 * df:
+            assert abs(fb[m].sum() * df - 1.0) < 0.05                            # unit area
