@@ -135,7 +135,7 @@ size_t some_workspace_bytes(const SomeHandle* h, int64_t total_frames, int32_t B
  * Streams: everything is ordered after the work already on `stream` and complete before anything enqueued on it
  * afterwards.  Inside, the two model streams of a layer (midi / bound, Gconform.py:82-87) run on `stream` and on a helper
  * stream the handle owns, forked and joined with events around every layer (SOME_AMD_DUAL_STREAM=0, kernel profiling, or a
- * first call made while `stream` is being captured: everything on `stream`).  One call at a time per handle. */
+ * first call made while `stream` is being captured: everything on `stream`).  Concurrent calls on one handle are serialised while they enqueue. */
 int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_offsets_dev, int32_t B,
                  int64_t total_frames, int32_t max_frames, const uint8_t* row_mask_dev, int32_t head_mode,
                  float* midi_dev, float* bound_dev, void* workspace_dev, size_t workspace_bytes, void* stream);

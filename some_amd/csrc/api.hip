@@ -598,6 +598,8 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
     // or attention shares the CUs - LayerNorm waves fit beside a GEMM workgroup (no LDS, ~30 VGPRs).  Kernel-level
     // HIP-event profiling needs serial execution: it uses the grouped single-stream path.
     bool dual = h->dual_stream && !h->profiling;
+    std::unique_lock<std::mutex> fwd_lock(h->fwd_mu, std::defer_lock);      // the helper stream and its events are per handle
+    if (dual) fwd_lock.lock();
     if (dual && !h->aux_stream) {      // first use: the helper stream cannot be created while the caller's stream is being captured
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) dual = false;
