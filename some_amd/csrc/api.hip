@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <set>
+#include <thread>
 
 #include "internal.h"
 #include "split.h"
@@ -321,13 +322,24 @@ int some_pack_weights(SomeHandle* h, const SomeTensorDesc* tensors, int32_t n, f
     }
     if (h->precision == SOME_PRECISION_F16X3) {
         // every GEMM weight except the K = units_dim input projections -> SPLIT32 in place (same byte size)
+        // 117 M weights (lay 8): the in-place conversion is spread over a few host threads (a cold start spends ~1 s here)
         auto to_split = [&](size_t off, size_t rows, size_t K) {
-            half_t tmp[64];
-            for (size_t i = 0; i < rows * (K / 32); ++i) {
-                float* blk = arena + off + i * 32;
-                for (int j = 0; j < 32; ++j) split_f16(blk[j], tmp[j], tmp[32 + j]);
-                memcpy(blk, tmp, 128);
-            }
+            const size_t n_blk = rows * (K / 32);
+            const unsigned hw = std::thread::hardware_concurrency();
+            const size_t n_thr = n_blk < 4096 ? 1 : std::min<size_t>(8, hw ? hw : 1);
+            auto work = [&](size_t b0, size_t b1) {
+                half_t tmp[64];
+                for (size_t i = b0; i < b1; ++i) {
+                    float* blk = arena + off + i * 32;
+                    for (int j = 0; j < 32; ++j) split_f16(blk[j], tmp[j], tmp[32 + j]);
+                    memcpy(blk, tmp, 128);
+                }
+            };
+            if (n_thr <= 1) { work(0, n_blk); return; }
+            std::vector<std::thread> pool;
+            const size_t per = (n_blk + n_thr - 1) / n_thr;
+            for (size_t t = 0; t < n_thr; ++t) pool.emplace_back(work, std::min(n_blk, t * per), std::min(n_blk, (t + 1) * per));
+            for (auto& th : pool) th.join();
         };
         to_split(L.out_w, (size_t)c.outdim, kDim);
         to_split(L.cut_w, 1, kDim);
