@@ -29,6 +29,34 @@ int fail_hip(SomeHandle* h, hipError_t e, const char* what) {
     } while (0)
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// fp32 k-blocks of 32 -> SPLIT32 in place with the x86 F16C conversions (round to nearest even, subnormals kept: the same
+// values as split.h's scalar split_f16, which falls back to a software conversion routine per element on the host).
+// Returns false when the CPU lacks F16C / AVX: the caller uses the scalar path.
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx,f16c"))) void split_blocks_f16c_impl(float* blk, size_t n_blocks) {
+    for (size_t i = 0; i < n_blocks; ++i, blk += 32) {
+        __m128i hi[4], lo[4];
+        for (int q = 0; q < 4; ++q) {
+            const __m256 x = _mm256_loadu_ps(blk + 8 * q);
+            hi[q] = _mm256_cvtps_ph(x, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+            lo[q] = _mm256_cvtps_ph(_mm256_sub_ps(x, _mm256_cvtph_ps(hi[q])), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+        }
+        for (int q = 0; q < 4; ++q) {
+            _mm_storeu_si128(reinterpret_cast<__m128i*>(blk) + q, hi[q]);
+            _mm_storeu_si128(reinterpret_cast<__m128i*>(blk) + 4 + q, lo[q]);
+        }
+    }
+}
+bool split_blocks_f16c(float* blk, size_t n_blocks) {
+    static const bool ok = __builtin_cpu_supports("f16c") && __builtin_cpu_supports("avx");
+    if (ok) split_blocks_f16c_impl(blk, n_blocks);
+    return ok;
+}
+#else
+bool split_blocks_f16c(float*, size_t) { return false; }
+#endif
 constexpr size_t kWsSlack = 1 << 20;   // per stream: room for the V^T row padding (ldv - M < 256 frames x 2 KiB)
 
 // ---- arena layout ------------------------------------------------------------------------------------
@@ -328,6 +356,7 @@ int some_pack_weights(SomeHandle* h, const SomeTensorDesc* tensors, int32_t n, f
             const unsigned hw = std::thread::hardware_concurrency();
             const size_t n_thr = n_blk < 4096 ? 1 : std::min<size_t>(8, hw ? hw : 1);
             auto work = [&](size_t b0, size_t b1) {
+                if (split_blocks_f16c(arena + off + b0 * 32, b1 - b0)) return;      // hardware conversions where the host has them
                 half_t tmp[64];
                 for (size_t i = b0; i < b1; ++i) {
                     float* blk = arena + off + i * 32;

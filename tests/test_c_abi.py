@@ -53,6 +53,17 @@ def test_pack_weights_layout_and_strictness():
     np.testing.assert_array_equal(hi, w.reshape(-1)[:32].astype(np.float16).astype(np.float32))
     # |x - hi - lo| <= 2^-22 |x|, floored by the f16 subnormal quantum (2^-24) / 2 for the small lo halves
     assert (np.abs(hi + lo - w.reshape(-1)[:32]) <= np.abs(w.reshape(-1)[:32]) * 2.0 ** -21 + 2.0 ** -25).all()
+    # the whole tensor, against numpy's own round-to-nearest-even fp16 conversions (the host side converts with F16C where
+    # the CPU has it): hi = f16(x), lo = f16(x - hi), bit for bit, tiny values (f16 subnormals) included
+    wf = (w.reshape(-1) * np.where(np.arange(w.size) % 7 == 0, 1e-4, 1.0)).astype(np.float32).reshape(w.shape)
+    sd2 = dict(sd, **{'model.outln.weight': wf})
+    a3 = eng3.pack_state_dict(sd2).numpy()
+    blocks = a3[off:off + wf.size].view(np.float16).reshape(-1, 2, 32)
+    x = wf.reshape(-1, 32)
+    want_hi = x.astype(np.float16)
+    want_lo = (x - want_hi.astype(np.float32)).astype(np.float16)
+    np.testing.assert_array_equal(blocks[:, 0].view(np.uint16), want_hi.view(np.uint16))
+    np.testing.assert_array_equal(blocks[:, 1].view(np.uint16), want_lo.view(np.uint16))
     assert arena.shape[0] == eng.arena_numel
     # first tensor of the arena is inln.weight verbatim
     np.testing.assert_array_equal(arena[:512 * 80].reshape(512, 80), sd['model.inln.weight'])
