@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t pack_split_pair(float v, int lane) {
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, bool FULL>
 __device__ __forceinline__ void epilogue(const GemmArgs& a, const GemmGroup& g, f32x16 (&acc)[TM][TN], int m0, int n0,
-                                         int wm, int wn, int lane) {
+                                         int wm, int wn, int lane, char* wave_lds = nullptr) {
     const int l31 = lane & 31, hi = lane >> 5;
     const uint32_t row_c = (uint32_t)a.ldc * 4u, row_r = (uint32_t)a.ldr * 4u;      // row pitches in bytes
     auto rk = [](int r) { return (uint32_t)((r & 3) + 8 * (r >> 2)); };             // row of element r within its tile
@@ -126,22 +126,40 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const GemmGroup& g, 
                     }
                 }
             } else {
-                const int d = n - 1024;
-                char* vh = reinterpret_cast<char*>(g.C3) + (size_t)d * g.ldv * 2;
-                char* vl = vh + (size_t)kDim * g.ldv * 2;
+                // V^T planes [d][frame] (f16 hi, then lo): a lane owns column d and 4-frame runs, so direct stores would be
+                // 8-byte pieces of 32 different rows per instruction.  The 32 x (32 TM) tile goes through a wave-private
+                // LDS patch instead ([plane][32 d][32 TM frames], rows padded to kVtRow bytes) and leaves as 16-byte
+                // stores in which TM * 4 neighbouring lanes cover a whole row segment (64 TM contiguous bytes).
+                constexpr int kVtRow = TM * 64 + 16;
+                char* patch = wave_lds;                                  // [2][32][kVtRow]
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int rq4 = 0; rq4 < 4; ++rq4) {
-                        const int m = m0 + (wm * TM + i) * 32 + 8 * rq4 + 4 * hi;     // 4 consecutive frames
                         half4 hh, ll;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { half_t h, l; split_f16(acc[i][jn][4 * rq4 + e], h, l); hh[e] = h; ll[e] = l; }
-                        if (FULL || m < g.ldv) {   // rows >= M carry exact zeros (zero-filled A rows, no bias): finite padding
-                            *reinterpret_cast<half4*>(vh + (size_t)m * 2) = hh;
-                            *reinterpret_cast<half4*>(vl + (size_t)m * 2) = ll;
-                        }
+                        const int f = i * 32 + 8 * rq4 + 4 * hi;          // first of 4 consecutive frames (tile-local)
+                        *reinterpret_cast<half4*>(patch + l31 * kVtRow + f * 2) = hh;
+                        *reinterpret_cast<half4*>(patch + 32 * kVtRow + l31 * kVtRow + f * 2) = ll;
                     }
+                __builtin_amdgcn_wave_barrier();
+                constexpr int LPR = TM * 4;                              // lanes per row (16 bytes = 8 frames each)
+                constexpr int RPI = 64 / LPR;                            // rows per instruction
+                const int d0 = n0 + (wn * TN + jn) * 32 - 1024;
+                const int mrow = m0 + wm * TM * 32 + (lane % LPR) * 8;
+#pragma unroll
+                for (int pass = 0; pass < 32 / RPI; ++pass) {
+                    const int dl = pass * RPI + lane / LPR;
+                    const f32x4 vh4 = *reinterpret_cast<const f32x4*>(patch + dl * kVtRow + (lane % LPR) * 16);
+                    const f32x4 vl4 = *reinterpret_cast<const f32x4*>(patch + 32 * kVtRow + dl * kVtRow + (lane % LPR) * 16);
+                    if (mrow < g.ldv) {   // rows >= M carry exact zeros (zero-filled A rows, no bias): finite padding
+                        char* vh = reinterpret_cast<char*>(g.C3) + ((size_t)(d0 + dl) * g.ldv + mrow) * 2;
+                        *reinterpret_cast<f32x4*>(vh) = vh4;
+                        *reinterpret_cast<f32x4*>(vh + (size_t)kDim * g.ldv * 2) = vl4;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
     } else {
@@ -512,10 +530,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
         else
             epilogue_tr<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane);
     } else {
+        char* wave_lds = nullptr;
+        if constexpr (EPI == EPI_QKV) {       // V^T tiles leave through a wave-private LDS patch: the stages must be drained
+            __syncthreads();
+            wave_lds = reinterpret_cast<char*>(lds) + wave * (2 * 32 * (TM * 64 + 16));
+        }
         if (m0 + BM <= a.M && n0 + BN <= g.N)
-            epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, true>(a, g, acc, m0, n0, wm, wn, lane);
+            epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, true>(a, g, acc, m0, n0, wm, wn, lane, wave_lds);
         else
-            epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane);
+            epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane, wave_lds);
     }
 }
 
@@ -631,10 +654,15 @@ __global__ __launch_bounds__(256, 2) void hgemm3_ring_kernel(GemmArgs a) {
         __builtin_amdgcn_s_barrier();
     }
 
+    char* wave_lds = nullptr;
+    if constexpr (EPI == EPI_QKV) {
+        __syncthreads();
+        wave_lds = lbase + wave * (2 * 32 * (TM * 64 + 16));
+    }
     if (m0 + BM <= a.M && n0 + BN <= g.N)
-        epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, true>(a, g, acc, m0, n0, wm, wn, lane);
+        epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, true>(a, g, acc, m0, n0, wm, wn, lane, wave_lds);
     else
-        epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane);
+        epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane, wave_lds);
 }
 
 template <int EPI, bool OUT_SPLIT>
