@@ -9,8 +9,8 @@
 //
 // Operands arrive pre-split from the QKV projection's epilogue (gemm_f16x3.hip, EPI_QKV):
 //   Q, K : [M, 512] SPLIT32 rows (split.h) - a head's 64 dims are 256 contiguous bytes (2 k-blocks of hi|lo);
-//   V^T  : hi and lo f16 planes [512, ldv] with the FRAME index contiguous, so a (d, 8-key) operand fragment
-//          is two ds_read_b64 and no transposition happens in this kernel.
+//   V^T  : hi and lo f16 planes [512, ldv] with the FRAME index contiguous (every aligned group of 16 frames stored as
+//          its quarters 0, 2, 1, 3), so a (d, 8-key) operand fragment is ONE ds_read_b128 and no transposition happens here.
 // Key tiles are aligned in GLOBAL frame coordinates (64 gt .. 64 gt + 63), which keeps every 16-byte V^T chunk
 // aligned however the clips are packed; keys outside the clip get score -inf (their data is another clip's
 // finite values or the zero padding the GEMM wrote, so 0 * v stays 0).
@@ -37,6 +37,12 @@ __device__ __forceinline__ float exp2_(float x) { return __builtin_amdgcn_exp2f(
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef ATTN_PV_FENCE
+#define ATTN_PV_FENCE 1
+#endif
+#ifndef ATTN_QK_FENCE
+#define ATTN_QK_FENCE 0
+#endif
 #ifndef ATTN_PIN_STAGING
 #define ATTN_PIN_STAGING 0
 #endif
@@ -179,6 +185,11 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
             const half8 kl0 = *reinterpret_cast<const half8*>(kp + off + 16);
             const half8 kh1 = *reinterpret_cast<const half8*>(kp + 32 * LDR + off);
             const half8 kl1 = *reinterpret_cast<const half8*>(kp + 32 * LDR + off + 16);
+#if ATTN_QK_FENCE == 1
+            __builtin_amdgcn_sched_barrier(0x407);      // ALU may cross (the previous tile's softmax), LDS reads / MFMAs may not
+#elif ATTN_QK_FENCE == 2
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             if (TERMS == 3) {
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
     // O^T += V^T P^T for tile i.  P slab (sub, s'): registers r = 8 s' .. 8 s' + 7 of the sub-tile hold keys
     // 16 s' + {0..3} + 4 kg and 16 s' + 8 + {0..3} + 4 kg  ->  two ds_read_b64 per V^T fragment
     auto pv = [&](int i, const f32x16 (&s0)[QT], const f32x16 (&s1)[QT]) {
-        const float* vp = vbuf(i) + l31 * LDR + 2 * kg;
+        const float* vp = vbuf(i) + l31 * LDR + (TRAIN ? 2 : 4) * kg;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -303,18 +314,31 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
                 // [32 hi | 32 lo][32 hi | 32 lo] (SPLIT32 over frames)
                 constexpr int LO = TRAIN ? 16 : 32;
                 const int kd = (TRAIN ? 32 : 16) * sub + 8 * sp;
-                const half4 a0 = *reinterpret_cast<const half4*>(vp + kd);
-                const half4 a1 = *reinterpret_cast<const half4*>(vp + kd + 4);
-                const half4 b0 = *reinterpret_cast<const half4*>(vp + LO + kd);
-                const half4 b1 = *reinterpret_cast<const half4*>(vp + LO + kd + 4);
-                const half4 c0 = *reinterpret_cast<const half4*>(vp + 32 * LDR + kd);
-                const half4 c1 = *reinterpret_cast<const half4*>(vp + 32 * LDR + kd + 4);
-                const half4 d0 = *reinterpret_cast<const half4*>(vp + 32 * LDR + LO + kd);
-                const half4 d1 = *reinterpret_cast<const half4*>(vp + 32 * LDR + LO + kd + 4);
-                const half8 vh0 = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                const half8 vl0 = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                const half8 vh1 = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
-                const half8 vl1 = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7);
+                half8 vh0, vl0, vh1, vl1;
+                if constexpr (TRAIN) {
+                    const half4 a0 = *reinterpret_cast<const half4*>(vp + kd);
+                    const half4 a1 = *reinterpret_cast<const half4*>(vp + kd + 4);
+                    const half4 b0 = *reinterpret_cast<const half4*>(vp + LO + kd);
+                    const half4 b1 = *reinterpret_cast<const half4*>(vp + LO + kd + 4);
+                    const half4 c0 = *reinterpret_cast<const half4*>(vp + 32 * LDR + kd);
+                    const half4 c1 = *reinterpret_cast<const half4*>(vp + 32 * LDR + kd + 4);
+                    const half4 d0 = *reinterpret_cast<const half4*>(vp + 32 * LDR + LO + kd);
+                    const half4 d1 = *reinterpret_cast<const half4*>(vp + 32 * LDR + LO + kd + 4);
+                    vh0 = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    vl0 = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    vh1 = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    vl1 = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7);
+                } else {
+                    // the QKV epilogue stores every 16-frame group as quarters 0, 2, 1, 3: this lane half's 8 keys
+                    // (4 kg + {0..3}, 8 + 4 kg + {0..3}) are the 16 bytes at 4 kg dwords - one conflict-free ds_read_b128
+                    vh0 = *reinterpret_cast<const half8*>(vp + kd);
+                    vl0 = *reinterpret_cast<const half8*>(vp + LO + kd);
+                    vh1 = *reinterpret_cast<const half8*>(vp + 32 * LDR + kd);
+                    vl1 = *reinterpret_cast<const half8*>(vp + 32 * LDR + LO + kd);
+#if ATTN_PV_FENCE
+                    __builtin_amdgcn_sched_barrier(0);   // the four reads of a group together, not one in front of each MFMA
+#endif
+                }
                 if (TERMS == 3) {
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {

@@ -139,7 +139,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const GemmGroup& g, 
                         half4 hh, ll;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { half_t h, l; split_f16(acc[i][jn][4 * rq4 + e], h, l); hh[e] = h; ll[e] = l; }
-                        const int f = i * 32 + 8 * rq4 + 4 * hi;          // first of 4 consecutive frames (tile-local)
+                        // frames are stored PERMUTED inside every aligned group of 16: quarters in the order 0, 2, 1, 3, so
+                        // that the 8 keys an attention lane needs for one MFMA (frames 4 kg + {0..3} and 8 + 4 kg + {0..3})
+                        // are 16 contiguous bytes - one conflict-free ds_read_b128 instead of two 2-way-conflicting b64
+                        const int fq = 2 * rq4 + hi;                      // quarter index (4 frames) within the 32-frame tile
+                        const int f = i * 32 + (fq & 4) * 4 + 4 * (((fq & 1) << 1) | ((fq >> 1) & 1));
                         *reinterpret_cast<half4*>(patch + l31 * kVtRow + f * 2) = hh;
                         *reinterpret_cast<half4*>(patch + 32 * kVtRow + l31 * kVtRow + f * 2) = ll;
                     }
