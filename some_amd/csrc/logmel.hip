@@ -22,8 +22,9 @@ constexpr int kFramesPerWg = 12;
 constexpr int kFramesPerWave = kFramesPerWg / 4;
 constexpr int kTile = kWin + (kFramesPerWg - 1) * kHop;          // 7680 samples
 constexpr int kMelPad = 32;                                      // padded band length of the LDS copy of the filterbank
+constexpr int kMelRow = kMelPad + 1;                             // LDS row stride: lane l reads row l - a stride of 32 floats would put all 64 lanes on one bank
 constexpr int kMelRows = kMels + 1;                              // + one all-zero row for lanes without a second band
-constexpr size_t kLdsBytes = (size_t)kTile * 4 + 4 * (size_t)FFT_TBUF * 8 + (size_t)kMelRows * kMelPad * 4;   // 75 904 B: two per CU
+constexpr size_t kLdsBytes = (size_t)kTile * 4 + 4 * (size_t)FFT_TBUF * 8 + (size_t)kMelRows * kMelRow * 4;   // 76 228 B: two per CU
 
 __device__ __forceinline__ float quad_xor2(float v) {     // value of lane ^ 2: quad_perm [2, 3, 0, 1]
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelTables t, const float
     }
     const bool padded = t.max_len <= kMelPad;
     if (padded)
-        for (int i = tid; i < kMelRows * kMelPad; i += 256) melpad[i] = t.mel_wpad[i];
+        for (int i = tid; i < kMelRows * kMelPad; i += 256) melpad[(i / kMelPad) * kMelRow + i % kMelPad] = t.mel_wpad[i];
 
     // per-lane constants, kept in registers for all frames of this wavefront
     float w0[16], w1[16];
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelTables t, const float
     __syncthreads();
 
     const int k1 = lane >> 2, qj = lane & 3, k3 = fft_quad_k3(qj);
-    const float* w0p = melpad + band0 * kMelPad;
-    const float* w1p = melpad + (band1 < kMels ? band1 : kMels) * kMelPad;
+    const float* w0p = melpad + band0 * kMelRow;
+    const float* w1p = melpad + (band1 < kMels ? band1 : kMels) * kMelRow;
     const int mel_steps = (t.max_len + 7) >> 3;
     for (int fi = 0; fi < kFramesPerWave; ++fi) {
         const int frame = fbase + wave * kFramesPerWave + fi;
