@@ -432,7 +432,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     auto frag = [&](const float* base, int tile, int s, int lo) {
         return *reinterpret_cast<const half8*>(base + tile * 32 * LDT + lo * 16 + s * 8);
     };
-    auto compute_staged = [&](int buf, int kt_load) {
+    // mode 0: steady state (store k-block kt + 1, load kt + 2); 1: second-to-last block (store only); 2: last block (neither)
+    auto compute_staged = [&](int buf, int kt_load, int mode) {
         const float* As = lds + buf * STAGE + a_off;
         const float* Ws = lds + buf * STAGE + w_off;
         float* wbase = lds + (buf ^ 1) * STAGE + dst0;
@@ -453,9 +454,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 #pragma unroll
             for (int o = 0; o < OPS; ++o) {
                 const int q = slot * OPS + o;
-                if (q < NLD) {
+                if (q < NLD && mode < 2) {
                     *reinterpret_cast<f32x4*>(wbase + q * RPP * LDT) = stage[q];
-                    stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q * RPP < BM ? rsa : rsw, voff[q], koff, 0));
+                    if (mode == 0)
+                        stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q * RPP < BM ? rsa : rsw, voff[q], koff, 0));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     int kt = 0;
     for (; kt + 2 < nk; ++kt) {
         if constexpr (TERMS == 3) {
-            compute_staged(kt & 1, kt + 2);
+            compute_staged(kt & 1, kt + 2, 0);
         } else {
             lstore((kt & 1) ^ 1);
             gload(kt + 2);
@@ -517,12 +519,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
         __syncthreads();
     }
     if (kt + 1 < nk) {
-        lstore((kt & 1) ^ 1);
-        compute(kt & 1);
+        if constexpr (TERMS == 3) {
+            compute_staged(kt & 1, 0, 1);
+        } else {
+            lstore((kt & 1) ^ 1);
+            compute(kt & 1);
+        }
         __syncthreads();
         ++kt;
     }
-    compute(kt & 1);
+    if constexpr (TERMS == 3) compute_staged(kt & 1, 0, 2);
+    else compute(kt & 1);
 
     // ---- epilogue (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
     // Interior workgroups take the unguarded path (no per-element exec masking).  Residual values are fetched one
