@@ -242,7 +242,7 @@ int some_create(const SomeConfig* cfg, SomeHandle** out) {
 void some_destroy(SomeHandle* h) {
     if (!h) return;
     if (h->mel_blob) (void)hipFree(h->mel_blob);
-    if (h->aux_stream) { (void)hipStreamDestroy(h->aux_stream); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
+    for (auto& a : h->aux_sets) { (void)hipStreamDestroy(a.aux); (void)hipEventDestroy(a.fork); (void)hipEventDestroy(a.join); }
     for (auto& r : h->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
     delete h;
@@ -641,16 +641,24 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
     bool dual = h->dual_stream && !h->profiling;
     std::unique_lock<std::mutex> fwd_lock(h->fwd_mu, std::defer_lock);      // the helper stream and its events are per handle
     if (dual) fwd_lock.lock();
-    if (dual && !h->aux_stream) {      // first use: the helper stream cannot be created while the caller's stream is being captured
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) dual = false;
+    SomeHandle::AuxSet* aux = nullptr;
+    if (dual) {
+        for (auto& a : h->aux_sets) if (a.caller == s) aux = &a;
+        if (!aux) {     // first use on this stream: the helper stream cannot be created while the caller's stream is being captured
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+                dual = false;
+            } else {
+                SomeHandle::AuxSet a{s, nullptr, nullptr, nullptr};
+                HIP_TRY(h, hipStreamCreateWithFlags(&a.aux, hipStreamNonBlocking));
+                HIP_TRY(h, hipEventCreateWithFlags(&a.fork, hipEventDisableTiming));
+                HIP_TRY(h, hipEventCreateWithFlags(&a.join, hipEventDisableTiming));
+                h->aux_sets.push_back(a);
+                aux = &h->aux_sets.back();
+            }
+        }
     }
-    if (dual && !h->aux_stream) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    }
-    hipStream_t s2 = dual ? h->aux_stream : s;
+    hipStream_t s2 = dual ? aux->aux : s;
 
     int rc;
     {   // Gconform.py:124-127: the two input projections (+ masked_fill on the midi stream)
@@ -665,12 +673,12 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
     }
     for (int layer = 0; layer <= c.lay; ++layer) {
         if (dual) {
-            HIP_TRY(h, hipEventRecord(h->ev_fork, s));
-            HIP_TRY(h, hipStreamWaitEvent(s2, h->ev_fork, 0));
+            HIP_TRY(h, hipEventRecord(aux->fork, s));
+            HIP_TRY(h, hipStreamWaitEvent(s2, aux->fork, 0));
             if ((rc = run_block(layer, 0, 1, s))) return rc;
             if ((rc = run_block(layer, 1, 1, s2))) return rc;
-            HIP_TRY(h, hipEventRecord(h->ev_join, s2));
-            HIP_TRY(h, hipStreamWaitEvent(s, h->ev_join, 0));
+            HIP_TRY(h, hipEventRecord(aux->join, s2));
+            HIP_TRY(h, hipStreamWaitEvent(s, aux->join, 0));
         } else if ((rc = run_block(layer, 0, kStreams, s))) {
             return rc;
         }

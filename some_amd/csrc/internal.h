@@ -226,9 +226,11 @@ struct SomeHandle {
     int tile = 2;               // f16x3 GEMM tile selector (tuning knob)
     int gemm_flags = GEMM_FLAG_TR;   // SOME_AMD_GEMM_FLAGS overrides (A/B runs)
     bool dual_stream = true;         // midi / bound model streams on two HIP streams (SOME_AMD_DUAL_STREAM=0: grouped launches)
-    hipStream_t aux_stream = nullptr;    // helper stream + fork / join events of the dual-stream forward; calls are serialised by fwd_mu
+    // helper stream + fork / join events of the dual-stream forward, one set per caller stream (two forwards enqueued on
+    // different streams must not share a helper stream); enqueues are serialised by fwd_mu
+    struct AuxSet { hipStream_t caller; hipStream_t aux; hipEvent_t fork, join; };
+    std::vector<AuxSet> aux_sets;
     std::mutex fwd_mu;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<ProfRecord> prof;
     std::vector<hipEvent_t> event_pool;
 };
