@@ -679,3 +679,28 @@ def test_bench_two_ranks_share_the_gpu_gloo():
     # whole-job value: both ranks' audio over the max-over-ranks time
     assert abs(res['value'] - 2 * 4 * 5.0 * 2 / (res['ms_per_step'] * 2e-3)) < 0.02 * res['value']
     assert res['notes_decoded_last_step'] > 0
+
+
+def test_dual_stream_forward_is_bit_identical_to_grouped_launches(monkeypatch):
+    """The default execution (midi / bound chains of a layer on two HIP streams, one group per launch) against the grouped
+    single-stream launches (SOME_AMD_DUAL_STREAM=0): the same kernels on the same data in a different launch grouping -
+    results must be bit-identical, also when repeated (fork / join events reused across layers and calls)."""
+    from some_amd import _lib
+    from some_amd.engine import ClipBatch, Engine
+    cfg = get_config('midi_conformer', lay=3)
+    sd = synth.synth_state_dict(cfg, 21)
+    rng = np.random.default_rng(4)
+    lens = [2584, 700, 64, 1, 2584, 333]
+    units = torch.from_numpy((rng.standard_normal((sum(lens), 80)) * 2 - 4).astype(np.float32)).cuda()
+    batch = ClipBatch(lens, 'cuda')
+    outs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('SOME_AMD_DUAL_STREAM', mode)
+        e = Engine(cfg, device='cuda')
+        e.load_state_dict(sd)
+        runs = [e.forward(units, batch, head_mode=_lib.HEAD_SIGMOID) for _ in range(3)]
+        torch.cuda.synchronize()
+        for m, b in runs[1:]:
+            assert torch.equal(m, runs[0][0]) and torch.equal(b, runs[0][1])
+        outs[mode] = runs[0]
+    assert torch.equal(outs['0'][0], outs['1'][0]) and torch.equal(outs['0'][1], outs['1'][1])
