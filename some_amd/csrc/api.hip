@@ -462,7 +462,8 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
     if (!h->arena) return fail(h, SOME_ESTATE, "some_forward: no weights attached (call some_attach_arena first)");
     if (B < 0 || total_frames < 0) return fail(h, SOME_EINVAL, "some_forward: negative size");
     if (B == 0 || total_frames == 0) return SOME_OK;
-    if (total_frames > (int64_t)1 << 30) return fail(h, SOME_EINVAL, "some_forward: total_frames too large");
+    // the widest activation row is 8 KiB (FFN hidden) and operands are addressed through 2 GiB buffer descriptors
+    if (total_frames > 262143) return fail(h, SOME_EINVAL, "some_forward: total_frames too large (at most 262143 frames = 50 minutes of audio per call; split the batch)");
     if (!units_dev || !frame_offsets_dev || !midi_dev || !bound_dev || !workspace_dev) return fail(h, SOME_EINVAL, "some_forward: null pointer");
     if (head_mode < 0 || head_mode > 2) return fail(h, SOME_EINVAL, "some_forward: bad head_mode");
     if (workspace_bytes < some_workspace_bytes(h, total_frames, B)) return fail(h, SOME_ENOMEM, "some_forward: workspace too small");
