@@ -118,6 +118,19 @@ int some_logmel(SomeHandle* h, const float* audio_dev, const int64_t* sample_off
                 const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, int32_t pad_mode,
                 float* units_dev, void* stream);
 
+/* Replaces: MelSpectrogram.forward(audio, keyshift, speed, center) for keyshift != 0, speed != 1 or center=False
+ * (modules/rmvpe/spec.py:38-72) - the key-shift augmentation of the training data
+ * (preprocessing/me_binarizer.py:235-246, me_quant_binarizer.py:39-48).  The caller evaluates spec.py:39-42 itself:
+ *   n_fft_new = round(n_fft * 2^(keyshift/12)), win_length_new likewise, hop_length_new = round(hop * speed);
+ * clip b yields T_b = 1 + (n_b + (center ? win_length_new : 0) - n_fft_new) / hop_length_new frames (the caller sizes
+ * frame_offsets with that; n_b + pad < n_fft_new is the caller's error, as it is torch.stft's).  rescale != 0 applies
+ * spec.py:63-68 (keep 1 + n_fft/2 bins, zero-fill, scale by win_length / win_length_new).  n_fft_new <= 4096 (key shifts
+ * up to +12 semitones, the range the reference's configs use).  Same packed layout and outputs as some_logmel. */
+int some_logmel_shifted(SomeHandle* h, const float* audio_dev, const int64_t* sample_offsets_dev,
+                        const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, int32_t n_fft_new,
+                        int32_t win_length_new, int32_t hop_length_new, int32_t center, int32_t rescale, float* units_dev,
+                        void* stream);
+
 /* ---- network ------------------------------------------------------------------------------------ */
 
 #define SOME_HEAD_LOGITS 0   /* midi = outln(x)                  (Gmidi_conform.py:30-32)            */

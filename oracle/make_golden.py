@@ -114,6 +114,32 @@ def gen_mel():
     print('mel.npz', {k: v.shape for k, v in out.items()})
 
 
+SHIFT_CASES = [
+    # name, keyshift, speed, center  (me_binarizer.py:237-239 draws float or rounded key shifts in [-12, 12])
+    ('up12', 12, 1, True),
+    ('down12', -12, 1, True),
+    ('up5', 5, 1, True),
+    ('down3p7', -3.7, 1, True),
+    ('up0p31', 0.31, 1, True),
+    ('speed1p3', 0, 1.3, True),
+    ('shift_speed', 7, 0.8, True),
+    ('nocenter', 0, 1, False),
+    ('nocenter_down2', -2, 1, False),
+]
+
+
+def gen_mel_shift():
+    cfg = get_config('midi_conformer')
+    mel = ref_mel(cfg)
+    wav = synth.synth_clip(3, 1.2)
+    out = {'audio': wav}
+    for name, ks, sp, ce in SHIFT_CASES:
+        with torch.no_grad():
+            out[name] = mel(torch.from_numpy(wav)[None], keyshift=ks, speed=sp, center=ce).transpose(1, 2)[0].contiguous().numpy()
+    np.savez_compressed(OUT / 'mel_shift.npz', **out)
+    print('mel_shift.npz', {k: v.shape for k, v in out.items()})
+
+
 MODEL_CASES = [
     # name, config, lay, seed, B, T, masked
     ('conf_lay8', 'midi_conformer', 8, 11, 1, 173, False),
@@ -525,7 +551,12 @@ if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
     OUT.mkdir(parents=True, exist_ok=True)
+    if len(sys.argv) > 1:                 # python oracle/make_golden.py gen_mel_shift ...: only the named generators
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     gen_mel()
+    gen_mel_shift()
     gen_model()
     gen_decode()
     gen_decode_scaled()

@@ -64,18 +64,30 @@ def mel_filterbank(sr=44100, n_fft=2048, n_mels=80, fmin=40.0, fmax=8000.0) -> n
     return weights
 
 
-def logmel(audio: np.ndarray, config: dict, dtype=torch.float32, keep_dtype=False) -> np.ndarray:
-    """reference modules/rmvpe/spec.py:38-72 with keyshift=0, speed=1, center=True, then the transpose of
-    inference/me_infer.py:31.  audio [L] -> units [T, n_mels], T = 1 + L // hop."""
+def logmel(audio: np.ndarray, config: dict, dtype=torch.float32, keep_dtype=False, keyshift=0, speed=1,
+           center=True) -> np.ndarray:
+    """reference modules/rmvpe/spec.py:38-72, then the transpose of inference/me_infer.py:31.
+    audio [L] -> units [T, n_mels]; T = 1 + L // hop for the inference configuration (keyshift=0, speed=1,
+    center=True); keyshift / speed are the training-data augmentation (preprocessing/me_binarizer.py:235-246)."""
     win, hop = config['win_size'], config['hop_size']
     basis = torch.from_numpy(mel_filterbank(config['audio_sample_rate'], win, config['units_dim'],
                                             config['fmin'], config['fmax'])).to(dtype)
+    factor = 2 ** (keyshift / 12)                                              # spec.py:39-42
+    n_fft_new = int(np.round(win * factor))
+    win_new = int(np.round(win * factor))
+    hop_new = int(np.round(hop * speed))
     x = torch.from_numpy(np.ascontiguousarray(audio)).to(dtype)[None]
-    x = F.pad(x, (win // 2, (win + 1) // 2))                                   # spec.py:47-50
-    window = torch.hann_window(win, dtype=dtype)                               # spec.py:44-46 (periodic)
-    spec = torch.stft(x, n_fft=win, hop_length=hop, win_length=win, window=window,
+    if center:
+        x = F.pad(x, (win_new // 2, (win_new + 1) // 2))                       # spec.py:47-50
+    window = torch.hann_window(win_new, dtype=dtype)                           # spec.py:44-46 (periodic)
+    spec = torch.stft(x, n_fft=n_fft_new, hop_length=hop_new, win_length=win_new, window=window,
                       center=False, return_complex=True)                       # spec.py:52-60
     mag = spec.abs()                                                           # spec.py:61
+    if keyshift != 0:                                                          # spec.py:63-68
+        size = win // 2 + 1
+        if mag.size(1) < size:
+            mag = F.pad(mag, (0, 0, 0, size - mag.size(1)))
+        mag = mag[:, :size, :] * win / win_new
     mel = torch.matmul(basis, mag)                                             # spec.py:70
     out = torch.log(torch.clamp(mel, min=1e-5))                                # spec.py:71
     out = out[0].transpose(0, 1).contiguous()

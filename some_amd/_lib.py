@@ -58,6 +58,8 @@ SYMBOLS = {
     'some_attach_arena': (C.c_int, [_P, _P, C.c_size_t]),
     'some_mel_filterbank': (C.c_int, [_P, _P]),
     'some_logmel': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    'some_logmel_shifted': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, _P, _P]),
     'some_workspace_bytes': (C.c_size_t, [_P, C.c_int64, C.c_int32]),
     'some_forward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_size_t, _P]),
     'some_decode_scratch_bytes': (C.c_size_t, [_P, C.c_int64]),

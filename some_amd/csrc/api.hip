@@ -242,6 +242,7 @@ int some_create(const SomeConfig* cfg, SomeHandle** out) {
 void some_destroy(SomeHandle* h) {
     if (!h) return;
     if (h->mel_blob) (void)hipFree(h->mel_blob);
+    for (auto& t : h->shift_tables) (void)hipFree(t.blob);
     for (auto& a : h->aux_sets) { (void)hipStreamDestroy(a.aux); (void)hipEventDestroy(a.fork); (void)hipEventDestroy(a.join); }
     for (auto& r : h->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
@@ -411,6 +412,57 @@ int some_logmel(SomeHandle* h, const float* audio_dev, const int64_t* sample_off
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(h, s, "logmel", 0.0, 0.0);
     HIP_TRY(h, launch_logmel(h->mel, audio_dev, sample_offsets_dev, frame_offsets_dev, B, max_frames, pad_mode, units_dev, s));
+    return SOME_OK;
+}
+
+int some_logmel_shifted(SomeHandle* h, const float* audio_dev, const int64_t* sample_offsets_dev,
+                        const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, int32_t n_fft_new,
+                        int32_t win_length_new, int32_t hop_length_new, int32_t center, int32_t rescale, float* units_dev,
+                        void* stream) {
+    if (!h) return SOME_EINVAL;
+    if (B < 0 || max_frames < 0) return fail(h, SOME_EINVAL, "some_logmel_shifted: negative size");
+    if (n_fft_new < 2 || n_fft_new > kMaxShiftFft) return fail(h, SOME_EINVAL, "some_logmel_shifted: n_fft_new must be in [2, 4096] (key shifts up to +12 semitones)");
+    if (win_length_new < 1 || win_length_new > n_fft_new) return fail(h, SOME_EINVAL, "some_logmel_shifted: win_length_new must be in [1, n_fft_new]");
+    if (hop_length_new < 1) return fail(h, SOME_EINVAL, "some_logmel_shifted: hop_length_new must be positive");
+    if (B == 0 || max_frames == 0) return SOME_OK;
+    if (!audio_dev || !sample_offsets_dev || !frame_offsets_dev || !units_dev) return fail(h, SOME_EINVAL, "some_logmel_shifted: null pointer");
+    if (B > 65535) return fail(h, SOME_EINVAL, "some_logmel_shifted: B > 65535");
+    int rc = ensure_mel_tables(h);
+    if (rc != SOME_OK) return rc;
+    SomeHandle::ShiftTables tab{};
+    {
+        std::lock_guard<std::mutex> lock(h->shift_mu);
+        bool found = false;
+        for (auto& t : h->shift_tables)
+            if (t.n_fft == n_fft_new && t.win == win_length_new) { tab = t; found = true; break; }
+        if (!found) {
+            // torch.hann_window(win') (periodic), centred in the n_fft' frame as torch.stft does (spec.py:44-46, 52-60)
+            const size_t o_tw = 0, o_win = (size_t)n_fft_new * 16, total = o_win + (size_t)n_fft_new * 4;
+            std::vector<char> host(total, 0);
+            double* tw = reinterpret_cast<double*>(host.data() + o_tw);
+            float* win = reinterpret_cast<float*>(host.data() + o_win);
+            for (int k = 0; k < n_fft_new; ++k) {
+                const double ang = 2.0 * M_PI * k / n_fft_new;
+                tw[2 * k] = std::cos(ang);
+                tw[2 * k + 1] = -std::sin(ang);
+            }
+            const int left = (n_fft_new - win_length_new) / 2;
+            for (int n = 0; n < win_length_new; ++n) win[left + n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / win_length_new));
+            void* dev = nullptr;
+            HIP_TRY(h, hipMalloc(&dev, total));
+            hipError_t e = hipMemcpy(dev, host.data(), total, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { (void)hipFree(dev); return fail_hip(h, e, "hipMemcpy(shifted mel tables)"); }
+            tab = {n_fft_new, win_length_new, dev, reinterpret_cast<float*>(static_cast<char*>(dev) + o_win),
+                   reinterpret_cast<double*>(static_cast<char*>(dev) + o_tw)};
+            h->shift_tables.push_back(tab);
+        }
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(h, s, "logmel_shifted", 0.0, 0.0);
+    // spec.py:47-50: pad_left = win' // 2 zeros when center; spec.py:68: magnitude * win / win'
+    HIP_TRY(h, launch_logmel_shift(h->mel, tab.window, tab.twiddle, audio_dev, sample_offsets_dev, frame_offsets_dev, B, max_frames,
+                                   n_fft_new, hop_length_new, center ? win_length_new / 2 : 0, rescale, (float)kWin,
+                                   (float)win_length_new, units_dev, s));
     return SOME_OK;
 }
 

@@ -149,6 +149,15 @@ struct LogmelTables {
 hipError_t launch_logmel(const LogmelTables& t, const float* audio, const int64_t* sample_offsets,
                          const int32_t* frame_offsets, int B, int max_frames, int pad_reflect, float* units, hipStream_t s);
 
+// general transform length (key-shift / speed augmentation, logmel_shift.hip); window: [N] fp32 (already centred in the
+// frame), twiddle: [N] (cos, -sin) fp64
+constexpr int kMaxShiftFft = 4096;
+size_t logmel_shift_lds_bytes(int N, int kmax);
+hipError_t launch_logmel_shift(const LogmelTables& t, const float* window, const double* twiddle, const float* audio,
+                               const int64_t* sample_offsets, const int32_t* frame_offsets, int B, int max_frames, int N,
+                               int hop, int pad_left, int rescale, float scale_num, float scale_den, float* units,
+                               hipStream_t s);
+
 // ---- decode ---------------------------------------------------------------------------------------
 struct DecodeArgs {
     const float* probs; const float* bounds; const uint8_t* mask;
@@ -233,4 +242,8 @@ struct SomeHandle {
     std::mutex fwd_mu;
     std::vector<ProfRecord> prof;
     std::vector<hipEvent_t> event_pool;
+    // window + twiddles of the key-shifted front end, one entry per (n_fft', win') seen
+    struct ShiftTables { int n_fft, win; void* blob; float* window; double* twiddle; };
+    std::vector<ShiftTables> shift_tables;
+    std::mutex shift_mu;
 };

@@ -191,6 +191,25 @@ class Engine:
             batch.B, batch.max_frames, _lib.PAD_REFLECT if reflect else _lib.PAD_ZERO, _ptr(units), self._stream()))
         return units
 
+    def logmel_shifted(self, audio: torch.Tensor, sample_counts: Sequence[int], n_fft_new: int, win_length_new: int,
+                       hop_length_new: int, center: bool = True, rescale: bool = True):
+        """MelSpectrogram.forward with a key shift / speed change (modules/rmvpe/spec.py:38-72; the training-data
+        augmentation of preprocessing/me_binarizer.py:235-246).  audio: packed fp32 [total_samples] on device.
+        Returns (units [total_frames, n_mels], ClipBatch)."""
+        assert audio.is_cuda and audio.dtype == torch.float32 and audio.is_contiguous()
+        sc = np.asarray(sample_counts, dtype=np.int64)
+        assert int(sc.sum()) == audio.numel()
+        padded = sc + (win_length_new if center else 0)
+        if sc.size and int(padded.min()) < n_fft_new:        # torch.stft raises for the same input
+            raise RuntimeError(f'clip of {int(sc.min())} samples is shorter than one frame of n_fft={n_fft_new}')
+        batch = ClipBatch(1 + (padded - n_fft_new) // hop_length_new, self.device, sample_counts=sc)
+        units = torch.empty((batch.total_frames, self.indim), dtype=torch.float32, device=self.device)
+        _lib.check(self.handle, self.lib.some_logmel_shifted(
+            self.handle, _ptr(audio), _ptr(batch.sample_offsets_dev), _ptr(batch.frame_offsets_dev), batch.B,
+            batch.max_frames, int(n_fft_new), int(win_length_new), int(hop_length_new), int(bool(center)),
+            int(bool(rescale)), _ptr(units), self._stream()))
+        return units, batch
+
     # ---- host ingest either side of the silence slicer ------------------------------------------------------
     @staticmethod
     def _sample_format(audio: torch.Tensor) -> int:

@@ -1,7 +1,8 @@
 """``MelSpectrogram`` with the reference's constructor / forward signature (modules/rmvpe/spec.py:8-72), backed
-by the fused HIP front end (csrc/logmel.hip).  Only the inference configuration is implemented:
-``keyshift=0, speed=1, center=True`` (the other values are training-time augmentation,
-preprocessing/me_binarizer.py, out of scope - SURVEY.md section 8a row a4)."""
+by the fused HIP front end: csrc/logmel.hip for the inference configuration (``keyshift=0, speed=1, center=True``),
+csrc/logmel_shift.hip (arbitrary transform length) for the key-shift / speed augmentation the reference's
+binarizers request (preprocessing/me_binarizer.py:235-246)."""
+import numpy as np
 import torch
 from torch import nn
 
@@ -42,13 +43,20 @@ class MelSpectrogram(nn.Module):
 
     @torch.no_grad()
     def forward(self, audio, keyshift=0, speed=1, center=True):
-        """audio [B, L] fp32 -> log-mel [B, n_mels, T], T = 1 + L // hop."""
-        if keyshift != 0 or speed != 1 or not center:
-            raise NotImplementedError('only keyshift=0, speed=1, center=True (the inference path) is implemented')
+        """audio [B, L] fp32 -> log-mel [B, n_mels, T], T = 1 + L // hop (inference configuration)."""
         if self._engine is None or (audio.is_cuda and self._engine.device != audio.device):
             self._engine = Engine(self._config, device=audio.device)    # raises for CPU tensors: no fallback
         eng = self._engine
         b, length = audio.shape
+        if keyshift != 0 or speed != 1 or not center:
+            factor = 2 ** (keyshift / 12)                                 # spec.py:39-42
+            n_fft_new = int(np.round(self.n_fft * factor))
+            win_length_new = int(np.round(self.win_length * factor))
+            hop_length_new = int(np.round(self.hop_length * speed))
+            flat = audio.to(device=eng.device, dtype=torch.float32).reshape(-1).contiguous()
+            units, _ = eng.logmel_shifted(flat, [length] * b, n_fft_new, win_length_new, hop_length_new, center=center,
+                                          rescale=keyshift != 0)
+            return units.view(b, -1, self.n_mel_channels).transpose(1, 2)
         batch = ClipBatch.from_sample_counts([length] * b, self.hop_length, eng.device)
         flat = audio.to(device=eng.device, dtype=torch.float32).reshape(-1).contiguous()
         units = eng.logmel(flat, batch)                                   # [B*T, n_mels]

@@ -46,6 +46,48 @@ def test_logmel_golden(golden_dir, case):
     np.testing.assert_allclose(u, g[case + '.units'], rtol=0, atol=2e-4)
 
 
+@pytest.mark.parametrize('case,ks,sp,ce', [
+    ('up12', 12, 1, True), ('down12', -12, 1, True), ('up5', 5, 1, True), ('down3p7', -3.7, 1, True),
+    ('up0p31', 0.31, 1, True), ('speed1p3', 0, 1.3, True), ('shift_speed', 7, 0.8, True), ('nocenter', 0, 1, False),
+    ('nocenter_down2', -2, 1, False)])
+def test_logmel_keyshift_speed_golden(golden_dir, case, ks, sp, ce):
+    """MelSpectrogram.forward(keyshift, speed, center) - the binarizers' augmentation (spec.py:38-72,
+    me_binarizer.py:235-246) - through the reference's own module interface, against the reference's output and against
+    an fp64 run of the same algorithm: the HIP path (fp64 accumulation) must be at least as close to fp64 as the
+    reference's fp32 FFT is, and within 2e-4 of the reference."""
+    from oracle import restate
+    from some_amd.modules.rmvpe.spec import MelSpectrogram
+    g = np.load(golden_dir / 'mel_shift.npz')
+    cfg = get_config('midi_conformer')
+    mel = MelSpectrogram(cfg['units_dim'], cfg['audio_sample_rate'], cfg['win_size'], cfg['hop_size'], None, cfg['fmin'],
+                         cfg['fmax']).cuda()
+    out = mel(torch.from_numpy(g['audio'])[None].cuda(), keyshift=ks, speed=sp, center=ce)
+    assert out.shape == (1, 80, g[case].shape[0])
+    u = out[0].transpose(0, 1).cpu().numpy()
+    np.testing.assert_allclose(u, g[case], rtol=0, atol=2e-4)
+    ref64 = restate.logmel(g['audio'], cfg, dtype=torch.float64, keep_dtype=True, keyshift=ks, speed=sp, center=ce)
+    err_hip, err_ref = np.abs(u - ref64).max(), np.abs(g[case] - ref64).max()
+    assert err_hip <= err_ref + 2e-6, (err_hip, err_ref)
+
+
+def test_logmel_keyshift_packed_ragged_batch_and_errors():
+    from oracle import restate
+    from some_amd.engine import Engine
+    cfg = get_config('midi_conformer', lay=0)
+    eng = Engine(cfg, device='cuda')
+    clips = [synth.synth_clip(i, s) for i, s in enumerate([0.4, 0.9, 0.06])]
+    n_fft = int(np.round(2048 * 2 ** (-7 / 12)))
+    units, batch = eng.logmel_shifted(torch.from_numpy(np.concatenate(clips)).cuda(), [len(c) for c in clips], n_fft, n_fft, 512)
+    units = units.cpu().numpy()
+    for b, c in enumerate(clips):
+        s, e = batch.frame_offsets[b], batch.frame_offsets[b + 1]
+        np.testing.assert_allclose(units[s:e], restate.logmel(c, cfg, keyshift=-7), rtol=0, atol=2e-4)
+    with pytest.raises(RuntimeError, match='shorter than one frame'):     # torch.stft raises too
+        eng.logmel_shifted(torch.zeros(100, device='cuda'), [100], 2048, 2048, 512, center=False)
+    with pytest.raises(RuntimeError, match='n_fft_new'):
+        eng.logmel_shifted(torch.zeros(9000, device='cuda'), [9000], 5000, 5000, 512)
+
+
 def test_logmel_packed_batch_equals_single_clips():
     from oracle import restate
     from some_amd.engine import ClipBatch, Engine
@@ -67,8 +109,8 @@ def test_mel_spectrogram_module_signature(golden_dir):
     out = mel(torch.from_numpy(g['clip0_1s.audio'])[None].cuda())
     assert out.shape == (1, 80, 87)
     np.testing.assert_allclose(out[0].t().cpu().numpy(), g['clip0_1s.units'], rtol=0, atol=2e-4)
-    with pytest.raises(NotImplementedError):
-        mel(torch.zeros(1, 4096).cuda(), keyshift=2)
+    with pytest.raises(RuntimeError, match='n_fft_new'):            # beyond the reference configs' [-12, 12] semitones
+        mel(torch.zeros(1, 9000).cuda(), keyshift=14)
 
 
 # ---- network --------------------------------------------------------------------------------------

@@ -29,6 +29,21 @@ def test_logmel(golden_dir, case):
     np.testing.assert_allclose(u, g[case + '.units'], rtol=0, atol=1e-6)
 
 
+SHIFT_CASES = {'up12': (12, 1, True), 'down12': (-12, 1, True), 'up5': (5, 1, True), 'down3p7': (-3.7, 1, True),
+               'up0p31': (0.31, 1, True), 'speed1p3': (0, 1.3, True), 'shift_speed': (7, 0.8, True),
+               'nocenter': (0, 1, False), 'nocenter_down2': (-2, 1, False)}
+
+
+@pytest.mark.parametrize('case', sorted(SHIFT_CASES))
+def test_logmel_keyshift_speed(golden_dir, case):
+    """MelSpectrogram.forward(keyshift, speed, center) of the reference (spec.py:38-72; the binarizers' augmentation)."""
+    g = np.load(golden_dir / 'mel_shift.npz')
+    ks, sp, ce = SHIFT_CASES[case]
+    u = restate.logmel(g['audio'], get_config('midi_conformer'), keyshift=ks, speed=sp, center=ce)
+    assert u.shape == g[case].shape
+    np.testing.assert_allclose(u, g[case], rtol=0, atol=1e-6)
+
+
 def _model_cases(golden_dir):
     return json.loads((golden_dir / 'model.json').read_text())
 
