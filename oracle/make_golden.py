@@ -502,6 +502,87 @@ FULL_CASES = [
 FULL_CLIPS = 8          # 8 x 30 s clips per config (T = 2584 each); probs are stored for clip 0 only (1.3 MB each)
 
 
+def _ref_training_utils():
+    """utils/training_utils.py needs lightning (absent): stub the three names it imports, then import the reference's
+    ``utils`` package as it is."""
+    if 'lightning' not in sys.modules:
+        pl = types.ModuleType('lightning.pytorch')
+        pl.LightningModule = object
+        cb = types.ModuleType('lightning.pytorch.callbacks')
+        cb.ModelCheckpoint = cb.TQDMProgressBar = object
+        rz = types.ModuleType('lightning.pytorch.utilities.rank_zero')
+        rz.rank_zero_info = print
+        ut = types.ModuleType('lightning.pytorch.utilities')
+        top = types.ModuleType('lightning')
+        top.pytorch, pl.callbacks, pl.utilities, ut.rank_zero = pl, cb, ut, rz
+        sys.modules.update({'lightning': top, 'lightning.pytorch': pl, 'lightning.pytorch.callbacks': cb,
+                            'lightning.pytorch.utilities': ut, 'lightning.pytorch.utilities.rank_zero': rz})
+    import utils.training_utils as tu          # the reference's (REF is first on sys.path)
+    assert str(REF) in tu.__file__
+    return tu
+
+
+class _Lengths:
+    """The three members of BaseDataset the samplers touch (training/base_task.py:55-71)."""
+
+    def __init__(self, sizes):
+        self._sizes = np.asarray(sizes)
+
+    def __len__(self):
+        return len(self._sizes)
+
+    def num_frames(self, i):
+        return self._sizes[i]
+
+
+def sampler_lengths(n, seed):
+    """Frame counts shaped like a sliced singing corpus: log-normal phrase lengths around 6 s, clipped to 1 - 20 s, at
+    the 86.13 frames/s of hop 512 @ 44.1 kHz."""
+    rng = np.random.default_rng(seed)
+    sec = np.clip(rng.lognormal(mean=np.log(6.0), sigma=0.55, size=n), 1.0, 20.0)
+    return np.round(sec * 44100 / 512).astype(np.int64)
+
+
+SAMPLER_CASES = [
+    # name, n items, seed, max_batch_frames, max_batch_size, num_replicas, multiple, sort, shuffle_batch, drop_last, grid, epochs
+    ('single', 257, 0, 80000, 8, 1, 1, True, False, False, 6, (0, 1)),
+    ('ddp8', 1000, 114514, 80000, 8, 8, 1, True, False, False, 6, (0, 3)),
+    ('ddp2_accum4', 333, 7, 20000, 48, 2, 4, True, False, False, 200, (0, 2)),
+    ('ddp3_unsorted_drop', 100, 1, 9000, 5, 3, 1, False, True, True, 200, (0, 1)),
+    ('ddp4_few', 37, 2, 30000, 8, 4, 2, True, True, False, 50, (0, 5)),
+]
+
+
+def gen_samplers():
+    tu = _ref_training_utils()
+    import utils as ref_utils
+    out = {}
+    for name, n, seed, mbf, mbs, world, mult, sort, shuf_b, drop, grid, epochs in SAMPLER_CASES:
+        ds = _Lengths(sampler_lengths(n, seed + 1))
+        plans = {}
+        for rank in range(world):
+            sm = tu.DsBatchSampler(ds, mbf, mbs, num_replicas=world, rank=rank, frame_count_grid=grid,
+                                   required_batch_count_multiple=mult, sort_by_similar_size=sort, shuffle_sample=True,
+                                   shuffle_batch=shuf_b, seed=seed, drop_last=drop)
+            for ep in epochs:
+                sm.set_epoch(ep)
+                plans[f'rank{rank}.epoch{ep}'] = [[int(i) for i in b] for b in sm]
+        out[name] = {'lengths': ds._sizes.tolist(), 'seed': seed, 'max_batch_frames': mbf, 'max_batch_size': mbs,
+                     'num_replicas': world, 'multiple': mult, 'sort': sort, 'shuffle_batch': shuf_b, 'drop_last': drop,
+                     'grid': grid, 'plans': plans}
+    ds = _Lengths(sampler_lengths(50, 9))
+    out['eval'] = {
+        'lengths': ds._sizes.tolist(),
+        'rank0_fixed': [[int(i) for i in b] for b in tu.DsEvalBatchSampler(ds, 20000, 4, rank=0, batch_by_size=False)],
+        'rank0_by_size': [[int(i) for i in b] for b in tu.DsEvalBatchSampler(ds, 3000, 4, rank=0, batch_by_size=True)],
+        'rank1': [[int(i) for i in b] for b in tu.DsEvalBatchSampler(ds, 20000, 4, rank=1)],
+    }
+    out['batch_by_size_multiple'] = [[int(i) for i in b] for b in ref_utils.batch_by_size(
+        list(range(50)), ds.num_frames, max_batch_frames=4000, max_batch_size=7, required_batch_size_multiple=2)]
+    (OUT / 'samplers.json').write_text(json.dumps(out))
+    print('samplers.json', {k: (len(v['plans']) if 'plans' in v else len(v)) for k, v in out.items()})
+
+
 def gen_fullsize():
     """The BASELINE configs at their OWN size (30 s clips, T = 2584, lay 8 / lay 3): waveform ->
     reference MelSpectrogram -> reference midi_conforms -> reference decode, B = 1 per clip as BaseInference.infer runs
@@ -569,3 +650,4 @@ if __name__ == '__main__':
     gen_lr_schedule()
     gen_e2e()
     gen_fullsize()
+    gen_samplers()

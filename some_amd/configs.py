@@ -28,6 +28,20 @@ _BASE = {
     'midi_num_bins': 128,
     'seed': 114514,
     'pl_trainer_precision': '32-true',      # configs/base.yaml:74
+    # data / schedule keys of the trainer (configs/base.yaml:4-9, 36, 50-66)
+    'binary_data_dir': None,
+    'train_set_name': 'train',
+    'valid_set_name': 'valid',
+    'sort_by_len': True,
+    'accumulate_grad_batches': 1,
+    'sampler_frame_count_grid': 6,
+    'max_batch_size': 8,
+    'max_batch_frames': 80000,
+    'max_val_batch_size': 1,
+    'max_val_batch_frames': 10000,
+    'val_check_interval': 1000,
+    'num_ckpt_keep': 5,
+    'max_updates': 100000,
 }
 
 

@@ -1,14 +1,16 @@
-"""Training samples and the collater of ``MIDIExtractionDataset`` (training/me_task.py:13-52) for the HIP training
-path, plus a synthetic singing-note source so that ``train.py`` runs without a binarised dataset.
-
-The reference reads ``binary_data_dir`` through h5py (utils/indexed_datasets.py), which this image does not have, so
-the on-disk reader is not provided; everything downstream of a loaded sample - per-sample fields
-(preprocessing/me_binarizer.py:202-223: note_midi / note_rest / note_dur / unit2note) and the batch the model sees - is
-restated here.  Units are computed by the HIP log-mel front end (some_logmel)."""
+"""Training data of the HIP training path: ``MIDIExtractionDataset`` (training/me_task.py:13-52 over
+training/base_task.py:31-76) reading the reference's binarised datasets - ``<prefix>.lengths`` + the HDF5 container
+``<prefix>.data`` (utils/indexed_datasets.py), through some_amd/utils/indexed_datasets.py - its collater, and a
+synthetic singing-note source with known notes (``SyntheticNoteDataset``) so that ``train.py`` also runs without a
+dataset on disk.  Per-sample fields follow preprocessing/me_binarizer.py:202-223 (note_midi / note_rest / note_dur /
+unit2note); synthetic units are computed by the HIP log-mel front end (some_logmel)."""
+import pathlib
 from typing import Dict, List
 
 import numpy as np
 import torch
+
+from ..utils.indexed_datasets import IndexedDataset
 
 
 def note_alignment(note_dur_sec: np.ndarray, length: int, timestep: float):
@@ -97,21 +99,48 @@ def collater(samples: List[Dict[str, torch.Tensor]], config: dict) -> Dict[str, 
     return batch
 
 
-def batches(lengths: List[int], max_batch_frames: int, max_batch_size: int, rank: int = 0, world: int = 1, seed: int = 0):
-    """Batch index lists in the spirit of DsBatchSampler (utils/training_utils.py:99-124): items sorted by length, packed
-    into batches bounded by padded frames and item count, batch order shuffled with a shared seed, every rank takes an
-    equal number of batches (rank :: world)."""
-    order = np.argsort(-np.asarray(lengths), kind='stable')
-    out, cur, longest = [], [], 0
-    for i in order:
-        longest_new = max(longest, int(lengths[i]))
-        if cur and (len(cur) + 1 > max_batch_size or longest_new * (len(cur) + 1) > max_batch_frames):
-            out.append(cur)
-            cur, longest_new = [], int(lengths[i])
-        cur.append(int(i))
-        longest = longest_new
-    if cur:
-        out.append(cur)
-    np.random.default_rng(seed).shuffle(out)
-    usable = len(out) // world * world
-    return out[:usable][rank::world] if usable else out[rank::world]
+class MIDIExtractionDataset:
+    """training/base_task.py:31-76 + training/me_task.py:13-52.  ``sizes`` are the frame counts the binarizer saved
+    (preprocessing/base_binarizer.py:196-199); the samplers read ``_sizes`` / ``num_frames``.  Items are moved to
+    ``device`` by the collater."""
+
+    def __init__(self, config: dict, data_dir, prefix: str, allow_aug: bool = False, device=None):
+        self.config, self.prefix, self.allow_aug, self.device = config, prefix, allow_aug, device
+        self.data_dir = pathlib.Path(data_dir)
+        self.sizes = np.load(self.data_dir / f'{prefix}.lengths')
+        self.indexed_ds = IndexedDataset(self.data_dir, prefix)
+        if len(self.indexed_ds) != len(self.sizes):
+            raise ValueError(f'{self.data_dir}/{prefix}: {len(self.indexed_ds)} items in .data but {len(self.sizes)} lengths')
+
+    @property
+    def _sizes(self):
+        return self.sizes
+
+    def __getitem__(self, index):
+        return self.indexed_ds[index]
+
+    def __len__(self):
+        return len(self.sizes)
+
+    def num_frames(self, index):
+        return self.sizes[index]
+
+    size = num_frames
+
+    def collater(self, samples: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
+        if self.device is not None:
+            samples = [{k: v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v for k, v in s.items()} for s in samples]
+        return collater(samples, self.config)
+
+
+class SyntheticNoteDataset(MIDIExtractionDataset):
+    """The same interface over synthetic sung clips (``synth_note_clip``) held in device memory."""
+
+    def __init__(self, config: dict, engine, indices, seconds, allow_aug: bool = False):
+        self.config, self.prefix, self.allow_aug, self.device = config, 'synthetic', allow_aug, None
+        timestep = config['hop_size'] / config['audio_sample_rate']
+        self.items = [make_sample(engine, synth_note_clip(i, sec), timestep) for i, sec in zip(indices, seconds)]
+        self.sizes = np.asarray([int(s['units'].shape[0]) for s in self.items], dtype=np.int64)
+
+    def __getitem__(self, index):
+        return self.items[index]

@@ -74,15 +74,24 @@ class MIDIExtractionTrainer:
             losses['midi_loss'] = self.ops.bce_with_logits(probs, sample['probs'].reshape(B * T, -1).float())
         return losses
 
-    def training_step(self, sample: Dict[str, torch.Tensor]) -> Dict[str, float]:
-        """One optimiser update: forward, losses, backward, gradient all-reduce, AdamW with the WarmupLR rate."""
+    def training_step(self, sample) -> Dict[str, float]:
+        """One optimiser update: forward, losses, backward, gradient all-reduce, AdamW with the WarmupLR rate.  A list of
+        batches is one update over ``accumulate_grad_batches`` micro-batches (configs/base.yaml:50, train.py:89): their
+        gradients accumulate in the flat buffer, each loss weighted 1 / n as Lightning does."""
         P = self.model.params
         P.zero_grad()
         self.model.train()
-        losses = self.run_model(sample)
-        total = sum(losses.values())
+        micro = sample if isinstance(sample, (list, tuple)) else [sample]
         scale = self.loss_scale
-        (total * scale if scale != 1.0 else total).backward()
+        losses, total = {}, 0.0
+        for mb in micro:
+            part = self.run_model(mb)
+            part_total = sum(part.values())
+            weight = scale / len(micro)
+            (part_total * weight if weight != 1.0 else part_total).backward()
+            total = total + part_total.detach() / len(micro)
+            for k, v in part.items():
+                losses[k] = losses.get(k, 0.0) + v.detach() / len(micro)
         if self.world > 1:
             torch.distributed.all_reduce(P.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
         # global gradient norm on the device (one double comes back: the step's only host synchronisation); it serves
@@ -112,8 +121,8 @@ class MIDIExtractionTrainer:
             self.ops.check(self.ops.lib.some_train_adamw(self.ops.h, p(P.flat), p(P.grad), p(self.exp_avg), p(self.exp_avg_sq), P.numel, lr,
                                                          self.betas[0], self.betas[1], self.eps, self.weight_decay, self.global_step,
                                                          clip_coef / (self.world * scale), self.ops.stream()))
-        out = {k: v.detach() for k, v in losses.items()}
-        out['total_loss'] = total.detach()
+        out = dict(losses)
+        out['total_loss'] = total
         out['lr'] = lr
         out['grad_scale'] = scale                # P.grad holds scale * (sum over ranks of) the gradient
         out['skipped'] = skipped

@@ -289,3 +289,51 @@ def test_trained_checkpoint_keeps_parity_with_the_cpu_oracle(tmp_path):
     assert len(notes['f16x3']['note_midi']) >= 1
     np.testing.assert_array_equal(notes['f16x3']['note_dur'], notes['f32']['note_dur'])
     np.testing.assert_array_equal(notes['f16x3']['note_rest'], notes['f32']['note_rest'])
+
+
+def test_cli_train_on_a_binarised_dataset(tmp_path, golden_dir):
+    """train.py on the reference's data format: binary_data_dir with train / valid HDF5 containers + .lengths (written by
+    libhdf5 in the binarizer's layout, tests/golden/binary), read without h5py, batched by the reference's DsBatchSampler plan,
+    two micro-batches per update (accumulate_grad_batches), validated through DsEvalBatchSampler, resumed from its checkpoint."""
+    import pathlib
+    import subprocess
+    import sys
+    import yaml
+    root = pathlib.Path(__file__).resolve().parents[1]
+    user = {'base_config': ['configs/base.yaml'], 'binary_data_dir': str(golden_dir / 'binary'), 'max_batch_frames': 600, 'max_batch_size': 4,
+            'accumulate_grad_batches': 2, 'val_check_interval': 4, 'max_val_batch_size': 1,
+            'midi_extractor_args': dict(get_config('two_head_model')['midi_extractor_args'], lay=1),
+            'lr_scheduler_args': {'scheduler_cls': 'lr_scheduler.scheduler.WarmupLR', 'warmup_steps': 2, 'min_lr': 1e-5}}
+    (tmp_path / 'two_head_model.yaml').write_text(yaml.safe_dump(user))
+    cmd = [sys.executable, str(root / 'train.py'), '--config', str(tmp_path / 'two_head_model.yaml'), '--exp_name', 'exp', '--work_dir', str(tmp_path),
+           '--log_interval', '1']
+    r = subprocess.run(cmd + ['--max_updates', '8'], capture_output=True, text=True, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    losses = [float(line.split('total_loss=')[1].split(',')[0]) for line in r.stdout.splitlines() if line.startswith('step ')]
+    assert len(losses) == 8 and all(np.isfinite(losses)) and min(losses[4:]) < losses[0]
+    assert 'validation @ 4:' in r.stdout and 'validation @ 8:' in r.stdout and 'midi_acc=' in r.stdout
+    assert (tmp_path / 'exp' / 'model_ckpt_steps_8.ckpt').exists()
+    r = subprocess.run(cmd + ['--max_updates', '10'], capture_output=True, text=True, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'resumed from model_ckpt_steps_8.ckpt at step 8' in r.stdout and 'step 10:' in r.stdout
+
+
+def test_gradient_accumulation_averages_the_micro_batch_gradients():
+    """accumulate_grad_batches: one update over two micro-batches uses the mean of their gradients (each loss weighted 1 / 2,
+    as Lightning does; BatchNorm statistics stay per micro-batch, so this is NOT the joint batch) and reports mean losses."""
+    from some_amd.training.task import MIDIExtractionTrainer
+    s = _sample()
+    halves = [{k: v[i:i + 1] for k, v in s.items()} for i in range(2)]
+
+    def run(batches):
+        tr = MIDIExtractionTrainer(dict(_cfg(), some_amd_precision='f32'), device='cuda', seed=5)
+        out = tr.training_step(batches)
+        assert not out['skipped'] and tr.global_step == 1
+        return out, tr.model.params.grad.clone() / out['grad_scale']
+
+    (oa, ga), (o0, g0), (o1, g1) = run(halves), run(halves[0]), run(halves[1])
+    want = 0.5 * (g0 + g1)
+    assert float((ga - want).norm() / want.norm()) < 1e-5
+    for k in ('midi_loss', 'bound_loss', 'total_loss'):
+        assert abs(float(oa[k]) - 0.5 * (float(o0[k]) + float(o1[k]))) < 1e-5 * abs(float(oa[k]))
+    assert oa['grad_norm'] == pytest.approx(float(want.norm()), rel=1e-4)

@@ -51,16 +51,6 @@ def test_note_alignment_and_collater():
             assert abs(float(row.argmax()) - float(samples[1]['note_midi'][n])) <= 0.5 and row.max() <= 1.0
 
 
-def test_batch_planner():
-    lengths = [100, 200, 300, 50, 60, 70, 400, 30]
-    plan = data.batches(lengths, 700, 3, seed=1)
-    assert sorted(i for b in plan for i in b) == list(range(8))
-    for b in plan:
-        assert len(b) <= 3 and max(lengths[i] for i in b) * len(b) <= 700
-    r0, r1 = data.batches(lengths, 700, 3, 0, 2, seed=1), data.batches(lengths, 700, 3, 1, 2, seed=1)
-    assert len(r0) == len(r1) and not set(map(tuple, r0)) & set(map(tuple, r1))
-
-
 _WORKER = r'''
 import os, sys, torch
 sys.path.insert(0, os.environ['REPO'])
@@ -76,11 +66,20 @@ grad = torch.arange(1000, dtype=torch.float32) * (rank + 1)
 dist.all_reduce(grad, op=dist.ReduceOp.SUM)
 mean = grad * (1.0 / 2)
 assert torch.allclose(mean, torch.arange(1000, dtype=torch.float32) * 1.5)
-from some_amd.training import data
-a = data.batches(list(range(10, 90, 10)), 200, 4, rank, 2, seed=3)
+# every rank plans the whole epoch itself (no communication) and keeps its own column of the batch grid
+import numpy as np
+from some_amd.training.samplers import DsBatchSampler
+class Lengths:
+    _sizes = np.arange(10, 210, 10)
+    def __len__(self): return len(self._sizes)
+    def num_frames(self, i): return self._sizes[i]
+sm = DsBatchSampler(Lengths(), 400, 4, num_replicas=2, rank=rank, shuffle_sample=True, seed=3)
+sm.set_epoch(1)
 gathered = [None, None]
-dist.all_gather_object(gathered, a)
-assert len(gathered[0]) == len(gathered[1]) and not set(map(tuple, gathered[0])) & set(map(tuple, gathered[1]))
+dist.all_gather_object(gathered, [list(map(int, b)) for b in sm])
+a, b = gathered
+assert len(a) == len(b) and {i for p in a + b for i in p} == set(range(20))
+assert sum(len(p) for p in a + b) <= 20 + 4          # at most one repeated batch (odd batch count)
 dist.barrier()
 dist.destroy_process_group()
 print('ok', rank)
@@ -101,3 +100,55 @@ def test_two_rank_gloo_gradient_sync(tmp_path):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+# ---- batch planning: the reference's samplers (utils/training_utils.py:45-176, utils/__init__.py:60-111) --------------
+class _Lengths:
+    def __init__(self, sizes):
+        self._sizes = np.asarray(sizes)
+
+    def __len__(self):
+        return len(self._sizes)
+
+    def num_frames(self, i):
+        return self._sizes[i]
+
+
+@pytest.mark.parametrize('case', ['single', 'ddp8', 'ddp2_accum4', 'ddp3_unsorted_drop', 'ddp4_few'])
+def test_ds_batch_sampler_plans_equal_the_reference(golden_dir, case):
+    """Same batches, in the same order, on every rank and epoch as the reference's DsBatchSampler - the numpy Generator
+    call sequence is part of the contract."""
+    from some_amd.training.samplers import DsBatchSampler
+    g = json.loads((golden_dir / 'samplers.json').read_text())[case]
+    ds = _Lengths(g['lengths'])
+    seen = {}
+    for key, want in g['plans'].items():
+        rank, epoch = (int(p.lstrip('rankepoch')) for p in key.split('.'))
+        sm = DsBatchSampler(ds, g['max_batch_frames'], g['max_batch_size'], num_replicas=g['num_replicas'], rank=rank,
+                            frame_count_grid=g['grid'], required_batch_count_multiple=g['multiple'],
+                            sort_by_similar_size=g['sort'], shuffle_sample=True, shuffle_batch=g['shuffle_batch'], seed=g['seed'],
+                            drop_last=g['drop_last'])
+        sm.set_epoch(epoch)
+        got = [list(map(int, b)) for b in sm]
+        assert got == want, key
+        assert len(sm) == len(want) and len(want) % g['multiple'] == 0
+        for b in got:                                         # the budget the plan exists for
+            assert len(b) <= g['max_batch_size'] and len(b) * max(g['lengths'][i] for i in b) <= g['max_batch_frames']
+        seen.setdefault(epoch, []).append(got)
+    for epoch, per_rank in seen.items():                      # every rank takes the same number of steps
+        assert len({len(p) for p in per_rank}) == 1
+        if not g['drop_last']:
+            assert {i for p in per_rank for b in p for i in b} == set(range(len(ds)))
+
+
+def test_eval_sampler_and_batch_by_size_equal_the_reference(golden_dir):
+    from some_amd.training.samplers import DsEvalBatchSampler, batch_by_size
+    g = json.loads((golden_dir / 'samplers.json').read_text())
+    ds = _Lengths(g['eval']['lengths'])
+    assert list(DsEvalBatchSampler(ds, 20000, 4, rank=0, batch_by_size=False)) == g['eval']['rank0_fixed']
+    assert [list(map(int, b)) for b in DsEvalBatchSampler(ds, 3000, 4, rank=0, batch_by_size=True)] == g['eval']['rank0_by_size']
+    assert list(DsEvalBatchSampler(ds, 20000, 4, rank=1)) == g['eval']['rank1'] == [[0]]
+    got = batch_by_size(list(range(50)), ds.num_frames, max_batch_frames=4000, max_batch_size=7, required_batch_size_multiple=2)
+    assert [list(map(int, b)) for b in got] == g['batch_by_size_multiple']
+    with pytest.raises(AssertionError, match='exceeds'):
+        batch_by_size([0], lambda i: 5000, max_batch_frames=4000)

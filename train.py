@@ -3,8 +3,10 @@
 (train.py:27-110) on the HIP training path: MIDIExtractionTask losses, AdamW + WarmupLR, checkpoints in the
 Lightning layout the inference classes load (``{'state_dict': {'model.<key>': ...}}`` + config.yaml beside it).
 
-Data: the reference reads a binarised dataset through h5py, which this image lacks; ``--synthetic N`` trains on N
-synthetic sung clips with known notes instead (units from the HIP log-mel front end).  Multi-GPU: launch with
+Data: ``binary_data_dir`` of the config (the reference's binarised dataset: ``train.data`` / ``valid.data`` HDF5
+containers + ``.lengths``, read without h5py through some_amd/utils/hdf5_lite.py), batched by the reference's
+DsBatchSampler / DsEvalBatchSampler plans; ``--synthetic N`` trains on N synthetic sung clips with known notes instead
+(units from the HIP log-mel front end).  Multi-GPU: launch with
 ``python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...`` - one process per GPU, rank 0's
 initial weights broadcast once, one all-reduce of the flat gradient per step (RCCL), every rank its own batches."""
 import os
@@ -39,6 +41,7 @@ def _load_config(config: str) -> dict:
 @click.option('--val_clips', type=int, default=8, help='held-out synthetic clips for the validation pass')
 def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_clips):
     from some_amd.training import data
+    from some_amd.training.samplers import DsBatchSampler, DsEvalBatchSampler
     from some_amd.training.task import MIDIExtractionTrainer
     cfg = _load_config(config)
     work = (pathlib.Path(work_dir) if work_dir else pathlib.Path(__file__).parent / 'experiments') / exp_name
@@ -51,21 +54,40 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
         work.mkdir(parents=True, exist_ok=True)
         with open(work / 'config.yaml', 'w', encoding='utf8') as f:
             yaml.safe_dump(cfg, f)
-    if synthetic <= 0:
-        raise click.UsageError('reading binary_data_dir needs h5py, which is not available here: pass --synthetic N')
     trainer = MIDIExtractionTrainer(cfg, device=f'cuda:{local}', seed=cfg.get('seed', 114514))
-    timestep = cfg['hop_size'] / cfg['audio_sample_rate']
-    rng_len = torch.Generator().manual_seed(1)
-    items = [data.make_sample(trainer.engine, data.synth_note_clip(i, 4.0 + 8.0 * torch.rand((), generator=rng_len).item()), timestep)
-             for i in range(synthetic)]
-    lengths = [int(s['units'].shape[0]) for s in items]
-    val_items = [data.make_sample(trainer.engine, data.synth_note_clip(10 ** 6 + i, 6.0), timestep) for i in range(val_clips)]
+    if synthetic > 0:
+        rng_len = torch.Generator().manual_seed(1)
+        seconds = [4.0 + 8.0 * torch.rand((), generator=rng_len).item() for _ in range(synthetic)]
+        train_set = data.SyntheticNoteDataset(cfg, trainer.engine, range(synthetic), seconds, allow_aug=True)
+        valid_set = data.SyntheticNoteDataset(cfg, trainer.engine, range(10 ** 6, 10 ** 6 + val_clips), [6.0] * val_clips) if val_clips else None
+        max_val_batch_size = max(val_clips, 1)
+    else:
+        if not cfg.get('binary_data_dir'):
+            raise click.UsageError('the config has no binary_data_dir: set it, or pass --synthetic N')
+        # training/base_task.py:135-142
+        train_set = data.MIDIExtractionDataset(cfg, cfg['binary_data_dir'], cfg['train_set_name'], allow_aug=True, device=trainer.ops.device)
+        valid_set = data.MIDIExtractionDataset(cfg, cfg['binary_data_dir'], cfg['valid_set_name'], device=trainer.ops.device)
+        max_val_batch_size = cfg['max_val_batch_size']
+    accumulate = int(cfg.get('accumulate_grad_batches', 1))
+    # training/base_task.py:360-395
+    sampler = DsBatchSampler(train_set, max_batch_frames=cfg['max_batch_frames'], max_batch_size=cfg['max_batch_size'],
+                             num_replicas=world, rank=rank, sort_by_similar_size=cfg['sort_by_len'],
+                             required_batch_count_multiple=accumulate, frame_count_grid=cfg['sampler_frame_count_grid'],
+                             shuffle_sample=True, shuffle_batch=False, seed=cfg['seed'])
+    val_sampler = DsEvalBatchSampler(valid_set, max_batch_frames=cfg['max_val_batch_frames'], max_batch_size=max_val_batch_size,
+                                     rank=rank, batch_by_size=False) if valid_set is not None and len(valid_set) else None
 
     def validate(step):
         trainer.sync_eval_engine()
-        res = trainer.validation_step(data.collater(val_items, cfg))
-        acc = float(res['midi_acc_correct']) / max(float(res['midi_acc_total']), 1.0)
-        print(f'validation @ {step}: ' + ', '.join(f'{k}={float(v):.5f}' for k, v in res.items() if k.endswith('loss')) + f', midi_acc={acc:.4f}')
+        sums, n = {}, 0
+        for idx in val_sampler:
+            res = trainer.validation_step(valid_set.collater([valid_set[i] for i in idx]))
+            n += 1
+            for k, v in res.items():
+                if k.endswith('loss') or k.startswith('midi_acc'):
+                    sums[k] = sums.get(k, 0.0) + float(v)
+        acc = sums['midi_acc_correct'] / max(sums['midi_acc_total'], 1.0)
+        print(f'validation @ {step}: ' + ', '.join(f'{k}={v / n:.5f}' for k, v in sums.items() if k.endswith('loss')) + f', midi_acc={acc:.4f}')
 
     total = max_updates if max_updates is not None else cfg.get('max_updates', 100000)
     # train.py:98-108 of the reference: continue from the newest checkpoint of the experiment directory, if any
@@ -75,12 +97,14 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
         if rank == 0:
             print(f'resumed from {existing[-1].name} at step {trainer.global_step}')
     keep, interval = cfg.get('num_ckpt_keep', 5), cfg.get('val_check_interval', 1000)
-    saved, epoch = list(existing), trainer.global_step // max(1, len(data.batches(lengths, cfg.get('max_batch_frames', 80000), cfg.get('max_batch_size', 8), rank, world)))
+    saved, epoch = list(existing), trainer.global_step // max(1, len(sampler) // accumulate)
     while trainer.global_step < total:
-        plan = data.batches(lengths, cfg.get('max_batch_frames', 80000), cfg.get('max_batch_size', 8), rank, world, seed=epoch)
+        sampler.set_epoch(epoch)
+        plan = list(sampler)
         epoch += 1
-        for idx in plan:
-            out = trainer.training_step(data.collater([items[i] for i in idx], cfg))
+        for g in range(0, len(plan), accumulate):
+            micro = [train_set.collater([train_set[i] for i in idx]) for idx in plan[g:g + accumulate]]
+            out = trainer.training_step(micro if accumulate > 1 else micro[0])
             step = trainer.global_step
             if rank == 0 and (step % log_interval == 0 or step == total):
                 print(f'step {step}: ' + ', '.join(f'{k}={float(v):.5f}' for k, v in out.items() if k.endswith('loss')) +
@@ -89,7 +113,7 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
                 path = work / f'model_ckpt_steps_{step}.ckpt'
                 torch.save(trainer.checkpoint(), path)
                 saved.append(path)
-                if val_items:
+                if val_sampler is not None:
                     validate(step)
                 while len(saved) > keep:
                     saved.pop(0).unlink(missing_ok=True)
