@@ -8,6 +8,7 @@ from typing import Dict, Optional
 import torch
 
 from ..engine import ClipBatch, Engine
+from .grad_sync import BucketedGradSync
 from .model import TrainableMidiConforms
 from .ops import TrainOps
 
@@ -57,6 +58,13 @@ class MIDIExtractionTrainer:
         if process_group is not None or torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
             torch.distributed.broadcast(self.model.params.flat, src=0, group=process_group)      # identical replicas
+        # gradient all-reduce in buckets, overlapped with the backward pass (grad_sync.py); some_amd_ddp_overlap=False falls back
+        # to one all-reduce of the whole flat gradient after backward
+        self.grad_sync = None
+        if self.world > 1 and config.get('some_amd_ddp_overlap', True):
+            P = self.model.params
+            order = [(P.views[k], P.offsets[k], (P.views[k].numel() + 63) // 64 * 64) for k in P.param_names]
+            self.grad_sync = BucketedGradSync(P.grad, order, process_group, int(config.get('some_amd_ddp_bucket_mb', 32)) << 20)
 
     # ---- me_task.py:79-111 ------------------------------------------------------------------------------------
     def run_model(self, sample: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -84,15 +92,19 @@ class MIDIExtractionTrainer:
         micro = sample if isinstance(sample, (list, tuple)) else [sample]
         scale = self.loss_scale
         losses, total = {}, 0.0
-        for mb in micro:
+        for i, mb in enumerate(micro):
             part = self.run_model(mb)
             part_total = sum(part.values())
             weight = scale / len(micro)
+            if self.grad_sync is not None and i == len(micro) - 1:
+                self.grad_sync.arm()                   # buckets go out as this backward pass completes them
             (part_total * weight if weight != 1.0 else part_total).backward()
             total = total + part_total.detach() / len(micro)
             for k, v in part.items():
                 losses[k] = losses.get(k, 0.0) + v.detach() / len(micro)
-        if self.world > 1:
+        if self.grad_sync is not None:
+            self.grad_sync.finish()
+        elif self.world > 1:
             torch.distributed.all_reduce(P.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
         # global gradient norm on the device (one double comes back: the step's only host synchronisation); it serves
         # Lightning's gradient_clip_val = clip_grad_norm (configs/base.yaml:49, train.py:88) and the overflow check

@@ -188,7 +188,7 @@ from some_amd import synth
 from some_amd.configs import get_config
 from some_amd.training.task import MIDIExtractionTrainer
 cfg = get_config('two_head_model', lay=1)
-tr = MIDIExtractionTrainer(cfg, device='cuda:0', seed=100 + rank)        # different initial weights: rank 0's must win
+tr = MIDIExtractionTrainer(dict(cfg, some_amd_ddp_bucket_mb=4), device='cuda:0', seed=100 + rank)        # different initial weights: rank 0's must win
 assert tr.world == 2
 sample = {k: torch.from_numpy(v).cuda() for k, v in synth.synth_train_batch(seed=21 + rank).items()}   # different data per rank
 for _ in range(2):
@@ -198,6 +198,15 @@ flat = tr.model.params.flat
 both = [torch.empty_like(flat), torch.empty_like(flat)]
 dist.all_gather(both, flat)
 assert torch.equal(both[0], both[1]), 'replicas diverged'
+# the default is the bucketed all-reduce launched from inside backward (grad_sync.py): every bucket went out, most of them
+# before backward returned; a single all-reduce of the flat gradient after backward gives the same parameters bit for bit
+gs = tr.grad_sync
+assert gs is not None and sorted(gs.launch_order) == list(range(len(gs.bounds))) and len(gs.bounds) >= 2, (gs.launch_order, gs.bounds)
+tr1 = MIDIExtractionTrainer(dict(cfg, some_amd_ddp_overlap=False, some_amd_ddp_bucket_mb=4), device='cuda:0', seed=100 + rank)
+assert tr1.grad_sync is None
+for _ in range(2):
+    tr1.training_step(sample)
+assert torch.equal(tr1.model.params.flat, flat), 'bucketed and single all-reduce disagree'
 torch.save({'flat': flat.cpu(), 'loss': float(out['total_loss'])}, os.environ['OUT'] + f'.{rank}')
 dist.barrier()
 dist.destroy_process_group()

@@ -152,3 +152,90 @@ def test_eval_sampler_and_batch_by_size_equal_the_reference(golden_dir):
     assert [list(map(int, b)) for b in got] == g['batch_by_size_multiple']
     with pytest.raises(AssertionError, match='exceeds'):
         batch_by_size([0], lambda i: 5000, max_batch_frames=4000)
+
+
+_SYNC_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ['REPO'])
+import torch.distributed as dist
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + os.environ['PORT'], rank=int(os.environ['RANK']), world_size=2)
+rank = dist.get_rank()
+from some_amd.training.grad_sync import BucketedGradSync
+# a flat parameter / gradient buffer cut into views, as FlatParams does; "layers" used in order by the forward pass
+sizes = [4096, 64] * 4
+offs, pos = [], 0
+for n in sizes:
+    offs.append(pos); pos += n
+flat = torch.linspace(-1, 1, pos).clone()
+grad = torch.zeros(pos)
+views = []
+for n, off in zip(sizes, offs):
+    p = flat[off:off + n]
+    p.requires_grad_(True)
+    p.grad = grad[off:off + n]
+    views.append(p)
+sync = BucketedGradSync(grad, [(p, off, n) for p, off, n in zip(views, offs, sizes)], None, bucket_bytes=5000 * 4)
+assert sync.bounds == [(0, 4160), (4160, 8320), (8320, 12480), (12480, 16640)]
+def loss_fn(skip_last=False):
+    x = torch.full((64,), 0.5 + rank)
+    for i in range(0, len(views) - (2 if skip_last else 0), 2):
+        w, b = views[i].view(-1, 64), views[i + 1]
+        x = torch.tanh(w @ x) + b * x
+    return (x * x).sum()
+for skip_last in (False, True):
+    # reference: plain backward, one all-reduce of the whole buffer
+    grad.zero_()
+    loss_fn(skip_last).backward()
+    want = grad.clone()
+    dist.all_reduce(want)
+    # micro-batch accumulation: the first backward is NOT reduced, the armed one is, bucket by bucket, during backward
+    grad.zero_()
+    loss_fn(skip_last).backward()
+    assert not sync.armed
+    first = grad.clone()
+    sync.arm()
+    loss_fn(skip_last).backward()
+    launched_in_backward = list(sync.launch_order)
+    sync.finish()
+    local_two = first * 2
+    want_two = local_two.clone()
+    dist.all_reduce(want_two)
+    assert torch.equal(grad, want_two), (grad - want_two).abs().max()
+    # last layers first: buckets complete in descending order while backward runs; a bucket whose parameters got no gradient
+    # (skip_last) is only sent by finish()
+    assert launched_in_backward == sorted(launched_in_backward, reverse=True) and len(launched_in_backward) >= 3
+    assert (len(launched_in_backward) < len(sync.bounds)) == skip_last
+    assert sorted(sync.launch_order) == list(range(len(sync.bounds)))
+    grad.zero_()
+    sync.arm()
+    loss_fn(skip_last).backward()
+    sync.finish()
+    assert torch.equal(grad, want)
+try:
+    sync.finish()
+    raise SystemExit('finish() without arm() must raise')
+except RuntimeError:
+    pass
+dist.barrier()
+dist.destroy_process_group()
+print('ok', rank)
+'''
+
+
+def test_bucketed_gradient_sync_overlaps_backward_and_equals_one_all_reduce(tmp_path):
+    """grad_sync.BucketedGradSync on gloo, world size 2 (CPU): buckets are launched from inside the backward pass, last
+    layers first; the reduced flat gradient equals a single all-reduce bit for bit, with gradient accumulation and with
+    parameters that receive no gradient."""
+    import os
+    import pathlib
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    script = tmp_path / 'sync_worker.py'
+    script.write_text(_SYNC_WORKER)
+    root = pathlib.Path(__file__).resolve().parents[1]
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), PORT=str(port), REPO=str(root)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs

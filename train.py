@@ -8,7 +8,8 @@ containers + ``.lengths``, read without h5py through some_amd/utils/hdf5_lite.py
 DsBatchSampler / DsEvalBatchSampler plans; ``--synthetic N`` trains on N synthetic sung clips with known notes instead
 (units from the HIP log-mel front end).  Multi-GPU: launch with
 ``python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...`` - one process per GPU, rank 0's
-initial weights broadcast once, one all-reduce of the flat gradient per step (RCCL), every rank its own batches."""
+initial weights broadcast once, the flat gradient all-reduced in buckets overlapped with backward (RCCL), every rank its own
+DsBatchSampler column."""
 import os
 import pathlib
 
