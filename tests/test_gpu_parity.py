@@ -746,3 +746,35 @@ def test_dual_stream_forward_is_bit_identical_to_grouped_launches(monkeypatch):
             assert torch.equal(m, runs[0][0]) and torch.equal(b, runs[0][1])
         outs[mode] = runs[0]
     assert torch.equal(outs['0'][0], outs['1'][0]) and torch.equal(outs['0'][1], outs['1'][1])
+
+
+def test_forward_is_capturable_in_a_hip_graph(engine_for):
+    """include/some_amd.h: every entry point only enqueues on the caller's stream - so log-mel + forward (dual-stream fork /
+    join included, once the helper stream exists) can be captured into a hipGraph and replayed on new audio; outputs are
+    bit-identical to eager launches."""
+    from some_amd import _lib
+    from some_amd.engine import ClipBatch
+    eng = engine_for('midi_conformer', 2, 41)
+    clips = [synth.synth_clip(70 + i, 1.7) for i in range(3)]
+    batch = ClipBatch.from_sample_counts([len(c) for c in clips], eng.hop, 'cuda')
+    audio = torch.from_numpy(np.concatenate(clips)).cuda()
+
+    def run():
+        return eng.forward(eng.logmel(audio, batch), batch, head_mode=_lib.HEAD_SIGMOID)
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                     # warm-up on the capture stream: workspace, helper stream, tables
+        eager = [t.clone() for t in run()]
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        out = run()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], eager[0]) and torch.equal(out[1], eager[1])
+    other = torch.from_numpy(np.concatenate([synth.synth_clip(80 + i, 1.7) for i in range(3)])).cuda()
+    audio.copy_(other)                                # new audio in the captured input buffer
+    graph.replay()
+    torch.cuda.synchronize()
+    want = eng.forward(eng.logmel(other, batch), batch, head_mode=_lib.HEAD_SIGMOID)
+    assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1]) and not torch.equal(out[0], eager[0])
