@@ -216,13 +216,16 @@ size_t some_train_scratch_bytes(const SomeHandle* h, int64_t M, int32_t N);
 /* Weight-gradient GEMM  C[M, N] = A[M, K] W[N, K]^T  with a LONG contraction (K = all frames of the batch) and a small
  * output: split-f16 kernel with the contraction cut into slices across workgroups (blockIdx.z), partial planes in
  * partial_dev (some_train_gemm_splitk_bytes), summed in slice order - deterministic.  A_split / W_split: SPLIT32 rows
- * (some_op_split_rows), K % 32 == 0, lda % 32 == 0.  hi_only = 1: plain f16 operands (one product instead of three). */
+ * (some_op_split_rows), K % 32 == 0, lda % 32 == 0.  hi_only = 1: plain f16 operands (one product instead of three);
+ * hi_only = 2: bf16 operands (made with SOME_OPERAND_BF16 / split_out = 2), the reference's pl_trainer_precision 'bf16'
+ * (configs/midi_conformer.yaml:35).  The same 0 / 1 / 2 applies to the attention entry points below. */
 size_t some_train_gemm_splitk_bytes(const SomeHandle* h, int32_t M, int32_t N, int32_t K);
 int some_train_gemm_splitk(SomeHandle* h, const float* A_split_dev, int32_t lda, const float* W_split_dev, float* C_dev,
                            int32_t M, int32_t N, int32_t K, int32_t hi_only, void* partial_dev, size_t partial_bytes,
                            void* stream);
 /* out[n, m] = in[m, n] for m < M, 0 for M <= m < ld_out (the zero padding makes ld_out a valid contraction length).
- * split_out = 1: rows are written in SPLIT32 format (ready as a split-f16 GEMM operand; ld_out % 32 == 0). */
+ * split_out = 1: rows are written in SPLIT32 format (ready as a split-f16 GEMM operand; ld_out % 32 == 0);
+ * split_out = 2: the same slots with bf16 hi halves (SOME_OPERAND_BF16). */
 int some_train_transpose(SomeHandle* h, const float* in_dev, int32_t M, int32_t N, int32_t ld_in, float* out_dev,
                          int32_t ld_out, int32_t split_out, void* stream);
 /* out[n] (+)= sum_m x[m, n]: bias gradient of nn.Linear / Conv1d. */
@@ -330,6 +333,7 @@ int some_train_attention_bwd_f16x3(SomeHandle* h, const float* qkv_split_dev, co
 #define SOME_GEMM_SPLIT_IN 1    /* A and W are in SPLIT32 format -> 3-term split-f16 kernel (K % 32 == 0)            */
 #define SOME_GEMM_SPLIT_OUT 2   /* C written in SPLIT32 format (SOME_EPI_BIAS_SILU only)                            */
 #define SOME_GEMM_HI_ONLY 4      /* with SPLIT_IN: use the f16 hi halves only - plain f16 x f16 -> fp32 (mixed-precision training); EPI_NONE / EPI_BIAS */
+#define SOME_GEMM_HI_BF16 8      /* with HI_ONLY: the hi slots hold bf16 (SOME_OPERAND_BF16) - bf16 x bf16 -> fp32 */
 #define SOME_GEMM_TILE(t) (((t) & 7) << 8)   /* split kernel tile: 0 = 128x128, 1 = 256x128, 2 = 256x256, 3 = DMA ring 128x256, 4 = 64x128 */
 int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t lda, const float* W_dev,
                  const float* bias_dev, const float* res_dev, int32_t ldr, float* C_dev, int32_t ldc,
@@ -337,6 +341,9 @@ int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t ld
                  int32_t flags, void* stream);
 /* fp32 rows [rows, K] -> SPLIT32 format (per 32-element k-block: 32 f16 hi | 32 f16 lo; same byte size). */
 int some_op_split_rows(SomeHandle* h, const float* x_dev, float* out_dev, int64_t rows, int32_t K, void* stream);
+#define SOME_OPERAND_F16X2 0     /* hi = f16(x), lo = f16(x - hi): operands of the 3-product and the f16 one-product kernels */
+#define SOME_OPERAND_BF16 1      /* hi slot = bf16(x), lo = 0: operands of the bf16 one-product kernels (hi_only = 2 / SOME_GEMM_HI_BF16) */
+int some_op_split_rows_fmt(SomeHandle* h, const float* x_dev, float* out_dev, int64_t rows, int32_t K, int32_t format, void* stream);
 /* nn.LayerNorm(512), eps 1e-5 (Gconform.py:49-53): y = LN(x) * gamma + beta, rows of 512. */
 int some_op_layernorm(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
                       float* y_dev, float* y_split_dev, int32_t M, void* stream);   /* either output may be NULL */

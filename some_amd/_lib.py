@@ -21,7 +21,8 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 SAMPLE_F32, SAMPLE_PCM16 = 0, 1
 (ELT_SILU_FWD, ELT_SILU_BWD, ELT_SIGMOID_FWD, ELT_SIGMOID_BWD, ELT_AXPY, ELT_DROPOUT, ELT_SILU_DROP_FWD, ELT_SILU_DROP_BWD,
  ELT_AXPY_DROP) = range(9)
-GEMM_SPLIT_IN, GEMM_SPLIT_OUT, GEMM_HI_ONLY = 1, 2, 4
+GEMM_SPLIT_IN, GEMM_SPLIT_OUT, GEMM_HI_ONLY, GEMM_HI_BF16 = 1, 2, 4, 8
+OPERAND_F16X2, OPERAND_BF16 = 0, 1
 
 
 class SomeConfig(C.Structure):
@@ -92,6 +93,7 @@ SYMBOLS = {
     'some_op_gemm': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32,
                                C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, C.c_int32, _P]),
     'some_op_split_rows': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
+    'some_op_split_rows_fmt': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     'some_op_layernorm': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     'some_op_attention': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     'some_op_qkv_attention_f16x3': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_size_t, _P]),

@@ -820,7 +820,7 @@ int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t ld
         if ((K & 31) || (lda & 31)) return fail(h, SOME_EINVAL, "some_op_gemm: SPLIT32 operands need K % 32 == 0 and lda % 32 == 0");
         if (flags & SOME_GEMM_HI_ONLY) {
             if (epilogue != EPI_NONE && epilogue != EPI_BIAS) return fail(h, SOME_EINVAL, "some_op_gemm: HI_ONLY supports EPI_NONE / EPI_BIAS");
-            HIP_TRY(h, launch_gemm_f16x1(static_cast<GemmEpi>(epilogue), a, (flags >> 8) & 7, s));
+            HIP_TRY(h, launch_gemm_f16x1(static_cast<GemmEpi>(epilogue), a, (flags >> 8) & 7, s, (flags & SOME_GEMM_HI_BF16) != 0));
         } else {
             HIP_TRY(h, launch_gemm_f16x3(static_cast<GemmEpi>(epilogue), a, (flags & SOME_GEMM_SPLIT_OUT) != 0, (flags >> 8) & 7, s));
         }
@@ -831,9 +831,14 @@ int some_op_gemm(SomeHandle* h, int32_t epilogue, const float* A_dev, int32_t ld
 }
 
 int some_op_split_rows(SomeHandle* h, const float* x_dev, float* out_dev, int64_t rows, int32_t K, void* stream) {
+    return some_op_split_rows_fmt(h, x_dev, out_dev, rows, K, SOME_OPERAND_F16X2, stream);
+}
+
+int some_op_split_rows_fmt(SomeHandle* h, const float* x_dev, float* out_dev, int64_t rows, int32_t K, int32_t format, void* stream) {
     if (!h) return SOME_EINVAL;
     if (rows < 0 || K <= 0 || (K & 31) || !x_dev || !out_dev) return fail(h, SOME_EINVAL, "some_op_split_rows: bad argument (K % 32 == 0)");
-    HIP_TRY(h, launch_split_rows(x_dev, out_dev, rows, K, static_cast<hipStream_t>(stream)));
+    if (format != SOME_OPERAND_F16X2 && format != SOME_OPERAND_BF16) return fail(h, SOME_EINVAL, "some_op_split_rows_fmt: bad format");
+    HIP_TRY(h, launch_split_rows(x_dev, out_dev, rows, K, static_cast<hipStream_t>(stream), format == SOME_OPERAND_BF16));
     return SOME_OK;
 }
 

@@ -80,13 +80,19 @@ __device__ __forceinline__ void split8(const f32x16& p, int base, half8& h, half
     }
 }
 
+// bf16 operand mode (TERMS = 1 only): hi = bf16(p) round-to-nearest in the hi slots, no lo
+__device__ __forceinline__ void split8_bf16(const f32x16& p, int base, half8& h) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = bf16_as_half(p[base + i]);
+}
+
 // TRAIN = true: the training forward (train_api: some_train_attention_fwd_f16x3) - Q / K rows come straight from
 // split_rows(qkv) (row stride 6144 B), V^T from transpose(qkv, split) (SPLIT32 over frames: 32-frame blocks [32 hi | 32 lo]),
 // the output is fp32 and the base-2 log-sum-exp is stored for the backward.
 // QT = query tiles (of 32) per wavefront.  QT = 1: 128 queries per workgroup, two workgroups per CU (two wavefronts per SIMD
 // cover each other's stalls).  QT = 2: 256 queries per workgroup, ONE wavefront per SIMD with the 512-register budget -
 // every K / V^T fragment read from LDS feeds two MFMA column tiles, staging traffic and barriers per MFMA halve.
-template <bool TRAIN, int TERMS = 3, int QT = 1>
+template <bool TRAIN, int TERMS = 3, int QT = 1, bool BF16 = false>      // BF16: bf16 hi halves, TERMS = 1 only (split.h)
 __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3Args a, int nqb) {
     constexpr int QB = 128 * QT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -183,19 +189,19 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
             if (TERMS == 3) {
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
-                    s0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[t][s], s0[t], 0, 0, 0);
-                    s1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[t][s], s1[t], 0, 0, 0);
+                    s0[t] = mfma_hi<BF16>(kl0, qh[t][s], s0[t]);
+                    s1[t] = mfma_hi<BF16>(kl1, qh[t][s], s1[t]);
                 }
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
-                    s0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[t][s], s0[t], 0, 0, 0);
-                    s1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[t][s], s1[t], 0, 0, 0);
+                    s0[t] = mfma_hi<BF16>(kh0, ql[t][s], s0[t]);
+                    s1[t] = mfma_hi<BF16>(kh1, ql[t][s], s1[t]);
                 }
             }
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                s0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[t][s], s0[t], 0, 0, 0);
-                s1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[t][s], s1[t], 0, 0, 0);
+                s0[t] = mfma_hi<BF16>(kh0, qh[t][s], s0[t]);
+                s1[t] = mfma_hi<BF16>(kh1, qh[t][s], s1[t]);
             }
         }
     };
@@ -299,7 +305,10 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
             for (int sp = 0; sp < 2; ++sp) {
                 half8 ph[QT], pl[QT];
 #pragma unroll
-                for (int t = 0; t < QT; ++t) split8(sub == 0 ? s0[t] : s1[t], 8 * sp, ph[t], pl[t]);
+                for (int t = 0; t < QT; ++t) {
+                    if constexpr (BF16) split8_bf16(sub == 0 ? s0[t] : s1[t], 8 * sp, ph[t]);
+                    else split8(sub == 0 ? s0[t] : s1[t], 8 * sp, ph[t], pl[t]);
+                }
                 // dword offset of key 32 sub + 16 s' and of its lo half: row = [64 hi | 64 lo] (planes) or
                 // [32 hi | 32 lo][32 hi | 32 lo] (SPLIT32 over frames)
                 constexpr int LO = TRAIN ? 16 : 32;
@@ -332,19 +341,19 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
                 if (TERMS == 3) {
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {
-                        o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl0, ph[t], o0[t], 0, 0, 0);
-                        o1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl1, ph[t], o1[t], 0, 0, 0);
+                        o0[t] = mfma_hi<BF16>(vl0, ph[t], o0[t]);
+                        o1[t] = mfma_hi<BF16>(vl1, ph[t], o1[t]);
                     }
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {
-                        o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, pl[t], o0[t], 0, 0, 0);
-                        o1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, pl[t], o1[t], 0, 0, 0);
+                        o0[t] = mfma_hi<BF16>(vh0, pl[t], o0[t]);
+                        o1[t] = mfma_hi<BF16>(vh1, pl[t], o1[t]);
                     }
                 }
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
-                    o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, ph[t], o0[t], 0, 0, 0);
-                    o1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, ph[t], o1[t], 0, 0, 0);
+                    o0[t] = mfma_hi<BF16>(vh0, ph[t], o0[t]);
+                    o1[t] = mfma_hi<BF16>(vh1, ph[t], o1[t]);
                 }
             }
         }
@@ -468,6 +477,8 @@ hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<true, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<false, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -483,7 +494,8 @@ hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
     const int nqb = (a.max_frames + QB - 1) / QB;
     const int units = a.B * kHeads * a.groups;
     const int slots = (units + 7) / 8;
-    if (!inference && a.hi_only) hipLaunchKernelGGL((attention3_kernel<true, 1>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    if (!inference && a.hi_only == 2) hipLaunchKernelGGL((attention3_kernel<true, 1, 1, true>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    else if (!inference && a.hi_only) hipLaunchKernelGGL((attention3_kernel<true, 1>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else if (!inference) hipLaunchKernelGGL(attention3_kernel<true>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else if (qt == 2) hipLaunchKernelGGL((attention3_kernel<false, 3, 2>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else hipLaunchKernelGGL(attention3_kernel<false>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);

@@ -299,8 +299,9 @@ __device__ __forceinline__ void epilogue_tr(const GemmArgs& a, const GemmGroup& 
 
 // TERMS = 3: x = hi + lo on both operands, three products (fp32-equivalent).  TERMS = 1: hi halves only - plain f16 operands
 // with fp32 accumulation on the same SPLIT32 layout (mixed-precision training, some_train_gemm_f16).
-template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3, bool TR = false>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3, bool TR = false, bool BF16 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs a) {
+    static_assert(!BF16 || (TERMS == 1 && !TR), "bf16 hi halves: one-product kernels only (split.h)");
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int STAGE = (BM + BN) * LDT;               // dwords
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     const int w_off = (BM + wn * TN * 32 + (TR ? pi32(l31) : l31)) * LDT + kg * 4;
     // TR: the W fragment is the first MFMA operand (accumulator rows <- n, lane <- m), see epilogue_tr
     auto mma = [](half8 x, half8 w, f32x16 c) {
-        return TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, c, 0, 0, 0);
+        return TR ? mfma_hi<BF16>(w, x, c) : mfma_hi<BF16>(x, w, c);
     };
 
     // the MFMAs of one k-block out of LDS buffer `buf`
@@ -697,12 +698,12 @@ hipError_t launch_ring(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3, bool TR = false>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3, bool TR = false, bool BF16 = false>
 hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LDT * sizeof(float);
     static bool attr_set = false;
-    auto kern = &hgemm3_kernel<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, TERMS, TR>;
+    auto kern = &hgemm3_kernel<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, TERMS, TR, BF16>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -759,16 +760,22 @@ static hipError_t launch_one(GemmEpi epi, const GemmArgs& a, bool out_split, int
 
 // Plain f16 operands (hi halves of the SPLIT32 layout), fp32 accumulate: the mixed-precision training GEMM.  256 x 256 tile,
 // EPI_NONE / EPI_BIAS, optional split-K.
-hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a_in, int tile, hipStream_t s) {
+template <bool BF16>
+static hipError_t launch_x1(GemmEpi epi, const GemmArgs& a, bool small, hipStream_t s) {
+    if (epi == EPI_NONE)
+        return small ? launch_cfg<2, 2, 2, 2, EPI_NONE, false, 1, false, BF16>(a, s) : launch_cfg<4, 2, 2, 4, EPI_NONE, false, 1, false, BF16>(a, s);
+    if (epi == EPI_BIAS && a.k_slices <= 1)
+        return small ? launch_cfg<2, 2, 2, 2, EPI_BIAS, false, 1, false, BF16>(a, s) : launch_cfg<4, 2, 2, 4, EPI_BIAS, false, 1, false, BF16>(a, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a_in, int tile, hipStream_t s, int bf16) {
     if (a_in.M <= 0) return hipSuccess;
     if ((a_in.K & 31) || (a_in.lda & 31)) return hipErrorInvalidValue;
     GemmArgs a = a_in;
     a.m_begin = 0;
     const bool small = tile == 0;                     // 128 x 128 (two workgroups per CU) for small grids, else 256 x 256
-    if (epi == EPI_NONE) return small ? launch_cfg<2, 2, 2, 2, EPI_NONE, false, 1>(a, s) : launch_cfg<4, 2, 2, 4, EPI_NONE, false, 1>(a, s);
-    if (epi == EPI_BIAS && a.k_slices <= 1)
-        return small ? launch_cfg<2, 2, 2, 2, EPI_BIAS, false, 1>(a, s) : launch_cfg<4, 2, 2, 4, EPI_BIAS, false, 1>(a, s);
-    return hipErrorInvalidValue;
+    return bf16 ? launch_x1<true>(epi, a, small, s) : launch_x1<false>(epi, a, small, s);
 }
 
 hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a_in, bool out_split, int tile, hipStream_t s) {

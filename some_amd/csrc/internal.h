@@ -60,7 +60,7 @@ hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 // (EPI_BIAS_SILU only); tile: 0 = 128x128, 1 = 256x128, 2 = 256x256.
 hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a, bool out_split, int tile, hipStream_t s);
 // hi halves only (plain f16 x f16 -> fp32): mixed-precision training; EPI_NONE (optional split-K) / EPI_BIAS, 256 x 256 tile
-hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a, int tile, hipStream_t s);
+hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a, int tile, hipStream_t s, int bf16 = 0);    // bf16: hi slots hold bf16 (split.h)
 
 // ---- row ops --------------------------------------------------------------------------------------
 // y[g][m][:] = LayerNorm(x[g][m][:]) * gamma[g] + beta[g], eps 1e-5, rows of 512.
@@ -74,7 +74,7 @@ struct LnArgs {
     int M;
 };
 hipError_t launch_layernorm(const LnArgs& a, hipStream_t s);
-hipError_t launch_split_rows(const float* x, float* out, int64_t rows, int K, hipStream_t s);
+hipError_t launch_split_rows(const float* x, float* out, int64_t rows, int K, hipStream_t s, int bf16 = 0);
 // in-place softmax over rows of width n (head_mode SOFTMAX)
 hipError_t launch_row_softmax(float* x, int64_t rows, int n, hipStream_t s);
 
@@ -116,7 +116,7 @@ struct Attn3Args {
     // transpose(qkv, split) ([.., ldv] SPLIT32 over frames, ldv % 64 == 0); fp32 output + base-2 log-sum-exp [8, M]
     float* out32[kStreams];
     float* lse[kStreams];
-    int hi_only;                   // training forward only: plain f16 operands (one product instead of three)
+    int hi_only;                   // training forward only: 1 = plain f16 operands (one product instead of three), 2 = bf16 operands
 };
 hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s);
 inline int vt_ld(int64_t M) { return (int)((M + 255) / 256 * 256); }

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ x,
     }
 }
 
-// fp32 rows -> SPLIT32 (split.h): one thread per 4 consecutive elements
+// fp32 rows -> SPLIT32 (split.h): one thread per 4 consecutive elements.  BF16: hi = bf16(x), lo = 0 (split.h)
+template <bool BF16>
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, char* __restrict__ out, int64_t n4, int k4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const int64_t row = i / k4;
@@ -109,7 +110,12 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
         half4 hh, ll;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { half_t h, l; split_f16(v[j], h, l); hh[j] = h; ll[j] = l; }
+        for (int j = 0; j < 4; ++j) {
+            half_t h, l;
+            if (BF16) { h = bf16_as_half(v[j]); l = (half_t)0.f; }
+            else split_f16(v[j], h, l);
+            hh[j] = h; ll[j] = l;
+        }
         char* p = out + row * (int64_t)k4 * 16 + (c >> 5) * 128 + (c & 31) * 2;
         *reinterpret_cast<half4*>(p) = hh;
         *reinterpret_cast<half4*>(p + 64) = ll;
@@ -118,13 +124,14 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 
 }  // namespace
 
-hipError_t launch_split_rows(const float* x, float* out, int64_t rows, int K, hipStream_t s) {
+hipError_t launch_split_rows(const float* x, float* out, int64_t rows, int K, hipStream_t s, int bf16) {
     if (rows <= 0) return hipSuccess;
     if (K & 31) return hipErrorInvalidValue;
     const int64_t n4 = rows * (K / 4);
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, reinterpret_cast<char*>(out), n4, K / 4);
+    if (bf16) hipLaunchKernelGGL(split_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, x, reinterpret_cast<char*>(out), n4, K / 4);
+    else hipLaunchKernelGGL(split_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, x, reinterpret_cast<char*>(out), n4, K / 4);
     return hipGetLastError();
 }
 

@@ -22,5 +22,19 @@ __host__ __device__ inline void split_f16(float x, half_t& hi, half_t& lo) {
     lo = (half_t)(x - (float)hi);
 }
 
+// bf16 operand mode of the mixed-precision training kernels (configs/midi_conformer.yaml:35 pl_trainer_precision 'bf16'): the hi
+// slot of a SPLIT32 block then holds the bf16 rounding of x (same 16 bits of storage, typed half_t only for transport), the
+// lo slot is zero, and the one-product kernels issue v_mfma_f32_32x32x16_bf16 on the same fragments.
+#if defined(__HIPCC__)
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ half_t bf16_as_half(float x) { return __builtin_bit_cast(half_t, (__bf16)x); }
+template <bool BF16>
+__device__ __forceinline__ f32x16 mfma_hi(half8 a, half8 b, f32x16 c) {
+    if constexpr (BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+#endif
+
 // byte offset of element k's hi half inside a SPLIT32 row; the lo half sits 64 bytes further
 __host__ __device__ inline size_t split_hi_off(int k) { return (size_t)(k >> 5) * 128 + (size_t)(k & 31) * 2; }

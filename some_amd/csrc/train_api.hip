@@ -62,7 +62,8 @@ int some_train_gemm_splitk(SomeHandle* h, const float* A_split_dev, int32_t lda,
     a.g[0] = GemmGroup{A_split_dev, W_split_dev, nullptr, nullptr, slices > 1 ? static_cast<float*>(partial_dev) : C_dev, nullptr, N, 0};
     a.groups = 1; a.M = M; a.K = K; a.lda = lda; a.ldc = N; a.ldr = N; a.alpha = 1.f;
     a.k_slices = slices; a.slice_stride = (size_t)M * N;
-    if (hi_only) T_TRY(h, launch_gemm_f16x1(EPI_NONE, a, 2, st(stream)));
+    T_CHECK(h, hi_only >= 0 && hi_only <= 2, "some_train_gemm_splitk: hi_only must be 0, 1 (f16) or 2 (bf16)");
+    if (hi_only) T_TRY(h, launch_gemm_f16x1(EPI_NONE, a, 2, st(stream), hi_only == 2));
     else T_TRY(h, launch_gemm_f16x3(EPI_NONE, a, false, 2, st(stream)));
     if (slices > 1) T_TRY(h, launch_reduce_slices(static_cast<const float*>(partial_dev), slices, (size_t)M * N, C_dev, st(stream)));
     return SOME_OK;
@@ -72,6 +73,7 @@ int some_train_transpose(SomeHandle* h, const float* in_dev, int32_t M, int32_t 
                          int32_t ld_out, int32_t split_out, void* stream) {
     if (!h) return SOME_EINVAL;
     T_CHECK(h, M >= 0 && N >= 0 && ld_in >= N && ld_out >= M, "some_train_transpose: bad shape");
+    T_CHECK(h, split_out >= 0 && split_out <= 2, "some_train_transpose: split_out must be 0 (fp32), 1 (SPLIT32) or 2 (bf16 hi)");
     T_CHECK(h, !split_out || (ld_out % 32) == 0, "some_train_transpose: SPLIT32 output needs ld_out % 32 == 0");
     if (M == 0 || N == 0) return SOME_OK;
     T_CHECK(h, in_dev && out_dev, "some_train_transpose: null pointer");
@@ -265,7 +267,7 @@ int some_train_attention_fwd_f16x3(SomeHandle* h, const float* qkv_split_dev, co
     Attn3Args a{};
     a.q[0] = qkv_split_dev; a.k[0] = qkv_split_dev + kDim;
     a.vt[0] = qkv_t_split_dev + (size_t)2 * kDim * Mp;            // V rows of the frame-major split tensor
-    a.out32[0] = out_dev; a.lse[0] = lse_dev; a.hi_only = hi_only ? 1 : 0;
+    a.out32[0] = out_dev; a.lse[0] = lse_dev; a.hi_only = hi_only;
     a.frame_offsets = frame_offsets_dev; a.groups = 1; a.B = B; a.max_frames = max_frames; a.M = M; a.ldv = Mp;
     T_TRY(h, launch_attention_f16x3(a, st(stream)));
     return SOME_OK;
@@ -284,7 +286,7 @@ int some_train_attention_bwd_f16x3(SomeHandle* h, const float* qkv_split_dev, co
                    dqkv_dev && dsum_scratch_dev, "some_train_attention_bwd_f16x3: null pointer");
     T_TRY(h, launch_attention_dsum(out_dev, dout_dev, dsum_scratch_dev, M, st(stream)));
     T_TRY(h, launch_attention_bwd_f16x3(qkv_split_dev, qkv_t_split_dev, dout_split_dev, dout_t_split_dev, lse_dev, dsum_scratch_dev,
-                                        frame_offsets_dev, B, max_frames, M, Mp, dqkv_dev, hi_only ? 1 : 0, st(stream)));
+                                        frame_offsets_dev, B, max_frames, M, Mp, dqkv_dev, hi_only, st(stream)));
     return SOME_OK;
 }
 

@@ -44,13 +44,23 @@ __device__ __forceinline__ void split8(const f32x16& p, int base, half8& h, half
 
 // product accumulate: acc += a * b with a = ah + al, b = bh + bl.  TERMS = 3: ah bh + ah bl + al bh (fp32-equivalent);
 // TERMS = 1: ah bh only (plain f16 operands: the mixed-precision training mode)
+// TERMS = 2: ONE product on bf16 operands (hi slots hold bf16, split.h) - the reference's pl_trainer_precision 'bf16'
 template <int TERMS>
 __device__ __forceinline__ void mma3(f32x16& acc, const half8& ah, const half8& al, const half8& bh, const half8& bl) {
     if (TERMS == 3) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+    acc = mfma_hi<TERMS == 2>(ah, bh, acc);
+}
+template <int TERMS>
+__device__ __forceinline__ void split8t(const f32x16& p, int base, half8& h, half8& l) {
+    if constexpr (TERMS == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { h[i] = bf16_as_half(p[base + i]); l[i] = (half_t)0.f; }
+    } else {
+        split8(p, base, h, l);
+    }
 }
 
 // fragment of a ROW-MAJOR SPLIT32 row of 64 dims at `row` (dword pointer), k-step s (dims 16 s .. 16 s + 15): 8 dims per lane half
@@ -207,8 +217,8 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dkv_kernel(Bwd3Args a, int n
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
             half8 ph, pl, gh, gl;
-            split8(s, 8 * sp, ph, pl);
-            split8(dp, 8 * sp, gh, gl);
+            split8t<TERMS>(s, 8 * sp, ph, pl);
+            split8t<TERMS>(dp, 8 * sp, gh, gl);
             half8 ah, al;
             frag_frames(Dt + l31 * LDT, sp, kg, ah, al);
             mma3<TERMS>(dv0, ah, al, ph, pl);
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dq_kernel(Bwd3Args a, int nq
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
             half8 gh, gl, ah, al;
-            split8(dp, 8 * sp, gh, gl);
+            split8t<TERMS>(dp, 8 * sp, gh, gl);
             frag_frames(Kt + l31 * LDT, sp, kg, ah, al);
             mma3<TERMS>(o0, ah, al, gh, gl);                     // dQ^T[d][q] += K^T dS^T
             frag_frames(Kt + (32 + l31) * LDT, sp, kg, ah, al);
@@ -397,5 +407,5 @@ hipError_t launch_attention_bwd_f16x3(const float* R, const float* Rt, const flo
                                       const int32_t* frame_offsets, int B, int max_frames, int M, int Mp, float* dqkv, int hi_only, hipStream_t s) {
     if (B <= 0 || max_frames <= 0 || M <= 0) return hipSuccess;
     Bwd3Args a{R, Rt, D, Dt, lse, dsum, dqkv, frame_offsets, B, max_frames, M, Mp};
-    return hi_only ? launch_bwd<1>(a, s) : launch_bwd<3>(a, s);
+    return hi_only == 2 ? launch_bwd<2>(a, s) : hi_only ? launch_bwd<1>(a, s) : launch_bwd<3>(a, s);
 }

@@ -28,7 +28,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---- transpose ---------------------------------------------------------------------------------------------
-template <bool SPLIT>
+template <int SPLIT>      // 0: fp32, 1: SPLIT32 (f16 hi + lo), 2: SPLIT32 slots with bf16 hi, zero lo (split.h)
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int M, int N, int ld_in,
                                                          float* __restrict__ out, int ld_out) {
     __shared__ float tile[32][33];
@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
             const float v = tile[tx][ty + 8 * i];                                        // zeros beyond M
             if (SPLIT) {   // SPLIT32 row (split.h): the 32 columns of this tile are exactly one k-block [32 hi | 32 lo]
                 half_t h, l;
-                split_f16(v, h, l);
+                if (SPLIT == 2) { h = bf16_as_half(v); l = (half_t)0.f; }
+                else split_f16(v, h, l);
                 half_t* blk = reinterpret_cast<half_t*>(out + (size_t)n * ld_out + m0);
                 blk[tx] = h;
                 blk[32 + tx] = l;
@@ -487,8 +488,9 @@ size_t train_dwconv_w_scratch_bytes(int M, int C) { return (size_t)((M + kDwChun
 hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, int split_out, hipStream_t s) {
     if (M <= 0 || N <= 0) return hipSuccess;
     dim3 grid((unsigned)((ld_out + 31) / 32), (unsigned)((N + 31) / 32));
-    if (split_out) hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, s, in, M, N, ld_in, out, ld_out);
-    else hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, s, in, M, N, ld_in, out, ld_out);
+    if (split_out == 2) hipLaunchKernelGGL(transpose_kernel<2>, grid, dim3(256), 0, s, in, M, N, ld_in, out, ld_out);
+    else if (split_out) hipLaunchKernelGGL(transpose_kernel<1>, grid, dim3(256), 0, s, in, M, N, ld_in, out, ld_out);
+    else hipLaunchKernelGGL(transpose_kernel<0>, grid, dim3(256), 0, s, in, M, N, ld_in, out, ld_out);
     return hipGetLastError();
 }
 

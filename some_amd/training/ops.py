@@ -29,15 +29,23 @@ class TrainOps:
         self._partial: Optional[torch.Tensor] = None
         self.gemm_precision = 'f16x3' if engine.c_config.precision == _lib.PRECISION_F16X3 else 'f32'
         self.attention_precision = self.gemm_precision      # forward + backward: split-f16 or exact-f32 MFMA kernels
-        self._hi = 0                                        # _lib.GEMM_HI_ONLY: mixed precision (set_mixed_precision)
+        self._hi = 0                                        # GEMM flag bits of the one-product modes (set_mixed_precision)
+        self._hi_mode = 0                                   # the `hi_only` argument: 0 three products, 1 f16, 2 bf16
+        self.operand = 'f16x2'
 
-    def set_mixed_precision(self, on: bool):
-        """Mixed-precision training (the reference's pl_trainer_precision '16-mixed' / 'bf16' analogue): the matrix products
-        read only the f16 hi halves of the split operands - plain f16 x f16 with fp32 accumulation, one MFMA product instead
-        of three - while parameters, activations, reductions, softmax statistics and the optimiser stay fp32."""
+    def set_mixed_precision(self, on: bool, operand: str = 'f16'):
+        """Mixed-precision training (the reference's pl_trainer_precision '16-mixed' / 'bf16'): the matrix products read one
+        16-bit value per element - ``operand`` 'f16' (the hi halves of the split operands; 11-bit significand, needs loss
+        scaling) or 'bf16' (the reference's bf16 autocast arithmetic: 8-bit significand, fp32 range) - with fp32 accumulation, one
+        MFMA product instead of three, while parameters, activations, reductions, softmax statistics and the optimiser stay fp32."""
         if on and self.gemm_precision != 'f16x3':
             raise ValueError('mixed precision runs on the split-f16 kernels: use some_amd_precision f16x3')
-        self._hi = _lib.GEMM_HI_ONLY if on else 0
+        if operand not in ('f16', 'bf16'):
+            raise ValueError(f"mixed-precision operand must be 'f16' or 'bf16', got {operand!r}")
+        bf16 = on and operand == 'bf16'
+        self._hi = (_lib.GEMM_HI_ONLY | (_lib.GEMM_HI_BF16 if bf16 else 0)) if on else 0
+        self._hi_mode = (2 if bf16 else 1) if on else 0
+        self.operand = 'bf16' if bf16 else 'f16x2'
 
     # ---- plumbing -------------------------------------------------------------------------------------------
     def stream(self):
@@ -59,7 +67,8 @@ class TrainOps:
     def split_rows(self, x: torch.Tensor) -> torch.Tensor:
         """fp32 [R, K] -> SPLIT32 rows (csrc/split.h: per 32-element k-block 32 f16 hi | 32 f16 lo; same byte size)."""
         out = torch.empty_like(x)
-        self.check(self.lib.some_op_split_rows(self.h, _p(x), _p(out), x.shape[0], x.shape[1], self.stream()))
+        fmt = _lib.OPERAND_BF16 if self._hi_mode == 2 else _lib.OPERAND_F16X2          # bf16 mode: hi slot = bf16(x), lo = 0
+        self.check(self.lib.some_op_split_rows_fmt(self.h, _p(x), _p(out), x.shape[0], x.shape[1], fmt, self.stream()))
         return out
 
     @staticmethod
@@ -121,23 +130,24 @@ class TrainOps:
         extra = 4 if with_bias else 0                                   # ones row + 3 zero rows keep (K + extra) % 4 == 0
         use3 = self.gemm_precision == 'f16x3' and N >= 32 and K % 4 == 0
         xt = torch.empty((K + extra, Mp), dtype=torch.float32, device=self.device)
-        self.check(self.lib.some_train_transpose(self.h, _p(x), M, K, K, _p(xt), Mp, 1 if use3 else 0, self.stream()))
+        split = (2 if self._hi_mode == 2 else 1) if use3 else 0         # SPLIT32 slots: f16 hi + lo, or bf16 hi
+        self.check(self.lib.some_train_transpose(self.h, _p(x), M, K, K, _p(xt), Mp, split, self.stream()))
         if with_bias:
             tail = xt[K:]
             tail.zero_()
-            if use3:                                                    # 1.0 = f16 0x3C00 in the hi halves, lo halves 0
-                tail[0].view(torch.int32).view(-1, 32)[:, :16] = 0x3C003C00
+            if use3:                                                    # 1.0 in the hi halves (f16 0x3C00 / bf16 0x3F80), lo halves 0
+                tail[0].view(torch.int32).view(-1, 32)[:, :16] = 0x3F803F80 if split == 2 else 0x3C003C00
             else:
                 tail[0].fill_(1.0)
         dyt = torch.empty((N, Mp), dtype=torch.float32, device=self.device)
-        self.check(self.lib.some_train_transpose(self.h, _p(dy), M, N, N, _p(dyt), Mp, 1 if use3 else 0, self.stream()))
+        self.check(self.lib.some_train_transpose(self.h, _p(dy), M, N, N, _p(dyt), Mp, split, self.stream()))
         Kx = K + extra
         out = self.new(N, Kx)
         if use3:
             need = int(self.lib.some_train_gemm_splitk_bytes(self.h, N, Kx, Mp))
             if self._partial is None or self._partial.numel() < need:
                 self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
-            self.check(self.lib.some_train_gemm_splitk(self.h, _p(dyt), Mp, _p(xt), _p(out), N, Kx, Mp, 1 if self._hi else 0, _p(self._partial), self._partial.numel(),
+            self.check(self.lib.some_train_gemm_splitk(self.h, _p(dyt), Mp, _p(xt), _p(out), N, Kx, Mp, self._hi_mode, _p(self._partial), self._partial.numel(),
                                                        self.stream()))
         else:
             self.check(self.lib.some_op_gemm(self.h, _lib.EPI_NONE, _p(dyt), Mp, _p(xt), None, None, Kx, _p(out), Kx, N, Kx, Mp, 1.0, 0, None, 0,
@@ -152,7 +162,7 @@ class TrainOps:
         M, N = x.shape
         Mp = (M + pad_to - 1) // pad_to * pad_to
         out = self.new(N, Mp)
-        self.check(self.lib.some_train_transpose(self.h, _p(x), M, N, N, _p(out), Mp, 1 if split else 0, self.stream()))
+        self.check(self.lib.some_train_transpose(self.h, _p(x), M, N, N, _p(out), Mp, (2 if self._hi_mode == 2 else 1) if split else 0, self.stream()))
         return out
 
     def colsum(self, x: torch.Tensor) -> torch.Tensor:
@@ -469,7 +479,7 @@ class _Attention(torch.autograd.Function):
         if ctx.prec == 'f16x3':
             R, Rt = ops.split_rows(qkv), ops.transpose(qkv, pad_to=64, split=True)
             ops.check(ops.lib.some_train_attention_fwd_f16x3(ops.h, _p(R), _p(Rt), _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M,
-                                                             Rt.shape[1], 1 if ops._hi else 0, _p(out), _p(lse), ops.stream()))
+                                                             Rt.shape[1], ops._hi_mode, _p(out), _p(lse), ops.stream()))
             ctx.save_for_backward(R, Rt, out, lse)
         else:
             ops.check(ops.lib.some_train_attention_fwd(ops.h, _p(qkv), _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M, _p(out),
@@ -491,7 +501,7 @@ class _Attention(torch.autograd.Function):
             dout = dout * scale
             D, Dt = ops.split_rows(dout), ops.transpose(dout, pad_to=64, split=True)
             ops.check(ops.lib.some_train_attention_bwd_f16x3(ops.h, _p(R), _p(Rt), _p(D), _p(Dt), _p(out), _p(dout), _p(lse),
-                                                             _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M, Rt.shape[1], 1 if ops._hi else 0,
+                                                             _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M, Rt.shape[1], ops._hi_mode,
                                                              _p(dqkv), _p(dsum), ops.stream()))
             dqkv.mul_(1.0 / scale)
         else:

@@ -32,7 +32,9 @@ class MIDIExtractionTrainer:
         # selects mixed precision - f16 operands on the matrix pipe, fp32 everything else, dynamic loss scaling
         prec = str(config.get('pl_trainer_precision', '32-true'))
         self.mixed = bool(config.get('some_amd_mixed_precision', '16' in prec))
-        self.ops.set_mixed_precision(self.mixed)
+        # 'bf16' / 'bf16-mixed' -> bf16 operands (the reference's arithmetic), '16-mixed' -> f16 operands; some_amd_mixed_operand overrides
+        self.mixed_operand = str(config.get('some_amd_mixed_operand', 'bf16' if 'bf16' in prec else 'f16'))
+        self.ops.set_mixed_precision(self.mixed, self.mixed_operand)
         self.model = TrainableMidiConforms(config, self.ops, seed=seed)
         oa = config.get('optimizer_args', {})
         self.base_lr = oa.get('lr', 1e-4)
@@ -49,7 +51,9 @@ class MIDIExtractionTrainer:
         # absolute floor is 2^-25 - activation gradients of a mean-reduced loss (~1 / (B T N)) sit below it unscaled.
         # The scaled gradient stays in the flat buffer and is unscaled inside the fused AdamW launch; a non-finite
         # gradient halves the scale and skips the update, `growth_interval` clean updates double it.
-        self.loss_scale = float(config.get('some_amd_loss_scale', 2.0 ** 14)) if self.ops.gemm_precision == 'f16x3' else 1.0
+        # bf16 operands have the fp32 exponent range: no scaling
+        scaled = self.ops.gemm_precision == 'f16x3' and self.ops.operand != 'bf16'
+        self.loss_scale = float(config.get('some_amd_loss_scale', 2.0 ** 14)) if scaled else 1.0
         self.growth_interval = int(config.get('some_amd_loss_scale_growth_interval', 200))
         self._clean_steps = 0
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=self.ops.device)

@@ -24,7 +24,8 @@ def main():
     ap.add_argument('--lay', type=int, default=3)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--mixed', action='store_true', help='mixed precision: f16 operands on the matrix pipe (pl_trainer_precision 16-bit)')
+    ap.add_argument('--mixed', action='store_true', help='mixed precision: 16-bit operands on the matrix pipe (pl_trainer_precision 16-bit)')
+    ap.add_argument('--operand', choices=['f16', 'bf16'], default='bf16', help="with --mixed: 'bf16' = pl_trainer_precision bf16 (the reference's configs), 'f16' = 16-mixed")
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank, local = int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
@@ -33,7 +34,7 @@ def main():
         torch.distributed.init_process_group(os.environ.get('SOME_AMD_DIST_BACKEND', 'nccl'))
     cfg = get_config('two_head_model', lay=args.lay)
     if args.mixed:
-        cfg['pl_trainer_precision'] = 'bf16'
+        cfg['pl_trainer_precision'] = 'bf16' if args.operand == 'bf16' else '16-mixed'
     tr = MIDIExtractionTrainer(cfg, device=f'cuda:{local}', seed=1)
     B, T = args.batch, args.frames
     rng = np.random.default_rng(rank)
@@ -56,7 +57,7 @@ def main():
     f_dense = nb * 12090368 + args.lay * 2097152 + 163840 + 1024 * 128 + 1024          # SURVEY.md section 8(d), per frame, forward
     flops = 3.0 * (f_dense + nb * 2048 * T) * B * T                                     # fwd + 2x bwd
     if rank == 0:
-        print(f'two_head_model lay {args.lay} ({"mixed f16" if tr.mixed else "fp32-equivalent"}): {B} x {T} frames/GPU x {world} GPU: {dt * 1e3:.1f} ms/step, '
+        print(f'two_head_model lay {args.lay} ({("mixed " + tr.mixed_operand) if tr.mixed else "fp32-equivalent"}): {B} x {T} frames/GPU x {world} GPU: {dt * 1e3:.1f} ms/step, '
               f'{world * B * T / dt:.0f} frames/s, {world * B * T * 512 / 44100 / dt:.0f} audio-s/s trained, '
               f'{flops / dt / 1e12:.1f} TFLOP/s/GPU (fwd+bwd model FLOPs), loss {out["total_loss"].item():.4f}')
     if world > 1:
