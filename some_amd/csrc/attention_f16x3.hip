@@ -41,6 +41,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef ATTN_PIN_STAGING
 #define ATTN_PIN_STAGING 0
 #endif
+#ifndef ATTN_V_BUFFER
+#define ATTN_V_BUFFER 1         // V^T tiles through buffer loads with a scalar tile offset (inference kernels)
+#endif
+#ifndef ATTN_WAVE_SGPR
+#define ATTN_WAVE_SGPR 0        // 1: wavefront index as an SGPR (readfirstlane)
+#endif
+#ifndef ATTN_SETPRIO
+#define ATTN_SETPRIO 1          // 1: raised wave priority over the PV product (pure MFMA + LDS reads; measured -3 % together with
+                                // -fno-slp-vectorize, which also frees the registers the flips would otherwise spill), 2: over QK + softmax (+1 %), 0: off
+#endif
 #ifndef ATTN_PACKED_F32
 #define ATTN_PACKED_F32 0       // softmax / P split on v_pk_fma_f32 / v_pk_add_f32 (0: scalar fp32 VALU)
 #endif
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
     const int q0 = qb * QB;
     if (q0 >= T) return;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = ATTN_WAVE_SGPR ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
     constexpr size_t ROW_B = TRAIN ? 6144 : 2048;       // bytes between consecutive frames of Q / K
     const char* __restrict__ Qp = reinterpret_cast<const char*>(a.q[g]) + head * 256;
@@ -149,8 +159,22 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
         for (int p = 0; p < 4; ++p)
             rk[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsk, (uint32_t)(g0 + srow + 16 * p) * (uint32_t)ROW_B + sc * 16u, 0, 0));
     };
+    // V^T rows (inference layout) through a buffer descriptor as well: per-thread 32-bit offsets fixed for the whole kernel,
+    // the tile position as the scalar offset - no 64-bit address arithmetic in the loop (every V^T read is in bounds: ldv pads M)
+    const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(Vh), 0, (int)((size_t)(2 * kDim - head * kHeadDim) * a.ldv * 2), 0x00020000);
+    uint32_t voff_v[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        voff_v[p] = (uint32_t)(srow + 16 * p) * (uint32_t)a.ldv * 2u + (uint32_t)(sc & 7) * 16u + (sc < 8 ? 0u : (uint32_t)kDim * (uint32_t)a.ldv * 2u);
     auto gload_v = [&](int i) {
         const int g0 = (gt0 + i) * KT;
+        if constexpr (!TRAIN && ATTN_V_BUFFER) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                rv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, voff_v[p], (uint32_t)g0 * 2u, 0));
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const char* vsrc = TRAIN ? Vh + ((size_t)(srow + 16 * p) * a.ldv + g0) * 4 + sc * 16      // two 32-frame blocks of hi | lo
@@ -391,9 +415,20 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
 #if ATTN_PIN_STAGING
         __builtin_amdgcn_sched_barrier(0);            // keep the global loads at the head (hipcc sinks them to the barrier)
 #endif
+#if ATTN_SETPRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
         qk(i + 1, n0, n1);
         softmax(c0, c1);
+#if ATTN_SETPRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#elif ATTN_SETPRIO == 1
+        __builtin_amdgcn_s_setprio(1);
+#endif
         pv(i, c0, c1);
+#if ATTN_SETPRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();
     };
     qk(0, sa0, sa1);

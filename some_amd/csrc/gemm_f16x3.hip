@@ -317,6 +317,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     const int m0 = a.m_begin + m_tile * BM, n0 = n_tile * BN;
     if (m0 >= a.M || n0 >= g.N) return;
 
+    // (the wavefront index is left lane-derived: forcing it into an SGPR with readfirstlane removes the 64 one-trip waterfall
+    // loops hipcc wraps around the row-per-lane epilogue's stores, cdna guide T20 - measured: no gain, 1.0002 vs 1.0005 ms, AND
+    // run-to-run different results at 32 x 30 s; profiles/r02_experiments.md)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & 31, kg = lane >> 5;

@@ -22,6 +22,21 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+#ifndef LN_ROWS
+#define LN_ROWS 2               // rows per wavefront and iteration (independent load -> reduce -> store chains in flight)
+#endif
+#ifndef LN_NT
+#define LN_NT 0                 // 1: non-temporal stores (the output is re-read by a GEMM after 0.7 GB of other traffic)
+#endif
+template <typename T>
+__device__ __forceinline__ void ln_store(T* p, T v) {
+#if LN_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave_in_grid = (blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -34,38 +49,47 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.gamma[g] + 256 + lane * 4);
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.beta[g] + lane * 4);
     const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.beta[g] + 256 + lane * 4);
-    for (int m = wave_in_grid; m < a.M; m += n_waves) {
-        const float* row = x + (size_t)m * kDim;
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(row + lane * 4);
-        f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 256 + lane * 4);
-        float s = (v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3]);
-        const float mean = wave_sum(s) * (1.0f / kDim);
-        v0 -= mean;
-        v1 -= mean;
-        float q = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]) +
-                  (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
-        const float var = wave_sum(q) * (1.0f / kDim);
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
-        f32x4 o0 = v0 * rstd * g0 + b0;
-        f32x4 o1 = v1 * rstd * g1 + b1;
-        if (y != nullptr) {
-            float* out = y + (size_t)m * kDim;
-            *reinterpret_cast<f32x4*>(out + lane * 4) = o0;
-            *reinterpret_cast<f32x4*>(out + 256 + lane * 4) = o1;
-        }
-        if (ys != nullptr) {     // SPLIT32: k-block = 8 lanes; 4 hi halves (8 B) + 4 lo halves (8 B) per lane
-            half4 h0, l0, h1, l1;
+    for (int mb = wave_in_grid * LN_ROWS; mb < a.M; mb += n_waves * LN_ROWS) {
+        f32x4 v0[LN_ROWS], v1[LN_ROWS];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                half_t h, l;
-                split_f16(o0[i], h, l); h0[i] = h; l0[i] = l;
-                split_f16(o1[i], h, l); h1[i] = h; l1[i] = l;
+        for (int u = 0; u < LN_ROWS; ++u) {
+            const float* row = x + (size_t)min(mb + u, a.M - 1) * kDim;
+            v0[u] = *reinterpret_cast<const f32x4*>(row + lane * 4);
+            v1[u] = *reinterpret_cast<const f32x4*>(row + 256 + lane * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < LN_ROWS; ++u) {
+            const int m = mb + u;
+            float s = (v0[u][0] + v0[u][1]) + (v0[u][2] + v0[u][3]) + (v1[u][0] + v1[u][1]) + (v1[u][2] + v1[u][3]);
+            const float mean = wave_sum(s) * (1.0f / kDim);
+            v0[u] -= mean;
+            v1[u] -= mean;
+            float q = (v0[u][0] * v0[u][0] + v0[u][1] * v0[u][1]) + (v0[u][2] * v0[u][2] + v0[u][3] * v0[u][3]) +
+                      (v1[u][0] * v1[u][0] + v1[u][1] * v1[u][1]) + (v1[u][2] * v1[u][2] + v1[u][3] * v1[u][3]);
+            const float var = wave_sum(q) * (1.0f / kDim);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            const f32x4 o0 = v0[u] * rstd * g0 + b0;
+            const f32x4 o1 = v1[u] * rstd * g1 + b1;
+            if (LN_ROWS > 1 && m >= a.M) break;      // wave-uniform
+            if (y != nullptr) {
+                float* out = y + (size_t)m * kDim;
+                ln_store(reinterpret_cast<f32x4*>(out + lane * 4), o0);
+                ln_store(reinterpret_cast<f32x4*>(out + 256 + lane * 4), o1);
             }
-            char* row = ys + (size_t)m * kDim * 4 + (lane >> 3) * 128 + (lane & 7) * 8;
-            *reinterpret_cast<half4*>(row) = h0;
-            *reinterpret_cast<half4*>(row + 64) = l0;
-            *reinterpret_cast<half4*>(row + 1024) = h1;
-            *reinterpret_cast<half4*>(row + 1024 + 64) = l1;
+            if (ys != nullptr) {     // SPLIT32: k-block = 8 lanes; 4 hi halves (8 B) + 4 lo halves (8 B) per lane
+                half4 h0, l0, h1, l1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    half_t h, l;
+                    split_f16(o0[i], h, l); h0[i] = h; l0[i] = l;
+                    split_f16(o1[i], h, l); h1[i] = h; l1[i] = l;
+                }
+                char* row = ys + (size_t)m * kDim * 4 + (lane >> 3) * 128 + (lane & 7) * 8;
+                ln_store(reinterpret_cast<half4*>(row), h0);
+                ln_store(reinterpret_cast<half4*>(row + 64), l0);
+                ln_store(reinterpret_cast<half4*>(row + 1024), h1);
+                ln_store(reinterpret_cast<half4*>(row + 1024 + 64), l1);
+            }
         }
     }
 }

@@ -748,13 +748,13 @@ def test_dual_stream_forward_is_bit_identical_to_grouped_launches(monkeypatch):
     assert torch.equal(outs['0'][0], outs['1'][0]) and torch.equal(outs['0'][1], outs['1'][1])
 
 
-def test_forward_is_capturable_in_a_hip_graph(engine_for):
+def test_forward_is_capturable_in_a_hip_graph(engines):
     """include/some_amd.h: every entry point only enqueues on the caller's stream - so log-mel + forward (dual-stream fork /
     join included, once the helper stream exists) can be captured into a hipGraph and replayed on new audio; outputs are
     bit-identical to eager launches."""
     from some_amd import _lib
     from some_amd.engine import ClipBatch
-    eng = engine_for('midi_conformer', 2, 41)
+    eng = engines("midi_conformer", 2, 41)
     clips = [synth.synth_clip(70 + i, 1.7) for i in range(3)]
     batch = ClipBatch.from_sample_counts([len(c) for c in clips], eng.hop, 'cuda')
     audio = torch.from_numpy(np.concatenate(clips)).cuda()
