@@ -223,6 +223,22 @@ size_t some_train_gemm_splitk_bytes(const SomeHandle* h, int32_t M, int32_t N, i
 int some_train_gemm_splitk(SomeHandle* h, const float* A_split_dev, int32_t lda, const float* W_split_dev, float* C_dev,
                            int32_t M, int32_t N, int32_t K, int32_t hi_only, void* partial_dev, size_t partial_bytes,
                            void* stream);
+/* Mixed-precision GEMM on fp32 operands (the reference's autocast matmuls under pl_trainer_precision 'bf16' / '16-mixed',
+ * configs/midi_conformer.yaml:35, training/me_task.py:79-111 through Lightning):
+ *     C[M, N] = Aop[M, K] Bop[N, K]^T (+ bias[N]),   Aop / Bop = the operand rounded to bf16 (operand = 2) or f16 (1),
+ * fp32 accumulation.  The rounding - and, where needed, the transposition - happens in the kernel's staging path, so no
+ * split / transposed copy of an activation is ever written:
+ *     ta = 0: A_dev is [M, lda] (contraction index contiguous);   ta = 1: A_dev is [K, lda] (A stored transposed)
+ *     tb = 0: B_dev is [N, ldb];                                   tb = 1: B_dev is [K, ldb]
+ * (ta, tb) = (0, 0) nn.Linear forward, (0, 1) its data gradient dX = dY W, (1, 1) its weight gradient dW = dY^T X - then the
+ * contraction runs over all frames and is cut into slices across workgroups, summed in slice order (deterministic) through
+ * partial_dev (some_train_gemm16_bytes), and sum_col >= 0 writes the fp32 column sums of A_dev (the bias gradient dY^T 1)
+ * into column sum_col of C (ldc > sum_col >= N).  Needs lda % 4 == ldb % 4 == 0; K % 32 == 0 unless ta = tb = 1; M even
+ * when ta; N % 4 == 0 when tb.  (1, 0) is not provided. */
+size_t some_train_gemm16_bytes(const SomeHandle* h, int32_t M, int32_t N, int32_t K, int32_t ldc);
+int some_train_gemm16(SomeHandle* h, const float* A_dev, int32_t lda, int32_t ta, const float* B_dev, int32_t ldb, int32_t tb,
+                      const float* bias_dev, float* C_dev, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t operand,
+                      int32_t sum_col, void* partial_dev, size_t partial_bytes, void* stream);
 /* out[n, m] = in[m, n] for m < M, 0 for M <= m < ld_out (the zero padding makes ld_out a valid contraction length).
  * split_out = 1: rows are written in SPLIT32 format (ready as a split-f16 GEMM operand; ld_out % 32 == 0);
  * split_out = 2: the same slots with bf16 hi halves (SOME_OPERAND_BF16). */

@@ -13,6 +13,8 @@
 // rows (16-byte global loads -> registers -> ds_write_b128 into [rows][36 dwords], conflict-free ds_read_b128);
 // neither operand is converted in this kernel: weights are split once at pack time, activations by the
 // epilogue of whichever kernel produced them (LayerNorm, SiLU epilogue below, attention, dwconv).
+#include <type_traits>
+
 #include "internal.h"
 #include "split.h"
 
@@ -722,6 +724,239 @@ hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+
+// ---- one-product GEMM on fp32 operands, converted on the way into LDS (mixed-precision training) --------------------
+//   C [M, N] = Aop [M, K] * Bop [N, K]^T  (+ bias),  Aop / Bop = bf16 (or f16) roundings of fp32 arrays stored EITHER way round:
+//     TA = false: A is [M, lda], the contraction index contiguous (activations in the forward, dY in the data gradient)
+//     TA = true : A is [K, lda], the OUTPUT-row index contiguous (dY in dW = dY^T X: the contraction runs over frames)
+//     TB likewise for B ([N, ldb] / [K, ldb]: W in the forward; W in dX = dY W and X in dW).
+// The SPLIT32 kernels above need their operands split (hi | lo planes) and - for a contraction over rows - transposed by
+// separate passes: 229 split + 233 transpose launches, 18 % of a bf16 training step.  Here the staging path does both: fp32
+// rows are loaded as they lie (coalesced along whichever index is contiguous), rounded with v_cvt_pk_bf16_f32 /
+// v_cvt_pk_f16_f32 in registers and written to LDS as [row][32 k] halves - an 8 (k) x 2 / 4 (rows) register block of a
+// row-contiguous operand leaves as one 16-byte LDS write per row, which IS the transposition.
+// 128 x 256 tile, 4 waves (2 x 2, each 64 x 128), k-blocks of 32, 2 LDS stages of 384 rows x 80 B = 60 KB: TWO workgroups per
+// CU, so one's epilogue (fp32 output rows: the HBM-heavy part of these GEMMs) runs under the other's products.
+// TA && TB (weight gradient): split-K over blockIdx.z into partial planes (ordered reduction afterwards), and the column
+// sums of A's stored array - the bias gradient - accumulated in fp32 from the staging registers into C column `sum_col`.
+struct Gemm16Args {
+    const float* A; const float* B; const float* bias; float* C;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int n_tiles;
+    int k_slices; size_t slice_stride;
+    int sum_col;               // TA && TB only; -1 = none
+};
+constexpr int LD16 = 20;       // LDS row in dwords: 32 halves (16 dwords) + 4 pad - 16 consecutive rows cover all 64 banks once
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+template <bool BF16>
+__device__ __forceinline__ uint32_t cvt2(float a, float b) {
+    const f32x2 v = {a, b};
+    if constexpr (BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, half2_t));
+}
+
+template <bool TA, bool TB, bool BF16>
+__global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
+    constexpr int WAVES_M = 2, WAVES_N = 2, TM = 2, TN = 4;
+    constexpr int BM = 128, BN = 256, NT = 256;
+    constexpr int STAGE = (BM + BN) * LD16;              // dwords
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint32_t* L = reinterpret_cast<uint32_t*>(lds);
+
+    const int n_tiles = a.n_tiles;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int m_tile = (j / n_tiles) * 8 + xcd, n_tile = j % n_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    if (m0 >= a.M || n0 >= a.N) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, kg = lane >> 5;
+
+    int nk = (a.K + 31) >> 5, kt0 = 0;
+    float* Cout = a.C;
+    if (a.k_slices > 1) {
+        const int per = (nk + a.k_slices - 1) / a.k_slices;
+        kt0 = blockIdx.z * per;
+        nk = min(nk, kt0 + per) - kt0;
+        Cout += (size_t)blockIdx.z * a.slice_stride;
+    }
+
+    // ---- staging roles
+    // contraction-contiguous operand (R rows of the tile): thread -> row tid / 8 + 32 p, 16-byte chunk tid % 8 of the 128-byte k-block
+    // row-contiguous operand ([32 k][R]): wavefront kq = tid / 64 owns k rows 8 kq .. 8 kq + 7, lane c owns R / 64 adjacent columns
+    constexpr int NA = TA ? 8 : BM / 32, NB = TB ? 8 : BN / 32;     // loads per thread and k-block
+    constexpr int WA = TA ? BM / 64 : 4, WB = TB ? BN / 64 : 4;     // floats per load
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(a.A, (size_t)(TA ? a.K : a.M) * a.lda * 4);
+    const __amdgpu_buffer_rsrc_t rsb = make_rsrc(a.B, (size_t)(TB ? a.K : a.N) * a.ldb * 4);
+    const int srow = tid >> 3, scol = tid & 7;
+    uint32_t va[NA], vb[NB];                                         // byte offsets of k-block 0 (row-contiguous: of k row 8 kq + r)
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+        if constexpr (TA) {
+            const int col = m0 + WA * lane;
+            va[p] = col < a.M ? (uint32_t)(kt0 * 32 + 8 * wave + p) * (uint32_t)a.lda * 4u + (uint32_t)col * 4u : kOob;
+        } else {
+            va[p] = (uint32_t)(m0 + srow + 32 * p) * (uint32_t)a.lda * 4u + (uint32_t)kt0 * 128u + scol * 16u;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        if constexpr (TB) {
+            const int col = n0 + WB * lane;
+            vb[p] = col < a.N ? (uint32_t)(kt0 * 32 + 8 * wave + p) * (uint32_t)a.ldb * 4u + (uint32_t)col * 4u : kOob;
+        } else {
+            vb[p] = (uint32_t)(n0 + srow + 32 * p) * (uint32_t)a.ldb * 4u + (uint32_t)kt0 * 128u + scol * 16u;
+        }
+    }
+    const uint32_t stepa = TA ? 32u * (uint32_t)a.lda * 4u : 128u, stepb = TB ? 32u * (uint32_t)a.ldb * 4u : 128u;
+    float ra[NA][WA], rb[NB][WB];
+    auto ldw = [](__amdgpu_buffer_rsrc_t r, uint32_t off, float* dst, auto width) {
+        constexpr int W = decltype(width)::value;
+        if constexpr (W == 4) {
+            const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+            dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3];
+        } else {
+            const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+            dst[0] = t[0]; dst[1] = t[1];
+        }
+    };
+    auto gload = [&]() {                  // the next k-block (offsets advance with every call)
+#pragma unroll
+        for (int p = 0; p < NA; ++p) { ldw(rsa, va[p], ra[p], std::integral_constant<int, WA>{}); if (va[p] < kOob) va[p] += stepa; }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) { ldw(rsb, vb[p], rb[p], std::integral_constant<int, WB>{}); if (vb[p] < kOob) vb[p] += stepb; }
+    };
+    float csum[TA ? WA : 1] = {};
+    auto lstore = [&](int buf) {
+        uint32_t* base = L + buf * STAGE;
+        if constexpr (TA) {
+#pragma unroll
+            for (int c = 0; c < WA; ++c) {
+                if constexpr (TB) csum[c] += ((ra[0][c] + ra[1][c]) + (ra[2][c] + ra[3][c])) + ((ra[4][c] + ra[5][c]) + (ra[6][c] + ra[7][c]));
+                const u32x4 w = {cvt2<BF16>(ra[0][c], ra[1][c]), cvt2<BF16>(ra[2][c], ra[3][c]), cvt2<BF16>(ra[4][c], ra[5][c]), cvt2<BF16>(ra[6][c], ra[7][c])};
+                *reinterpret_cast<u32x4*>(base + (WA * lane + c) * LD16 + wave * 4) = w;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NA; ++p) {
+                const u32x2 w = {cvt2<BF16>(ra[p][0], ra[p][1]), cvt2<BF16>(ra[p][2], ra[p][3])};
+                *reinterpret_cast<u32x2*>(base + (srow + 32 * p) * LD16 + scol * 2) = w;
+            }
+        }
+        if constexpr (TB) {
+#pragma unroll
+            for (int c = 0; c < WB; ++c) {
+                const u32x4 w = {cvt2<BF16>(rb[0][c], rb[1][c]), cvt2<BF16>(rb[2][c], rb[3][c]), cvt2<BF16>(rb[4][c], rb[5][c]), cvt2<BF16>(rb[6][c], rb[7][c])};
+                *reinterpret_cast<u32x4*>(base + (BM + WB * lane + c) * LD16 + wave * 4) = w;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                const u32x2 w = {cvt2<BF16>(rb[p][0], rb[p][1]), cvt2<BF16>(rb[p][2], rb[p][3])};
+                *reinterpret_cast<u32x2*>(base + (BM + srow + 32 * p) * LD16 + scol * 2) = w;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+
+    const int a_off = (wm * TM * 32 + l31) * LD16 + kg * 4;
+    const int w_off = (BM + wn * TN * 32 + l31) * LD16 + kg * 4;
+    auto compute = [&](int buf) {
+        const uint32_t* As = L + buf * STAGE + a_off;
+        const uint32_t* Ws = L + buf * STAGE + w_off;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                    // two k = 16 slabs per k-block
+            half8 ah[TM], bh[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const half8*>(As + i * 32 * LD16 + s * 8);
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) bh[jn] = *reinterpret_cast<const half8*>(Ws + jn * 32 * LD16 + s * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mfma_hi<BF16>(ah[i], bh[jn], acc[i][jn]);
+        }
+    };
+
+    // same one-register-set pipeline as hgemm3_kernel: the registers hold k-block kt + 1 at the top of iteration kt
+    gload();
+    lstore(0);
+    if (nk > 1) gload();
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+        lstore((kt & 1) ^ 1);
+        gload();
+        __builtin_amdgcn_sched_barrier(0);
+        compute(kt & 1);
+        __syncthreads();
+    }
+    if (kt + 1 < nk) {
+        lstore((kt & 1) ^ 1);
+        compute(kt & 1);
+        __syncthreads();
+        ++kt;
+    }
+    compute(kt & 1);
+
+    // ---- epilogue: the column-per-lane fp32 stores of the split kernels (whole 128-byte row segments per instruction)
+    GemmArgs ga{};
+    ga.M = a.M; ga.ldc = a.ldc; ga.ldr = a.ldc; ga.alpha = 1.f;
+    GemmGroup g{};
+    g.C = Cout; g.bias = a.bias; g.N = a.N;
+    const bool full = m0 + BM <= a.M && n0 + BN <= a.N;
+    if (a.bias != nullptr) {
+        if (full) epilogue<WAVES_M, WAVES_N, TM, TN, EPI_BIAS, false, true>(ga, g, acc, m0, n0, wm, wn, lane);
+        else epilogue<WAVES_M, WAVES_N, TM, TN, EPI_BIAS, false, false>(ga, g, acc, m0, n0, wm, wn, lane);
+    } else {
+        if (full) epilogue<WAVES_M, WAVES_N, TM, TN, EPI_NONE, false, true>(ga, g, acc, m0, n0, wm, wn, lane);
+        else epilogue<WAVES_M, WAVES_N, TM, TN, EPI_NONE, false, false>(ga, g, acc, m0, n0, wm, wn, lane);
+    }
+    if constexpr (TA && TB) {
+        // bias gradient: sum over this slice's contraction rows of A's stored array, per output row; wavefront w holds the rows
+        // 8 w .. 8 w + 7 of every k-block - combined in wavefront order (deterministic) by the first column tile
+        if (a.sum_col >= 0 && n_tile == 0) {
+            __syncthreads();
+            float* red = lds;                            // [4][BM]
+#pragma unroll
+            for (int c = 0; c < WA; ++c) red[wave * BM + WA * lane + c] = csum[c];
+            __syncthreads();
+            if (tid < BM && m0 + tid < a.M)
+                Cout[(size_t)(m0 + tid) * a.ldc + a.sum_col] = ((red[tid] + red[BM + tid]) + red[2 * BM + tid]) + red[3 * BM + tid];
+        }
+    }
+}
+
+template <bool TA, bool TB, bool BF16>
+hipError_t launch_gemm16_cfg(const Gemm16Args& a_in, hipStream_t s) {
+    constexpr int BM = 128, BN = 256;
+    constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LD16 * sizeof(float);
+    static bool attr_set = false;
+    auto kern = &gemm16_kernel<TA, TB, BF16>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    Gemm16Args a = a_in;
+    const int m_tiles = (a.M + BM - 1) / BM;
+    a.n_tiles = (a.N + BN - 1) / BN;
+    dim3 grid((unsigned)((m_tiles + 7) / 8 * 8 * a.n_tiles), 1, (unsigned)(a.k_slices > 1 ? a.k_slices : 1));
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
 template <int EPI, bool OUT_SPLIT>
 hipError_t launch_epi(const GemmArgs& a, int tile, hipStream_t s) {
     constexpr bool kCanTr = EPI == EPI_BIAS_SILU && OUT_SPLIT;
@@ -779,6 +1014,24 @@ hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a_in, int tile, hipStr
     a.m_begin = 0;
     const bool small = tile == 0;                     // 128 x 128 (two workgroups per CU) for small grids, else 256 x 256
     return bf16 ? launch_x1<true>(epi, a, small, s) : launch_x1<false>(epi, a, small, s);
+}
+
+// fp32 operands converted on the fly (gemm16_kernel): C [M, N] = Aop [M, K] Bop [N, K]^T (+ bias); ta / tb: the operand is stored
+// with the contraction index as its ROW index ([K, ld]).  Contraction-contiguous operands need K % 32 == 0 and ld % 4 == 0,
+// row-contiguous ones ld % 4 == 0 and an even (A) / multiple-of-4 (B) count of valid columns.  slices > 1: partial planes at
+// C + z * slice_stride (ta && tb only).
+hipError_t launch_gemm16(const float* A, int lda, int ta, const float* B, int ldb, int tb, const float* bias, float* C, int ldc,
+                         int M, int N, int K, int bf16, int slices, size_t slice_stride, int sum_col, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0) return hipSuccess;
+    if ((lda & 3) || (ldb & 3) || (!(ta && tb) && (K & 31)) || (ta && (M & 1)) || (tb && (N & 3))) return hipErrorInvalidValue;
+    if ((!ta || !tb) && (slices > 1 || sum_col >= 0)) return hipErrorInvalidValue;
+    if (ta && !tb) return hipErrorInvalidValue;
+    Gemm16Args a{};
+    a.A = A; a.B = B; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.k_slices = slices; a.slice_stride = slice_stride; a.sum_col = sum_col;
+    if (!ta && !tb) return bf16 ? launch_gemm16_cfg<false, false, true>(a, s) : launch_gemm16_cfg<false, false, false>(a, s);
+    if (!ta && tb) return bf16 ? launch_gemm16_cfg<false, true, true>(a, s) : launch_gemm16_cfg<false, true, false>(a, s);
+    return bf16 ? launch_gemm16_cfg<true, true, true>(a, s) : launch_gemm16_cfg<true, true, false>(a, s);
 }
 
 hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a_in, bool out_split, int tile, hipStream_t s) {

@@ -4,6 +4,7 @@ Activations are packed [M, C] fp32 row-major tensors on the GPU (M = B * T_max f
 PyTorch only records the tape and owns the memory; forward and backward math run in libsome_amd.so.  Each function
 names the reference op it stands for."""
 import ctypes as C
+import os
 from typing import Optional
 
 import numpy as np
@@ -32,6 +33,9 @@ class TrainOps:
         self._hi = 0                                        # GEMM flag bits of the one-product modes (set_mixed_precision)
         self._hi_mode = 0                                   # the `hi_only` argument: 0 three products, 1 f16, 2 bf16
         self.operand = 'f16x2'
+        # one-product modes: GEMMs on the fp32 arrays as they lie, rounded (and transposed) in the kernel's staging path
+        # (some_train_gemm16) instead of split_rows / transpose passes + the SPLIT32 kernels; SOME_AMD_TRAIN_GEMM16=0: A/B runs
+        self.gemm16 = os.environ.get('SOME_AMD_TRAIN_GEMM16', '1') != '0'
 
     def set_mixed_precision(self, on: bool, operand: str = 'f16'):
         """Mixed-precision training (the reference's pl_trainer_precision '16-mixed' / 'bf16'): the matrix products read one
@@ -80,6 +84,9 @@ class TrainOps:
     def _use_split(self, M: int, N: int, K: int) -> bool:
         return self.gemm_precision == 'f16x3' and K % 32 == 0 and N >= 64 and M >= 64
 
+    def _use16(self, M: int, N: int, K: int) -> bool:
+        return bool(self._hi_mode) and self.gemm16 and self._use_split(M, N, K) and N % 4 == 0
+
     def gemm(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         """a [M, K] @ w[N, K]^T (+ bias).  ``gemm_precision`` 'f16x3' (default): both operands are split into f16
         hi + lo halves and contracted with three f16 MFMA products, fp32 accumulation (gemm_f16x3.hip; fp32-equivalent,
@@ -92,6 +99,10 @@ class TrainOps:
         if M == 0:
             return out
         epi = _lib.EPI_BIAS if bias is not None else _lib.EPI_NONE
+        if self._use16(M, N, K):
+            self.check(self.lib.some_train_gemm16(self.h, _p(a), K, 0, _p(w), K, 0, _p(bias), _p(out), N, M, N, K, self._hi_mode, -1, None, 0,
+                                                  self.stream()))
+            return out
         if self._use_split(M, N, K):
             a3 = self.split_rows(a)
             w3 = self.split_rows(w)
@@ -111,6 +122,11 @@ class TrainOps:
         """dy [M, N] @ w [N, K]: the data gradient of ``linear`` (the weight is transposed - and split - on the fly)."""
         M, N = dy.shape
         K = w.shape[1]
+        if self._use16(M, K, N):                                        # w [N, K] is the contraction-major operand as it lies
+            out = self.new(M, K)
+            self.check(self.lib.some_train_gemm16(self.h, _p(dy), N, 0, _p(w), K, 1, None, _p(out), K, M, K, N, self._hi_mode, -1, None, 0,
+                                                  self.stream()))
+            return out
         if self._use_split(M, K, N):
             wt3 = self.transpose(w, pad_to=32, split=True)
             a3 = self.split_rows(dy)
@@ -126,6 +142,19 @@ class TrainOps:
         SPLIT32 form in f16x3 mode; the long contraction is cut across workgroups (split-K)."""
         M, N = dy.shape
         K = x.shape[1]
+        if self._hi_mode and self.gemm16 and self.gemm_precision == 'f16x3' and N >= 32 and N % 2 == 0 and K % 4 == 0 and K >= 32:
+            # dy [M, N] and x [M, K] are both contraction-major as they lie; the bias gradient is the fp32 column sum of dy,
+            # accumulated in the kernel's staging registers into column K of the output
+            ldc = K + (4 if with_bias else 0)
+            out = self.new(N, ldc)
+            need = int(self.lib.some_train_gemm16_bytes(self.h, N, K, M, ldc))
+            if self._partial is None or self._partial.numel() < need:
+                self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.check(self.lib.some_train_gemm16(self.h, _p(dy), N, 1, _p(x), K, 1, None, _p(out), ldc, N, K, M, self._hi_mode,
+                                                  K if with_bias else -1, _p(self._partial), self._partial.numel(), self.stream()))
+            if not with_bias:
+                return out, None
+            return out[:, :K].contiguous(), out[:, K].contiguous()
         Mp = (M + 31) // 32 * 32
         extra = 4 if with_bias else 0                                   # ones row + 3 zero rows keep (K + extra) % 4 == 0
         use3 = self.gemm_precision == 'f16x3' and N >= 32 and K % 4 == 0

@@ -195,3 +195,98 @@ def test_attention_fwd_bwd(ops, lens, precision):
         _pair(lambda qkv: ops.attention(qkv, batch), ref, [qkv], tol=3e-5)
     finally:
         ops.attention_precision = ops.gemm_precision
+
+
+# ---- some_train_gemm16: fp32 operands rounded (and transposed) in the staging path ---------------------------------------
+def _round16(t, operand):
+    return (t.bfloat16() if operand == 'bf16' else t.half()).double()
+
+
+@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+@pytest.mark.parametrize('M,K,N,bias', [(300, 512, 2048, True), (128, 32, 256, False), (129, 2048, 512, True), (2584, 512, 1536, False),
+                                         (64, 512, 132, True), (1000, 64, 64, True)])
+def test_gemm16_forward_layout(ops, operand, M, K, N, bias):
+    """(ta, tb) = (0, 0): x [M, K] @ w [N, K]^T + b equals the fp64 product of the 16-bit roundings (products of 16-bit values are
+    exact in fp32, only the accumulation order differs) - and is NOT the fp32 product."""
+    from some_amd.training.ops import _p
+    x, w = _rand(M, K, seed=11).detach() * 3, _rand(N, K, seed=12).detach()
+    b = _rand(N, seed=13).detach() if bias else None
+    out = torch.full((M, N), float('nan'), device='cuda')
+    ops.check(ops.lib.some_train_gemm16(ops.h, _p(x), K, 0, _p(w), K, 0, _p(b), _p(out), N, M, N, K, 2 if operand == 'bf16' else 1, -1, None, 0,
+                                        ops.stream()))
+    want = _round16(x, operand) @ _round16(w, operand).t() + (b.double() if bias else 0)
+    scale = float(want.abs().max())
+    assert float((out.double() - want).abs().max()) < 2e-6 * scale * max(1.0, (K / 512) ** 0.5)
+    if K >= 512:
+        assert float((out.double() - (x.double() @ w.double().t() + (b.double() if bias else 0))).abs().max()) > 1e-4 * scale
+
+
+@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+@pytest.mark.parametrize('M,N,K', [(300, 2048, 512), (129, 512, 2048), (2584, 1536, 512), (70, 64, 132), (257, 128, 516)])
+def test_gemm16_data_gradient_layout(ops, operand, M, N, K):
+    """(0, 1): dx [M, K] = dy [M, N] @ w [N, K] with w read as it lies (its rows are the contraction index)."""
+    from some_amd.training.ops import _p
+    dy, w = _rand(M, N, seed=21).detach(), _rand(N, K, seed=22).detach() * 2
+    out = torch.full((M, K), float('nan'), device='cuda')
+    ops.check(ops.lib.some_train_gemm16(ops.h, _p(dy), N, 0, _p(w), K, 1, None, _p(out), K, M, K, N, 2 if operand == 'bf16' else 1, -1, None, 0,
+                                        ops.stream()))
+    want = _round16(dy, operand) @ _round16(w, operand)
+    assert float((out.double() - want).abs().max()) < 2e-6 * float(want.abs().max()) * max(1.0, (N / 512) ** 0.5)
+
+
+@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+@pytest.mark.parametrize('M,N,K,bias', [(300, 2048, 512, True), (2584 * 2 + 7, 512, 2048, True), (1001, 1536, 512, False), (95, 32, 80, True),
+                                         (20672, 132, 36, True), (31, 512, 512, True)])
+def test_gemm16_weight_gradient_layout(ops, operand, M, N, K, bias):
+    """(1, 1): dW [N, K] = dy [M, N]^T @ x [M, K] over ALL M frames (any M: no padding copies), split across workgroups and
+    summed in slice order; column K of the output = the fp32 column sums of dy (bias gradient), from the unrounded values."""
+    from some_amd.training.ops import _p
+    dy, x = _rand(M, N, seed=31).detach(), _rand(M, K, seed=32).detach() + 0.3
+    ldc = K + (4 if bias else 0)
+    out = torch.full((N, ldc), float('nan'), device='cuda')
+    need = int(ops.lib.some_train_gemm16_bytes(ops.h, N, K, M, ldc))
+    part = torch.empty(need, dtype=torch.uint8, device='cuda')
+    args = (ops.h, _p(dy), N, 1, _p(x), K, 1, None, _p(out), ldc, N, K, M, 2 if operand == 'bf16' else 1, K if bias else -1, _p(part), need, ops.stream())
+    ops.check(ops.lib.some_train_gemm16(*args))
+    want = _round16(dy, operand).t() @ _round16(x, operand)
+    tol = 3e-6 * max(1.0, (M / 512) ** 0.5)
+    assert float((out[:, :K].double() - want).abs().max()) < tol * float(want.abs().max())
+    if bias:
+        db = dy.double().sum(0)
+        assert float((out[:, K].double() - db).abs().max()) < tol * float(db.abs().max() + dy.abs().max())
+    first = out.clone()
+    ops.check(ops.lib.some_train_gemm16(*args))                        # deterministic: no atomics anywhere
+    assert torch.equal(first[:, :K + (1 if bias else 0)], out[:, :K + (1 if bias else 0)])
+
+
+def test_gemm16_argument_checks(ops):
+    from some_amd.training.ops import _p
+    a, b, c = torch.zeros(64, 64, device='cuda'), torch.zeros(64, 64, device='cuda'), torch.zeros(64, 64, device='cuda')
+    bad = [dict(ta=1, tb=0), dict(operand=0), dict(K=48), dict(lda=66), dict(sum_col=64)]
+    for kw in bad:
+        d = dict(lda=64, ta=0, ldb=64, tb=0, ldc=64, M=64, N=64, K=64, operand=2, sum_col=-1)
+        d.update(kw)
+        rc = ops.lib.some_train_gemm16(ops.h, _p(a), d['lda'], d['ta'], _p(b), d['ldb'], d['tb'], None, _p(c), d['ldc'], d['M'], d['N'], d['K'],
+                                       d['operand'], d['sum_col'], None, 0, ops.stream())
+        assert rc != 0, kw
+
+
+@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+def test_mixed_linear_matches_the_split_kernels(ops, operand):
+    """ops.linear in the one-product modes: the fused-staging GEMMs (default) against the split_rows / transpose + SPLIT32 kernels
+    they replace - same operand roundings, so outputs and all three gradients agree to accumulation-order noise."""
+    x, w, b = _rand(700, 512, seed=41), _rand(2048, 512, seed=42, scale=512 ** -0.5), _rand(2048, seed=43)
+    res = {}
+    try:
+        ops.set_mixed_precision(True, operand)
+        for g16 in (True, False):
+            ops.gemm16 = g16
+            xa, wa, ba = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+            y = ops.linear(xa, wa, ba)
+            y.backward(torch.ones_like(y) * 0.01 + y.detach() * 1e-3)
+            res[g16] = (y.detach(), xa.grad, wa.grad, ba.grad)
+    finally:
+        ops.gemm16 = True
+        ops.set_mixed_precision(False)
+    for p, q in zip(res[True], res[False]):
+        _close(p, q, 5e-5 if operand == 'f16' else 3e-4)     # (bias gradient: fp32 sums here, 16-bit-rounded dy through the ones row there)
