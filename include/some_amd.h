@@ -247,6 +247,10 @@ int some_train_transpose(SomeHandle* h, const float* in_dev, int32_t M, int32_t 
 /* out[n] (+)= sum_m x[m, n]: bias gradient of nn.Linear / Conv1d. */
 int some_train_colsum(SomeHandle* h, const float* x_dev, int32_t M, int32_t N, int32_t ld, float* out_dev,
                       int32_t accumulate, void* scratch_dev, size_t scratch_bytes, void* stream);
+/* out[n] = sum_m w[m * ldw] x[m, n], wsum[n] = sum_m w[m * ldw] (same value for every n; may be NULL): weight and bias gradient
+ * of a ONE-output nn.Linear (the bound head `cutheard`, modules/conform/Gconform.py:116) - a column reduction, not a GEMM. */
+int some_train_weighted_colsum(SomeHandle* h, const float* w_dev, int32_t ldw, const float* x_dev, int32_t M, int32_t N, int32_t ld,
+                               float* out_dev, float* wsum_dev, void* scratch_dev, size_t scratch_bytes, void* stream);
 /* nn.LayerNorm(512, eps 1e-5) forward with saved statistics, and its backward (Gconform.py:48-52). */
 int some_train_layernorm_fwd(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
                              float* y_dev, float* mean_dev, float* rstd_dev, int32_t M, void* stream);

@@ -75,6 +75,7 @@ SYMBOLS = {
     'some_train_gemm16': (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
     'some_train_transpose': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
+    'some_train_weighted_colsum': (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_size_t, _P]),
     'some_train_colsum': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P]),
     'some_train_layernorm_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     'some_train_layernorm_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),

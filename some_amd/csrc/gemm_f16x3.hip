@@ -737,13 +737,13 @@ hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
 // row-contiguous operand leaves as one 16-byte LDS write per row, which IS the transposition.
 // 128 x 256 tile, 4 waves (2 x 2, each 64 x 128), k-blocks of 32, 2 LDS stages of 384 rows x 80 B = 60 KB: TWO workgroups per
 // CU, so one's epilogue (fp32 output rows: the HBM-heavy part of these GEMMs) runs under the other's products.
-// TA && TB (weight gradient): split-K over blockIdx.z into partial planes (ordered reduction afterwards), and the column
+// TA && TB (weight gradient): split-K (slices mapped to XCDs) into partial planes (ordered reduction afterwards), and the column
 // sums of A's stored array - the bias gradient - accumulated in fp32 from the staging registers into C column `sum_col`.
 struct Gemm16Args {
     const float* A; const float* B; const float* bias; float* C;
     int M, N, K;
     int lda, ldb, ldc;
-    int n_tiles;
+    int m_tiles, n_tiles;
     int k_slices; size_t slice_stride;
     int sum_col;               // TA && TB only; -1 = none
 };
@@ -769,7 +769,19 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
 
     const int n_tiles = a.n_tiles;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int m_tile = (j / n_tiles) * 8 + xcd, n_tile = j % n_tiles;
+    int m_tile, n_tile, slice = 0;
+    if (a.k_slices > 1) {
+        // weight gradient: ALL tiles of one contraction slice run on ONE XCD (workgroups go round-robin over the XCDs), so the
+        // slice's rows of both operands are fetched into that XCD's L2 once instead of once per XCD
+        const int tiles = a.m_tiles * n_tiles;
+        slice = (j / tiles) * 8 + xcd;
+        if (slice >= a.k_slices) return;
+        m_tile = (j % tiles) / n_tiles;
+        n_tile = j % n_tiles;
+    } else {
+        m_tile = (j / n_tiles) * 8 + xcd;
+        n_tile = j % n_tiles;
+    }
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     if (m0 >= a.M || n0 >= a.N) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -780,9 +792,9 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
     float* Cout = a.C;
     if (a.k_slices > 1) {
         const int per = (nk + a.k_slices - 1) / a.k_slices;
-        kt0 = blockIdx.z * per;
+        kt0 = slice * per;
         nk = min(nk, kt0 + per) - kt0;
-        Cout += (size_t)blockIdx.z * a.slice_stride;
+        Cout += (size_t)slice * a.slice_stride;
     }
 
     // ---- staging roles
@@ -950,9 +962,9 @@ hipError_t launch_gemm16_cfg(const Gemm16Args& a_in, hipStream_t s) {
         attr_set = true;
     }
     Gemm16Args a = a_in;
-    const int m_tiles = (a.M + BM - 1) / BM;
+    a.m_tiles = (a.M + BM - 1) / BM;
     a.n_tiles = (a.N + BN - 1) / BN;
-    dim3 grid((unsigned)((m_tiles + 7) / 8 * 8 * a.n_tiles), 1, (unsigned)(a.k_slices > 1 ? a.k_slices : 1));
+    dim3 grid(a.k_slices > 1 ? (unsigned)((a.k_slices + 7) / 8 * 8 * a.m_tiles * a.n_tiles) : (unsigned)((a.m_tiles + 7) / 8 * 8 * a.n_tiles));
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, s, a);
     return hipGetLastError();
 }

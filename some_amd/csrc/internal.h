@@ -187,6 +187,7 @@ size_t train_dwconv_w_scratch_bytes(int M, int C);
 hipError_t launch_reduce_slices(const float* partial, int slices, size_t n, float* out, hipStream_t s);
 hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, int split_out, hipStream_t s);
 hipError_t launch_colsum(const float* x, int M, int N, int ld, float* out, int accumulate, float* scratch, hipStream_t s);
+hipError_t launch_weighted_colsum(const float* w, int ldw, const float* x, int M, int N, int ld, float* out, float* wsum, float* scratch, hipStream_t s);
 hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, hipStream_t s);
 hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx,
                          float* dgamma, float* dbeta, int accumulate, int M, float* scratch, hipStream_t s);

@@ -126,6 +126,16 @@ int some_train_colsum(SomeHandle* h, const float* x_dev, int32_t M, int32_t N, i
     return SOME_OK;
 }
 
+int some_train_weighted_colsum(SomeHandle* h, const float* w_dev, int32_t ldw, const float* x_dev, int32_t M, int32_t N, int32_t ld,
+                               float* out_dev, float* wsum_dev, void* scratch_dev, size_t scratch_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M >= 0 && N > 0 && ld >= N && ldw >= 1 && out_dev, "some_train_weighted_colsum: bad argument");
+    if (M == 0) return SOME_OK;
+    T_CHECK(h, w_dev && x_dev && scratch_dev && scratch_bytes >= train_col_scratch_bytes(M, N), "some_train_weighted_colsum: scratch too small");
+    T_TRY(h, launch_weighted_colsum(w_dev, ldw, x_dev, M, N, ld, out_dev, wsum_dev, static_cast<float*>(scratch_dev), st(stream)));
+    return SOME_OK;
+}
+
 int some_train_layernorm_fwd(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
                              float* y_dev, float* mean_dev, float* rstd_dev, int32_t M, void* stream) {
     if (!h) return SOME_EINVAL;

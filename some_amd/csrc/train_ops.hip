@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }
 
 // ---- column reductions: partial[p][2][N] over row chunk p, then an ordered final sum -----------------------------
-constexpr int kChunkRows = 512;
+constexpr int kChunkRows = 128;      // 162 row chunks x N / 64 column groups at 8 x 2584 frames: enough workgroups to keep HBM busy (512: 1.9 TB/s)
 
 template <class F>
 __global__ __launch_bounds__(256) void col_partial_kernel(int M, int N, float* __restrict__ partial, F f) {
@@ -95,6 +95,10 @@ __global__ __launch_bounds__(256) void col_final_kernel(const float* __restrict_
 struct ColsumF {
     const float* x; int ld;
     __device__ void operator()(int m, int n, float& s1, float& s2) const { s1 += x[(size_t)m * ld + n]; (void)s2; }
+};
+struct RowWeightedF {   // s1 = sum_m w[m] x[m, n] (weight gradient of a one-output nn.Linear), s2 = sum_m w[m] (its bias gradient)
+    const float* w; int ldw; const float* x; int ld;
+    __device__ void operator()(int m, int n, float& s1, float& s2) const { const float v = w[(size_t)m * ldw]; s1 += v * x[(size_t)m * ld + n]; s2 += v; }
 };
 struct ColStatsF {
     const float* x; int ld;
@@ -236,11 +240,7 @@ __device__ __forceinline__ uint32_t mix32(uint64_t z) {          // splitmix64 f
 }
 
 template <int OP>
-__global__ __launch_bounds__(256) void eltwise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                                                       int64_t n, float alpha, float p, uint64_t seed) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float x = a[i];
+__device__ __forceinline__ float eltwise_one(float x, float bv, int64_t i, float alpha, float p, uint64_t seed) {
     // dropout factor of element i: 0 with probability p, else 1 / (1 - p); a pure function of (seed, i), so the backward
     // regenerates the forward's mask
     float keep = 1.f;
@@ -248,17 +248,35 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const float* __restrict__ 
         const float u = (float)(mix32(seed + (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
         keep = u >= p ? 1.0f / (1.0f - p) : 0.f;
     }
-    float r;
-    if (OP == ELT_SILU_FWD) r = x * sigmoid_(x);
-    else if (OP == ELT_SILU_BWD) { const float u = b[i], s = sigmoid_(u); r = x * s * (1.f + u * (1.f - s)); }       // a = dy, b = pre-activation
-    else if (OP == ELT_SIGMOID_FWD) r = sigmoid_(x);
-    else if (OP == ELT_SIGMOID_BWD) { const float y = b[i]; r = x * y * (1.f - y); }                                 // a = dy, b = sigmoid output
-    else if (OP == ELT_AXPY) r = alpha * x + (b ? b[i] : 0.f);                                                       // alpha a (+ b)
-    else if (OP == ELT_DROPOUT) r = x * keep;
-    else if (OP == ELT_SILU_DROP_FWD) r = x * sigmoid_(x) * keep;                                                    // dropout(silu(a))
-    else if (OP == ELT_SILU_DROP_BWD) { const float u = b[i], s = sigmoid_(u); r = x * keep * s * (1.f + u * (1.f - s)); }
-    else r = alpha * (x * keep) + (b ? b[i] : 0.f);                                                                  // alpha dropout(a) (+ b)
-    out[i] = r;
+    if (OP == ELT_SILU_FWD) return x * sigmoid_(x);
+    if (OP == ELT_SILU_BWD) { const float s = sigmoid_(bv); return x * s * (1.f + bv * (1.f - s)); }       // a = dy, b = pre-activation
+    if (OP == ELT_SIGMOID_FWD) return sigmoid_(x);
+    if (OP == ELT_SIGMOID_BWD) return x * bv * (1.f - bv);                                                // a = dy, b = sigmoid output
+    if (OP == ELT_AXPY) return alpha * x + bv;                                                            // alpha a (+ b)
+    if (OP == ELT_DROPOUT) return x * keep;
+    if (OP == ELT_SILU_DROP_FWD) return x * sigmoid_(x) * keep;                                           // dropout(silu(a))
+    if (OP == ELT_SILU_DROP_BWD) { const float s = sigmoid_(bv); return x * keep * s * (1.f + bv * (1.f - s)); }
+    return alpha * (x * keep) + bv;                                                                       // alpha dropout(a) (+ b)
+}
+
+// four consecutive elements per thread: 16-byte accesses when all three pointers allow them, scalar otherwise and for the tail
+template <int OP>
+__global__ __launch_bounds__(256) void eltwise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                       int64_t n, float alpha, float p, uint64_t seed) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (aligned && i + 4 <= n) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a + i);
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (b) bv = *reinterpret_cast<const f32x4*>(b + i);
+        f32x4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = eltwise_one<OP>(x[k], bv[k], i + k, alpha, p, seed);
+        *reinterpret_cast<f32x4*>(out + i) = r;
+    } else {
+        for (int64_t k = i; k < n && k < i + 4; ++k) out[k] = eltwise_one<OP>(a[k], b ? b[k] : 0.f, k, alpha, p, seed);
+    }
 }
 
 // GLU over the channel halves of [M, 2C]: y = x[:, :C] * sigmoid(x[:, C:])
@@ -507,6 +525,11 @@ hipError_t launch_colsum(const float* x, int M, int N, int ld, float* out, int a
     return col_reduce(M, N, ColsumF{x, ld}, out, nullptr, accumulate, scratch, s);
 }
 
+hipError_t launch_weighted_colsum(const float* w, int ldw, const float* x, int M, int N, int ld, float* out, float* wsum, float* scratch, hipStream_t s) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    return col_reduce(M, N, RowWeightedF{w, ldw, x, ld}, out, wsum, 0, scratch, s);
+}
+
 hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, hipStream_t s) {
     if (M <= 0) return hipSuccess;
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, g, b, y, mean, rstd, M);
@@ -545,7 +568,7 @@ hipError_t launch_bn_bwd(const float* dy, const float* x, const float* g, const 
 
 hipError_t launch_eltwise(int op, const float* a, const float* b, float* out, int64_t n, float alpha, float p, uint64_t seed, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((n + 255) / 256));
+    const dim3 grid((unsigned)((n + 1023) / 1024));
 #define ELT_CASE(OP) case OP: hipLaunchKernelGGL(eltwise_kernel<OP>, grid, dim3(256), 0, s, a, b, out, n, alpha, p, seed); break;
     switch (op) {
         ELT_CASE(ELT_SILU_FWD) ELT_CASE(ELT_SILU_BWD) ELT_CASE(ELT_SIGMOID_FWD) ELT_CASE(ELT_SIGMOID_BWD) ELT_CASE(ELT_AXPY)

@@ -142,6 +142,11 @@ class TrainOps:
         SPLIT32 form in f16x3 mode; the long contraction is cut across workgroups (split-K)."""
         M, N = dy.shape
         K = x.shape[1]
+        if N == 1:                                                      # one output (the bound head): a weighted column sum of x
+            out, ws = self.new(1, K), self.new(K)
+            sc = self.scratch(M, K)
+            self.check(self.lib.some_train_weighted_colsum(self.h, _p(dy), 1, _p(x), M, K, K, _p(out), _p(ws), _p(sc), sc.numel(), self.stream()))
+            return out, (ws[:1].clone() if with_bias else None)
         if self._hi_mode and self.gemm16 and self.gemm_precision == 'f16x3' and N >= 32 and N % 2 == 0 and K % 4 == 0 and K >= 32:
             # dy [M, N] and x [M, K] are both contraction-major as they lie; the bias gradient is the fp32 column sum of dy,
             # accumulated in the kernel's staging registers into column K of the output
