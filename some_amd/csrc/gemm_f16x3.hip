@@ -725,18 +725,21 @@ hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
 }
 
 
-// ---- one-product GEMM on fp32 operands, converted on the way into LDS (mixed-precision training) --------------------
-//   C [M, N] = Aop [M, K] * Bop [N, K]^T  (+ bias),  Aop / Bop = bf16 (or f16) roundings of fp32 arrays stored EITHER way round:
+// ---- GEMMs on fp32 operands, converted on the way into LDS (training) --------------------------------------------------
+//   C [M, N] = Aop [M, K] * Bop [N, K]^T  (+ bias),  Aop / Bop = fp32 arrays stored EITHER way round:
 //     TA = false: A is [M, lda], the contraction index contiguous (activations in the forward, dY in the data gradient)
 //     TA = true : A is [K, lda], the OUTPUT-row index contiguous (dY in dW = dY^T X: the contraction runs over frames)
 //     TB likewise for B ([N, ldb] / [K, ldb]: W in the forward; W in dX = dY W and X in dW).
+// MODE 1 / 2: one product on the f16 / bf16 roundings (mixed-precision training); MODE 3: the fp32-equivalent 3-term split
+// (x = hi + lo, ah bh + ah bl + al bh) of the kernels above.
 // The SPLIT32 kernels above need their operands split (hi | lo planes) and - for a contraction over rows - transposed by
-// separate passes: 229 split + 233 transpose launches, 18 % of a bf16 training step.  Here the staging path does both: fp32
-// rows are loaded as they lie (coalesced along whichever index is contiguous), rounded with v_cvt_pk_bf16_f32 /
-// v_cvt_pk_f16_f32 in registers and written to LDS as [row][32 k] halves - an 8 (k) x 2 / 4 (rows) register block of a
-// row-contiguous operand leaves as one 16-byte LDS write per row, which IS the transposition.
-// 128 x 256 tile, 4 waves (2 x 2, each 64 x 128), k-blocks of 32, 2 LDS stages of 384 rows x 80 B = 60 KB: TWO workgroups per
-// CU, so one's epilogue (fp32 output rows: the HBM-heavy part of these GEMMs) runs under the other's products.
+// separate passes: 229 split + 233 transpose launches, 14 - 18 % of a training step.  Here the staging path does both: fp32
+// rows are loaded as they lie (coalesced along whichever index is contiguous), rounded / split in registers
+// (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32) and written to LDS as [row][32 k] halves - an 8 (k) x 2 / 4 (rows) register block of
+// a row-contiguous operand leaves as one 16-byte LDS write per row, which IS the transposition.
+// 4 waves (2 x 2), k-blocks of 32, TWO workgroups per CU, so one's epilogue (fp32 output rows: the HBM-heavy part of these
+// GEMMs) runs under the other's products: 128 x 256 tile with 80-byte LDS rows (60 KB) in the one-product modes, 128 x 128
+// with the [32 hi | 32 lo] 144-byte rows (72 KB) in the split mode.
 // TA && TB (weight gradient): split-K (slices mapped to XCDs) into partial planes (ordered reduction afterwards), and the column
 // sums of A's stored array - the bias gradient - accumulated in fp32 from the staging registers into C column `sum_col`.
 struct Gemm16Args {
@@ -747,23 +750,36 @@ struct Gemm16Args {
     int k_slices; size_t slice_stride;
     int sum_col;               // TA && TB only; -1 = none
 };
-constexpr int LD16 = 20;       // LDS row in dwords: 32 halves (16 dwords) + 4 pad - 16 consecutive rows cover all 64 banks once
+constexpr int LD16 = 20;       // one-product LDS row in dwords: 32 halves (16 dwords) + 4 pad - 16 consecutive rows cover all 64 banks once
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
-template <bool BF16>
-__device__ __forceinline__ uint32_t cvt2(float a, float b) {
+// two fp32 -> one dword of 16-bit values (element 0 in the low half); MODE 3 also returns the dword of lo halves
+template <int MODE>
+__device__ __forceinline__ uint32_t cvt2(float a, float b, uint32_t& lo) {
     const f32x2 v = {a, b};
-    if constexpr (BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, half2_t));
+    if constexpr (MODE == 2) { lo = 0; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t)); }
+    const half2_t h = __builtin_convertvector(v, half2_t);
+    if constexpr (MODE == 3) lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - __builtin_convertvector(h, f32x2), half2_t));
+    else lo = 0;
+    return __builtin_bit_cast(uint32_t, h);
 }
 
-template <bool TA, bool TB, bool BF16>
+template <int MODE> struct Gemm16Cfg {
+    static constexpr bool SPLIT = MODE == 3;
+    static constexpr int BM = 128, BN = SPLIT ? 128 : 256, TN = SPLIT ? 2 : 4;
+    static constexpr int LDR = SPLIT ? LDT : LD16;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LDR * sizeof(float);
+};
+
+template <bool TA, bool TB, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
-    constexpr int WAVES_M = 2, WAVES_N = 2, TM = 2, TN = 4;
-    constexpr int BM = 128, BN = 256, NT = 256;
-    constexpr int STAGE = (BM + BN) * LD16;              // dwords
+    using Cfg = Gemm16Cfg<MODE>;
+    constexpr bool SPLIT = Cfg::SPLIT, BF16 = MODE == 2;
+    constexpr int WAVES_M = 2, WAVES_N = 2, TM = 2, TN = Cfg::TN;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, LDR = Cfg::LDR;
+    constexpr int STAGE = (BM + BN) * LDR;               // dwords
     extern __shared__ __attribute__((aligned(16))) float lds[];
     uint32_t* L = reinterpret_cast<uint32_t*>(lds);
 
@@ -843,34 +859,38 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
         for (int p = 0; p < NB; ++p) { ldw(rsb, vb[p], rb[p], std::integral_constant<int, WB>{}); if (vb[p] < kOob) vb[p] += stepb; }
     };
     float csum[TA ? WA : 1] = {};
+    // eight k values of one row -> 16 bytes of hi halves (and, split mode, 16 bytes of lo halves 16 dwords further)
+    auto put8 = [&](uint32_t* dst, float k0, float k1, float k2, float k3, float k4, float k5, float k6, float k7) {
+        uint32_t l0, l1, l2, l3;
+        const u32x4 hi = {cvt2<MODE>(k0, k1, l0), cvt2<MODE>(k2, k3, l1), cvt2<MODE>(k4, k5, l2), cvt2<MODE>(k6, k7, l3)};
+        *reinterpret_cast<u32x4*>(dst) = hi;
+        if constexpr (SPLIT) { const u32x4 lo = {l0, l1, l2, l3}; *reinterpret_cast<u32x4*>(dst + 16) = lo; }
+    };
+    auto put4 = [&](uint32_t* dst, const float (&v)[4]) {
+        uint32_t l0, l1;
+        const u32x2 hi = {cvt2<MODE>(v[0], v[1], l0), cvt2<MODE>(v[2], v[3], l1)};
+        *reinterpret_cast<u32x2*>(dst) = hi;
+        if constexpr (SPLIT) { const u32x2 lo = {l0, l1}; *reinterpret_cast<u32x2*>(dst + 16) = lo; }
+    };
     auto lstore = [&](int buf) {
         uint32_t* base = L + buf * STAGE;
         if constexpr (TA) {
 #pragma unroll
             for (int c = 0; c < WA; ++c) {
                 if constexpr (TB) csum[c] += ((ra[0][c] + ra[1][c]) + (ra[2][c] + ra[3][c])) + ((ra[4][c] + ra[5][c]) + (ra[6][c] + ra[7][c]));
-                const u32x4 w = {cvt2<BF16>(ra[0][c], ra[1][c]), cvt2<BF16>(ra[2][c], ra[3][c]), cvt2<BF16>(ra[4][c], ra[5][c]), cvt2<BF16>(ra[6][c], ra[7][c])};
-                *reinterpret_cast<u32x4*>(base + (WA * lane + c) * LD16 + wave * 4) = w;
+                put8(base + (WA * lane + c) * LDR + wave * 4, ra[0][c], ra[1][c], ra[2][c], ra[3][c], ra[4][c], ra[5][c], ra[6][c], ra[7][c]);
             }
         } else {
 #pragma unroll
-            for (int p = 0; p < NA; ++p) {
-                const u32x2 w = {cvt2<BF16>(ra[p][0], ra[p][1]), cvt2<BF16>(ra[p][2], ra[p][3])};
-                *reinterpret_cast<u32x2*>(base + (srow + 32 * p) * LD16 + scol * 2) = w;
-            }
+            for (int p = 0; p < NA; ++p) put4(base + (srow + 32 * p) * LDR + scol * 2, ra[p]);
         }
         if constexpr (TB) {
 #pragma unroll
-            for (int c = 0; c < WB; ++c) {
-                const u32x4 w = {cvt2<BF16>(rb[0][c], rb[1][c]), cvt2<BF16>(rb[2][c], rb[3][c]), cvt2<BF16>(rb[4][c], rb[5][c]), cvt2<BF16>(rb[6][c], rb[7][c])};
-                *reinterpret_cast<u32x4*>(base + (BM + WB * lane + c) * LD16 + wave * 4) = w;
-            }
+            for (int c = 0; c < WB; ++c)
+                put8(base + (BM + WB * lane + c) * LDR + wave * 4, rb[0][c], rb[1][c], rb[2][c], rb[3][c], rb[4][c], rb[5][c], rb[6][c], rb[7][c]);
         } else {
 #pragma unroll
-            for (int p = 0; p < NB; ++p) {
-                const u32x2 w = {cvt2<BF16>(rb[p][0], rb[p][1]), cvt2<BF16>(rb[p][2], rb[p][3])};
-                *reinterpret_cast<u32x2*>(base + (BM + srow + 32 * p) * LD16 + scol * 2) = w;
-            }
+            for (int p = 0; p < NB; ++p) put4(base + (BM + srow + 32 * p) * LDR + scol * 2, rb[p]);
         }
     };
 
@@ -882,18 +902,34 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
 
-    const int a_off = (wm * TM * 32 + l31) * LD16 + kg * 4;
-    const int w_off = (BM + wn * TN * 32 + l31) * LD16 + kg * 4;
+    const int a_off = (wm * TM * 32 + l31) * LDR + kg * 4;
+    const int w_off = (BM + wn * TN * 32 + l31) * LDR + kg * 4;
     auto compute = [&](int buf) {
         const uint32_t* As = L + buf * STAGE + a_off;
         const uint32_t* Ws = L + buf * STAGE + w_off;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {                    // two k = 16 slabs per k-block
-            half8 ah[TM], bh[TN];
+            half8 ah[TM], bh[TN], al[SPLIT ? TM : 1], bl[SPLIT ? TN : 1];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const half8*>(As + i * 32 * LD16 + s * 8);
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const half8*>(As + i * 32 * LDR + s * 8);
+                if constexpr (SPLIT) al[i] = *reinterpret_cast<const half8*>(As + i * 32 * LDR + 16 + s * 8);
+            }
 #pragma unroll
-            for (int jn = 0; jn < TN; ++jn) bh[jn] = *reinterpret_cast<const half8*>(Ws + jn * 32 * LD16 + s * 8);
+            for (int jn = 0; jn < TN; ++jn) {
+                bh[jn] = *reinterpret_cast<const half8*>(Ws + jn * 32 * LDR + s * 8);
+                if constexpr (SPLIT) bl[jn] = *reinterpret_cast<const half8*>(Ws + jn * 32 * LDR + 16 + s * 8);
+            }
+            if constexpr (SPLIT) {                       // three sweeps: consecutive MFMAs never share an accumulator
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mfma_hi<false>(al[i], bh[jn], acc[i][jn]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mfma_hi<false>(ah[i], bl[jn], acc[i][jn]);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -950,22 +986,21 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
     }
 }
 
-template <bool TA, bool TB, bool BF16>
+template <bool TA, bool TB, int MODE>
 hipError_t launch_gemm16_cfg(const Gemm16Args& a_in, hipStream_t s) {
-    constexpr int BM = 128, BN = 256;
-    constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LD16 * sizeof(float);
+    using Cfg = Gemm16Cfg<MODE>;
     static bool attr_set = false;
-    auto kern = &gemm16_kernel<TA, TB, BF16>;
+    auto kern = &gemm16_kernel<TA, TB, MODE>;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     Gemm16Args a = a_in;
-    a.m_tiles = (a.M + BM - 1) / BM;
-    a.n_tiles = (a.N + BN - 1) / BN;
+    a.m_tiles = (a.M + Cfg::BM - 1) / Cfg::BM;
+    a.n_tiles = (a.N + Cfg::BN - 1) / Cfg::BN;
     dim3 grid(a.k_slices > 1 ? (unsigned)((a.k_slices + 7) / 8 * 8 * a.m_tiles * a.n_tiles) : (unsigned)((a.m_tiles + 7) / 8 * 8 * a.n_tiles));
-    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, s, a);
     return hipGetLastError();
 }
 
@@ -1029,21 +1064,30 @@ hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a_in, int tile, hipStr
 }
 
 // fp32 operands converted on the fly (gemm16_kernel): C [M, N] = Aop [M, K] Bop [N, K]^T (+ bias); ta / tb: the operand is stored
-// with the contraction index as its ROW index ([K, ld]).  Contraction-contiguous operands need K % 32 == 0 and ld % 4 == 0,
-// row-contiguous ones ld % 4 == 0 and an even (A) / multiple-of-4 (B) count of valid columns.  slices > 1: partial planes at
-// C + z * slice_stride (ta && tb only).
+// with the contraction index as its ROW index ([K, ld]); mode 1 f16, 2 bf16 (one product), 3 split-f16 (three products).
+// Contraction-contiguous operands need K % 32 == 0 and ld % 4 == 0, row-contiguous ones ld % 4 == 0 and an even (A) /
+// multiple-of-4 (B) count of valid columns.  slices > 1: partial planes at C + z * slice_stride (ta && tb only).
+int gemm16_tile_n(int mode) { return mode == 3 ? 128 : 256; }
+
+template <int MODE>
+static hipError_t launch_gemm16_mode(const Gemm16Args& a, int ta, int tb, hipStream_t s) {
+    if (!ta && !tb) return launch_gemm16_cfg<false, false, MODE>(a, s);
+    if (!ta && tb) return launch_gemm16_cfg<false, true, MODE>(a, s);
+    return launch_gemm16_cfg<true, true, MODE>(a, s);
+}
+
 hipError_t launch_gemm16(const float* A, int lda, int ta, const float* B, int ldb, int tb, const float* bias, float* C, int ldc,
-                         int M, int N, int K, int bf16, int slices, size_t slice_stride, int sum_col, hipStream_t s) {
+                         int M, int N, int K, int mode, int slices, size_t slice_stride, int sum_col, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0) return hipSuccess;
     if ((lda & 3) || (ldb & 3) || (!(ta && tb) && (K & 31)) || (ta && (M & 1)) || (tb && (N & 3))) return hipErrorInvalidValue;
     if ((!ta || !tb) && (slices > 1 || sum_col >= 0)) return hipErrorInvalidValue;
-    if (ta && !tb) return hipErrorInvalidValue;
+    if ((ta && !tb) || mode < 1 || mode > 3) return hipErrorInvalidValue;
     Gemm16Args a{};
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.k_slices = slices; a.slice_stride = slice_stride; a.sum_col = sum_col;
-    if (!ta && !tb) return bf16 ? launch_gemm16_cfg<false, false, true>(a, s) : launch_gemm16_cfg<false, false, false>(a, s);
-    if (!ta && tb) return bf16 ? launch_gemm16_cfg<false, true, true>(a, s) : launch_gemm16_cfg<false, true, false>(a, s);
-    return bf16 ? launch_gemm16_cfg<true, true, true>(a, s) : launch_gemm16_cfg<true, true, false>(a, s);
+    if (mode == 1) return launch_gemm16_mode<1>(a, ta, tb, s);
+    if (mode == 2) return launch_gemm16_mode<2>(a, ta, tb, s);
+    return launch_gemm16_mode<3>(a, ta, tb, s);
 }
 
 hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a_in, bool out_split, int tile, hipStream_t s) {

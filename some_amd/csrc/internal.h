@@ -61,9 +61,11 @@ hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a, bool out_split, int tile, hipStream_t s);
 // hi halves only (plain f16 x f16 -> fp32): mixed-precision training; EPI_NONE (optional split-K) / EPI_BIAS, 256 x 256 tile
 hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a, int tile, hipStream_t s, int bf16 = 0);    // bf16: hi slots hold bf16 (split.h)
-// one 16-bit product on fp32 operands rounded in the staging path, either operand stored contraction-major (gemm16_kernel)
+// GEMM on fp32 operands rounded / split in the staging path, either operand stored contraction-major (gemm16_kernel);
+// mode 1 f16, 2 bf16 (one product), 3 split-f16 (three products, fp32-equivalent)
 hipError_t launch_gemm16(const float* A, int lda, int ta, const float* B, int ldb, int tb, const float* bias, float* C, int ldc,
-                         int M, int N, int K, int bf16, int slices, size_t slice_stride, int sum_col, hipStream_t s);
+                         int M, int N, int K, int mode, int slices, size_t slice_stride, int sum_col, hipStream_t s);
+int gemm16_tile_n(int mode);
 
 // ---- row ops --------------------------------------------------------------------------------------
 // y[g][m][:] = LayerNorm(x[g][m][:]) * gamma[g] + beta[g], eps 1e-5, rows of 512.

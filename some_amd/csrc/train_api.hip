@@ -69,8 +69,9 @@ int some_train_gemm_splitk(SomeHandle* h, const float* A_split_dev, int32_t lda,
     return SOME_OK;
 }
 
-static int gemm16_slices(int M, int N, int K) {
-    const int tiles = ((M + 127) / 128) * ((N + 255) / 256), nk = (K + 31) / 32;
+static int gemm16_slices(int M, int N, int K, int mode) {
+    const int bn = gemm16_tile_n(mode);
+    const int tiles = ((M + 127) / 128) * ((N + bn - 1) / bn), nk = (K + 31) / 32;
     int want = (512 + tiles - 1) / tiles;                       // two 128 x 256 workgroups per CU in flight
     if (want > nk) want = nk;
     if (want < 1) want = 1;
@@ -81,7 +82,8 @@ static int gemm16_slices(int M, int N, int K) {
 size_t some_train_gemm16_bytes(const SomeHandle* h, int32_t M, int32_t N, int32_t K, int32_t ldc) {
     (void)h;
     if (M <= 0 || N <= 0 || K <= 0 || ldc <= 0) return 256;
-    return (size_t)gemm16_slices(M, N, K) * (size_t)M * ldc * sizeof(float) + 256;
+    const int s1 = gemm16_slices(M, N, K, 1), s3 = gemm16_slices(M, N, K, 3);     // the slice count depends on the mode's tile width
+    return (size_t)(s1 > s3 ? s1 : s3) * (size_t)M * ldc * sizeof(float) + 256;
 }
 
 int some_train_gemm16(SomeHandle* h, const float* A_dev, int32_t lda, int32_t ta, const float* B_dev, int32_t ldb, int32_t tb,
@@ -89,17 +91,17 @@ int some_train_gemm16(SomeHandle* h, const float* A_dev, int32_t lda, int32_t ta
                       int32_t sum_col, void* partial_dev, size_t partial_bytes, void* stream) {
     if (!h) return SOME_EINVAL;
     T_CHECK(h, M > 0 && N > 0 && K > 0 && A_dev && B_dev && C_dev, "some_train_gemm16: bad argument");
-    T_CHECK(h, operand == 1 || operand == 2, "some_train_gemm16: operand must be 1 (f16) or 2 (bf16)");
+    T_CHECK(h, operand >= 1 && operand <= 3, "some_train_gemm16: operand must be 1 (f16), 2 (bf16) or 3 (split f16, fp32-equivalent)");
     T_CHECK(h, (ta == 0 || ta == 1) && (tb == 0 || tb == 1) && !(ta && !tb), "some_train_gemm16: layouts (0,0), (0,1), (1,1) only");
     T_CHECK(h, (lda % 4) == 0 && (ldb % 4) == 0 && lda >= (ta ? M : K) && ldb >= (tb ? N : K), "some_train_gemm16: leading dimensions (% 4, >= row length)");
     T_CHECK(h, (ta && tb) || (K % 32) == 0, "some_train_gemm16: a contraction-contiguous operand needs K % 32 == 0");
     T_CHECK(h, (!ta || (M % 2) == 0) && (!tb || (N % 4) == 0), "some_train_gemm16: M even (ta) / N % 4 == 0 (tb)");
     T_CHECK(h, ldc >= N && (sum_col < 0 || (ta && tb && sum_col >= N && sum_col < ldc)), "some_train_gemm16: ldc / sum_col");
     T_CHECK(h, !bias_dev || !(ta && tb), "some_train_gemm16: no bias epilogue on the weight-gradient layout");
-    const int slices = (ta && tb) ? gemm16_slices(M, N, K) : 1;
-    if (slices > 1) T_CHECK(h, partial_dev && partial_bytes >= some_train_gemm16_bytes(h, M, N, K, ldc), "some_train_gemm16: partial buffer too small");
+    const int slices = (ta && tb) ? gemm16_slices(M, N, K, operand) : 1;
+    if (slices > 1) T_CHECK(h, partial_dev && partial_bytes >= (size_t)slices * (size_t)M * ldc * sizeof(float), "some_train_gemm16: partial buffer too small");
     float* out = slices > 1 ? static_cast<float*>(partial_dev) : C_dev;
-    T_TRY(h, launch_gemm16(A_dev, lda, ta, B_dev, ldb, tb, bias_dev, out, ldc, M, N, K, operand == 2, slices, (size_t)M * ldc, sum_col, st(stream)));
+    T_TRY(h, launch_gemm16(A_dev, lda, ta, B_dev, ldb, tb, bias_dev, out, ldc, M, N, K, operand, slices, (size_t)M * ldc, sum_col, st(stream)));
     if (slices > 1) T_TRY(h, launch_reduce_slices(static_cast<const float*>(partial_dev), slices, (size_t)M * ldc, C_dev, st(stream)));
     return SOME_OK;
 }

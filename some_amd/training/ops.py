@@ -33,8 +33,8 @@ class TrainOps:
         self._hi = 0                                        # GEMM flag bits of the one-product modes (set_mixed_precision)
         self._hi_mode = 0                                   # the `hi_only` argument: 0 three products, 1 f16, 2 bf16
         self.operand = 'f16x2'
-        # one-product modes: GEMMs on the fp32 arrays as they lie, rounded (and transposed) in the kernel's staging path
-        # (some_train_gemm16) instead of split_rows / transpose passes + the SPLIT32 kernels; SOME_AMD_TRAIN_GEMM16=0: A/B runs
+        # GEMMs on the fp32 arrays as they lie, rounded / split (and transposed) in the kernel's staging path (some_train_gemm16)
+        # instead of split_rows / transpose passes + the SPLIT32 kernels; SOME_AMD_TRAIN_GEMM16=0: A/B runs
         self.gemm16 = os.environ.get('SOME_AMD_TRAIN_GEMM16', '1') != '0'
 
     def set_mixed_precision(self, on: bool, operand: str = 'f16'):
@@ -85,7 +85,12 @@ class TrainOps:
         return self.gemm_precision == 'f16x3' and K % 32 == 0 and N >= 64 and M >= 64
 
     def _use16(self, M: int, N: int, K: int) -> bool:
-        return bool(self._hi_mode) and self.gemm16 and self._use_split(M, N, K) and N % 4 == 0
+        return self.gemm16 and self._use_split(M, N, K) and N % 4 == 0
+
+    @property
+    def _op16(self) -> int:
+        """some_train_gemm16 operand code: 1 f16 / 2 bf16 (one product), 3 split f16 (three products, fp32-equivalent)."""
+        return self._hi_mode or 3
 
     def gemm(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         """a [M, K] @ w[N, K]^T (+ bias).  ``gemm_precision`` 'f16x3' (default): both operands are split into f16
@@ -100,7 +105,7 @@ class TrainOps:
             return out
         epi = _lib.EPI_BIAS if bias is not None else _lib.EPI_NONE
         if self._use16(M, N, K):
-            self.check(self.lib.some_train_gemm16(self.h, _p(a), K, 0, _p(w), K, 0, _p(bias), _p(out), N, M, N, K, self._hi_mode, -1, None, 0,
+            self.check(self.lib.some_train_gemm16(self.h, _p(a), K, 0, _p(w), K, 0, _p(bias), _p(out), N, M, N, K, self._op16, -1, None, 0,
                                                   self.stream()))
             return out
         if self._use_split(M, N, K):
@@ -124,7 +129,7 @@ class TrainOps:
         K = w.shape[1]
         if self._use16(M, K, N):                                        # w [N, K] is the contraction-major operand as it lies
             out = self.new(M, K)
-            self.check(self.lib.some_train_gemm16(self.h, _p(dy), N, 0, _p(w), K, 1, None, _p(out), K, M, K, N, self._hi_mode, -1, None, 0,
+            self.check(self.lib.some_train_gemm16(self.h, _p(dy), N, 0, _p(w), K, 1, None, _p(out), K, M, K, N, self._op16, -1, None, 0,
                                                   self.stream()))
             return out
         if self._use_split(M, K, N):
@@ -147,7 +152,7 @@ class TrainOps:
             sc = self.scratch(M, K)
             self.check(self.lib.some_train_weighted_colsum(self.h, _p(dy), 1, _p(x), M, K, K, _p(out), _p(ws), _p(sc), sc.numel(), self.stream()))
             return out, (ws[:1].clone() if with_bias else None)
-        if self._hi_mode and self.gemm16 and self.gemm_precision == 'f16x3' and N >= 32 and N % 2 == 0 and K % 4 == 0 and K >= 32:
+        if self.gemm16 and self.gemm_precision == 'f16x3' and N >= 32 and N % 2 == 0 and K % 4 == 0 and K >= 32:
             # dy [M, N] and x [M, K] are both contraction-major as they lie; the bias gradient is the fp32 column sum of dy,
             # accumulated in the kernel's staging registers into column K of the output
             ldc = K + (4 if with_bias else 0)
@@ -155,7 +160,7 @@ class TrainOps:
             need = int(self.lib.some_train_gemm16_bytes(self.h, N, K, M, ldc))
             if self._partial is None or self._partial.numel() < need:
                 self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
-            self.check(self.lib.some_train_gemm16(self.h, _p(dy), N, 1, _p(x), K, 1, None, _p(out), ldc, N, K, M, self._hi_mode,
+            self.check(self.lib.some_train_gemm16(self.h, _p(dy), N, 1, _p(x), K, 1, None, _p(out), ldc, N, K, M, self._op16,
                                                   K if with_bias else -1, _p(self._partial), self._partial.numel(), self.stream()))
             if not with_bias:
                 return out, None

@@ -199,10 +199,15 @@ def test_attention_fwd_bwd(ops, lens, precision):
 
 # ---- some_train_gemm16: fp32 operands rounded (and transposed) in the staging path ---------------------------------------
 def _round16(t, operand):
+    if operand == 'f16x3':                 # hi + lo carries 22 bits: the fp32 value to 2^-22
+        return t.double()
     return (t.bfloat16() if operand == 'bf16' else t.half()).double()
 
 
-@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+_OP16 = {'f16': 1, 'bf16': 2, 'f16x3': 3}
+
+
+@pytest.mark.parametrize('operand', ['bf16', 'f16', 'f16x3'])
 @pytest.mark.parametrize('M,K,N,bias', [(300, 512, 2048, True), (128, 32, 256, False), (129, 2048, 512, True), (2584, 512, 1536, False),
                                          (64, 512, 132, True), (1000, 64, 64, True)])
 def test_gemm16_forward_layout(ops, operand, M, K, N, bias):
@@ -212,29 +217,29 @@ def test_gemm16_forward_layout(ops, operand, M, K, N, bias):
     x, w = _rand(M, K, seed=11).detach() * 3, _rand(N, K, seed=12).detach()
     b = _rand(N, seed=13).detach() if bias else None
     out = torch.full((M, N), float('nan'), device='cuda')
-    ops.check(ops.lib.some_train_gemm16(ops.h, _p(x), K, 0, _p(w), K, 0, _p(b), _p(out), N, M, N, K, 2 if operand == 'bf16' else 1, -1, None, 0,
+    ops.check(ops.lib.some_train_gemm16(ops.h, _p(x), K, 0, _p(w), K, 0, _p(b), _p(out), N, M, N, K, _OP16[operand], -1, None, 0,
                                         ops.stream()))
     want = _round16(x, operand) @ _round16(w, operand).t() + (b.double() if bias else 0)
     scale = float(want.abs().max())
     assert float((out.double() - want).abs().max()) < 2e-6 * scale * max(1.0, (K / 512) ** 0.5)
-    if K >= 512:
+    if K >= 512 and operand != 'f16x3':
         assert float((out.double() - (x.double() @ w.double().t() + (b.double() if bias else 0))).abs().max()) > 1e-4 * scale
 
 
-@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+@pytest.mark.parametrize('operand', ['bf16', 'f16', 'f16x3'])
 @pytest.mark.parametrize('M,N,K', [(300, 2048, 512), (129, 512, 2048), (2584, 1536, 512), (70, 64, 132), (257, 128, 516)])
 def test_gemm16_data_gradient_layout(ops, operand, M, N, K):
     """(0, 1): dx [M, K] = dy [M, N] @ w [N, K] with w read as it lies (its rows are the contraction index)."""
     from some_amd.training.ops import _p
     dy, w = _rand(M, N, seed=21).detach(), _rand(N, K, seed=22).detach() * 2
     out = torch.full((M, K), float('nan'), device='cuda')
-    ops.check(ops.lib.some_train_gemm16(ops.h, _p(dy), N, 0, _p(w), K, 1, None, _p(out), K, M, K, N, 2 if operand == 'bf16' else 1, -1, None, 0,
+    ops.check(ops.lib.some_train_gemm16(ops.h, _p(dy), N, 0, _p(w), K, 1, None, _p(out), K, M, K, N, _OP16[operand], -1, None, 0,
                                         ops.stream()))
     want = _round16(dy, operand) @ _round16(w, operand)
     assert float((out.double() - want).abs().max()) < 2e-6 * float(want.abs().max()) * max(1.0, (N / 512) ** 0.5)
 
 
-@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+@pytest.mark.parametrize('operand', ['bf16', 'f16', 'f16x3'])
 @pytest.mark.parametrize('M,N,K,bias', [(300, 2048, 512, True), (2584 * 2 + 7, 512, 2048, True), (1001, 1536, 512, False), (95, 32, 80, True),
                                          (20672, 132, 36, True), (31, 512, 512, True)])
 def test_gemm16_weight_gradient_layout(ops, operand, M, N, K, bias):
@@ -246,7 +251,7 @@ def test_gemm16_weight_gradient_layout(ops, operand, M, N, K, bias):
     out = torch.full((N, ldc), float('nan'), device='cuda')
     need = int(ops.lib.some_train_gemm16_bytes(ops.h, N, K, M, ldc))
     part = torch.empty(need, dtype=torch.uint8, device='cuda')
-    args = (ops.h, _p(dy), N, 1, _p(x), K, 1, None, _p(out), ldc, N, K, M, 2 if operand == 'bf16' else 1, K if bias else -1, _p(part), need, ops.stream())
+    args = (ops.h, _p(dy), N, 1, _p(x), K, 1, None, _p(out), ldc, N, K, M, _OP16[operand], K if bias else -1, _p(part), need, ops.stream())
     ops.check(ops.lib.some_train_gemm16(*args))
     want = _round16(dy, operand).t() @ _round16(x, operand)
     tol = 3e-6 * max(1.0, (M / 512) ** 0.5)
@@ -262,7 +267,7 @@ def test_gemm16_weight_gradient_layout(ops, operand, M, N, K, bias):
 def test_gemm16_argument_checks(ops):
     from some_amd.training.ops import _p
     a, b, c = torch.zeros(64, 64, device='cuda'), torch.zeros(64, 64, device='cuda'), torch.zeros(64, 64, device='cuda')
-    bad = [dict(ta=1, tb=0), dict(operand=0), dict(K=48), dict(lda=66), dict(sum_col=64)]
+    bad = [dict(ta=1, tb=0), dict(operand=0), dict(operand=4), dict(K=48), dict(lda=66), dict(sum_col=64)]
     for kw in bad:
         d = dict(lda=64, ta=0, ldb=64, tb=0, ldc=64, M=64, N=64, K=64, operand=2, sum_col=-1)
         d.update(kw)
@@ -271,14 +276,15 @@ def test_gemm16_argument_checks(ops):
         assert rc != 0, kw
 
 
-@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+@pytest.mark.parametrize('operand', ['bf16', 'f16', None])
 def test_mixed_linear_matches_the_split_kernels(ops, operand):
     """ops.linear in the one-product modes: the fused-staging GEMMs (default) against the split_rows / transpose + SPLIT32 kernels
     they replace - same operand roundings, so outputs and all three gradients agree to accumulation-order noise."""
     x, w, b = _rand(700, 512, seed=41), _rand(2048, 512, seed=42, scale=512 ** -0.5), _rand(2048, seed=43)
     res = {}
     try:
-        ops.set_mixed_precision(True, operand)
+        if operand:
+            ops.set_mixed_precision(True, operand)
         for g16 in (True, False):
             ops.gemm16 = g16
             xa, wa, ba = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
@@ -289,4 +295,4 @@ def test_mixed_linear_matches_the_split_kernels(ops, operand):
         ops.gemm16 = True
         ops.set_mixed_precision(False)
     for p, q in zip(res[True], res[False]):
-        _close(p, q, 5e-5 if operand == 'f16' else 3e-4)     # (bias gradient: fp32 sums here, 16-bit-rounded dy through the ones row there)
+        _close(p, q, {'f16': 5e-5, 'bf16': 3e-4, None: 5e-6}[operand])     # (bias gradient: fp32 sums here, 16-bit-rounded dy through the ones row there)
