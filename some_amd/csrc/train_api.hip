@@ -98,6 +98,10 @@ int some_train_gemm16(SomeHandle* h, const float* A_dev, int32_t lda, int32_t ta
     T_CHECK(h, (!ta || (M % 2) == 0) && (!tb || (N % 4) == 0), "some_train_gemm16: M even (ta) / N % 4 == 0 (tb)");
     T_CHECK(h, ldc >= N && (sum_col < 0 || (ta && tb && sum_col >= N && sum_col < ldc)), "some_train_gemm16: ldc / sum_col");
     T_CHECK(h, !bias_dev || !(ta && tb), "some_train_gemm16: no bias epilogue on the weight-gradient layout");
+    // 32-bit byte offsets behind buffer descriptors (2 GiB each): refuse what they cannot address instead of reading zeros
+    const size_t lim = 0x7fffffffull;
+    T_CHECK(h, (size_t)(ta ? K : M) * lda * 4 <= lim && (size_t)(tb ? K : N) * ldb * 4 <= lim && (size_t)M * ldc * 4 <= lim,
+            "some_train_gemm16: an operand exceeds 2 GiB (split the batch)");
     const int slices = (ta && tb) ? gemm16_slices(M, N, K, operand) : 1;
     if (slices > 1) T_CHECK(h, partial_dev && partial_bytes >= (size_t)slices * (size_t)M * ldc * sizeof(float), "some_train_gemm16: partial buffer too small");
     float* out = slices > 1 ? static_cast<float*>(partial_dev) : C_dev;
