@@ -206,7 +206,7 @@ int some_train_eltwise(SomeHandle* h, int32_t op, const float* a_dev, const floa
 int some_train_glu(SomeHandle* h, const float* dy_dev, const float* x_dev, float* out_dev, int64_t M, int32_t C,
                    int32_t backward, void* stream) {
     if (!h) return SOME_EINVAL;
-    T_CHECK(h, M >= 0 && C > 0 && x_dev && out_dev && (!backward || dy_dev), "some_train_glu: bad argument");
+    T_CHECK(h, M >= 0 && C > 0 && (C % 4) == 0 && x_dev && out_dev && (!backward || dy_dev), "some_train_glu: bad argument (C % 4 == 0, 16-byte aligned arrays)");
     T_TRY(h, launch_glu(dy_dev, x_dev, out_dev, M, C, backward, st(stream)));
     return SOME_OK;
 }
