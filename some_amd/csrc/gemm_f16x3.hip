@@ -322,7 +322,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     // (the wavefront index is left lane-derived: forcing it into an SGPR with readfirstlane removes the 64 one-trip waterfall
     // loops hipcc wraps around the row-per-lane epilogue's stores, cdna guide T20 - measured: no gain, 1.0002 vs 1.0005 ms, AND
     // run-to-run different results at 32 x 30 s; profiles/r02_experiments.md)
+#ifdef GEMM_WAVE_SGPR_EPI        // diagnostic builds only (profiles/r02_experiments.md): SGPR wave index for the epilogues in the bit mask
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = ((GEMM_WAVE_SGPR_EPI >> EPI) & 1) ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
+#else
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#endif
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & 31, kg = lane >> 5;
     // split-K (weight gradients: small output, contraction over all frames): slice z covers k-blocks [kt0, kt0 + nk)
