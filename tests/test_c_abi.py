@@ -94,3 +94,32 @@ def test_forward_requires_weights_and_gpu_pointers():
     assert rc == _lib.SOME_ESTATE and b'attach' in lib.some_last_error(eng.handle)
     assert lib.some_workspace_bytes(eng.handle, 1000, 1) >= 2 * 1000 * (512 * 3 + 2048) * 4
     assert lib.some_decode_scratch_bytes(eng.handle, 1000) >= 1000 * 13
+
+
+def test_train_gemm16_validates_arguments_before_any_launch():
+    """some_train_gemm16 (training GEMMs on fp32 operands as they lie): layout / alignment / size rules are checked on the host
+    and refused with SOME_EINVAL - in particular a partial-plane buffer smaller than the MODE'S OWN slice count needs (the
+    one-product modes cut the contraction finer than the split mode: sizing by the wrong mode once wrote past the buffer)."""
+    from some_amd.engine import Engine
+    lib = _lib.load()
+    eng = Engine(get_config('two_head_model', lay=1), host_only=True)
+    h = eng.handle
+    fake = C.c_void_p(4096)                  # never dereferenced: every call below fails validation first
+
+    def call(lda=512, ta=0, ldb=512, tb=0, bias=None, ldc=2048, M=256, N=2048, K=512, operand=2, sum_col=-1, partial=None, pbytes=0):
+        return lib.some_train_gemm16(h, fake, lda, ta, fake, ldb, tb, bias, fake, ldc, M, N, K, operand, sum_col, partial, pbytes, None)
+
+    for kw, msg in [(dict(operand=0), b'operand'), (dict(operand=4), b'operand'), (dict(ta=1, tb=0), b'layouts'), (dict(K=512, lda=514, ldb=514), b'% 4'),
+                    (dict(K=48, lda=48, ldb=48), b'K % 32'), (dict(lda=510), b'leading'), (dict(sum_col=2048), b'sum_col'),
+                    (dict(ldc=1024), b'ldc'), (dict(M=1 << 20, lda=2048, K=2048, ldb=2048), b'2 GiB')]:
+        assert call(**kw) == _lib.SOME_EINVAL, kw
+        assert msg in lib.some_last_error(h), (kw, lib.some_last_error(h))
+    # weight-gradient layout: dW [2048, 512 (+4)] = dY [20672, 2048]^T x [20672, 512]
+    wg = dict(lda=2048, ta=1, ldb=512, tb=1, ldc=516, M=2048, N=512, K=20672, sum_col=512)
+    plane = 2048 * 516 * 4
+    need = lib.some_train_gemm16_bytes(h, 2048, 512, 20672, 516)
+    assert need >= 8 * plane                                           # at least 8 slices for a 32 / 64-tile output
+    for operand in (1, 2, 3):
+        assert call(operand=operand, partial=fake, pbytes=plane, **wg) == _lib.SOME_EINVAL
+        assert b'partial buffer too small' in lib.some_last_error(h)
+    assert call(bias=fake, partial=fake, pbytes=need, **wg) == _lib.SOME_EINVAL and b'no bias' in lib.some_last_error(h)
