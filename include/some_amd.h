@@ -239,6 +239,13 @@ size_t some_train_gemm16_bytes(const SomeHandle* h, int32_t M, int32_t N, int32_
 int some_train_gemm16(SomeHandle* h, const float* A_dev, int32_t lda, int32_t ta, const float* B_dev, int32_t ldb, int32_t tb,
                       const float* bias_dev, float* C_dev, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t operand,
                       int32_t sum_col, void* partial_dev, size_t partial_bytes, void* stream);
+/* The weight gradient of nn.Linear written where it belongs: dW[N, K] (+)= dY[frames, N]^T X[frames, K] and, if db_dev, db[N] (+)= the
+ * fp32 column sums of dY - the (1, 1) layout of some_train_gemm16 with the slice reduction storing straight into the parameter-
+ * gradient arrays (accumulate = 1: added to their contents, i.e. to the flat gradient buffer across micro-batches), so that no
+ * intermediate tensor, slice copy or autograd accumulation launch remains.  partial_dev: some_train_gemm16_bytes(N, K, frames, K + 4). */
+int some_train_gemm16_wgrad(SomeHandle* h, const float* dY_dev, int32_t ldy, const float* X_dev, int32_t ldx, float* dW_dev, float* db_dev,
+                            int32_t N, int32_t K, int32_t frames, int32_t operand, int32_t accumulate, void* partial_dev, size_t partial_bytes,
+                            void* stream);
 /* out[n, m] = in[m, n] for m < M, 0 for M <= m < ld_out (the zero padding makes ld_out a valid contraction length).
  * split_out = 1: rows are written in SPLIT32 format (ready as a split-f16 GEMM operand; ld_out % 32 == 0);
  * split_out = 2: the same slots with bf16 hi halves (SOME_OPERAND_BF16). */

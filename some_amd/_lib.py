@@ -74,6 +74,7 @@ SYMBOLS = {
     'some_train_gemm16_bytes': (C.c_size_t, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'some_train_gemm16': (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
+    'some_train_gemm16_wgrad': (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
     'some_train_transpose': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
     'some_train_weighted_colsum': (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_size_t, _P]),
     'some_train_colsum': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P]),

@@ -187,6 +187,8 @@ hipError_t launch_pcm_gather(const void* src, int is_pcm16, const int64_t* src_o
 size_t train_col_scratch_bytes(int M, int N);
 size_t train_dwconv_w_scratch_bytes(int M, int C);
 hipError_t launch_reduce_slices(const float* partial, int slices, size_t n, float* out, hipStream_t s);
+hipError_t launch_reduce_wgrad(const float* partial, int slices, size_t stride, int M, int N, int ldc, float* dw, float* db, int accumulate,
+                               hipStream_t s);
 hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, int split_out, hipStream_t s);
 hipError_t launch_colsum(const float* x, int M, int N, int ld, float* out, int accumulate, float* scratch, hipStream_t s);
 hipError_t launch_weighted_colsum(const float* w, int ldw, const float* x, int M, int N, int ld, float* out, float* wsum, float* scratch, hipStream_t s);

@@ -110,6 +110,25 @@ int some_train_gemm16(SomeHandle* h, const float* A_dev, int32_t lda, int32_t ta
     return SOME_OK;
 }
 
+int some_train_gemm16_wgrad(SomeHandle* h, const float* dY_dev, int32_t ldy, const float* X_dev, int32_t ldx, float* dW_dev, float* db_dev,
+                            int32_t N, int32_t K, int32_t frames, int32_t operand, int32_t accumulate, void* partial_dev, size_t partial_bytes,
+                            void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, N > 0 && K > 0 && frames > 0 && dY_dev && X_dev && dW_dev && partial_dev, "some_train_gemm16_wgrad: bad argument");
+    T_CHECK(h, operand >= 1 && operand <= 3, "some_train_gemm16_wgrad: operand must be 1 (f16), 2 (bf16) or 3 (split f16, fp32-equivalent)");
+    T_CHECK(h, (ldy % 4) == 0 && (ldx % 4) == 0 && ldy >= N && ldx >= K && (N % 2) == 0 && (K % 4) == 0, "some_train_gemm16_wgrad: shapes (ld % 4, N even, K % 4)");
+    T_CHECK(h, (reinterpret_cast<uintptr_t>(dW_dev) & 15) == 0, "some_train_gemm16_wgrad: dW must be 16-byte aligned");
+    const int ldc = K + 4;
+    const size_t lim = 0x7fffffffull;
+    T_CHECK(h, (size_t)frames * ldy * 4 <= lim && (size_t)frames * ldx * 4 <= lim && (size_t)N * ldc * 4 <= lim, "some_train_gemm16_wgrad: an operand exceeds 2 GiB (split the batch)");
+    const int slices = gemm16_slices(N, K, frames, operand);
+    T_CHECK(h, partial_bytes >= (size_t)slices * (size_t)N * ldc * sizeof(float), "some_train_gemm16_wgrad: partial buffer too small (some_train_gemm16_bytes(N, K, frames, K + 4))");
+    float* planes = static_cast<float*>(partial_dev);
+    T_TRY(h, launch_gemm16(dY_dev, ldy, 1, X_dev, ldx, 1, nullptr, planes, ldc, N, K, frames, operand, slices, (size_t)N * ldc, db_dev ? K : -1, st(stream)));
+    T_TRY(h, launch_reduce_wgrad(planes, slices, (size_t)N * ldc, N, K, ldc, dW_dev, db_dev, accumulate, st(stream)));
+    return SOME_OK;
+}
+
 int some_train_transpose(SomeHandle* h, const float* in_dev, int32_t M, int32_t N, int32_t ld_in, float* out_dev,
                          int32_t ld_out, int32_t split_out, void* stream) {
     if (!h) return SOME_EINVAL;

@@ -563,6 +563,45 @@ hipError_t launch_reduce_slices(const float* partial, int slices, size_t n, floa
     return hipGetLastError();
 }
 
+// Weight-gradient planes [slice][M][ldc] (ldc = N + 4: the GEMM's N columns, then the column-sum column) -> the parameter-gradient
+// arrays themselves: dW [M, N] contiguous and db [M], summed in slice order, added to what is there when `accumulate` (the flat
+// gradient buffer across micro-batches) - no intermediate tensor, no separate add.
+static __global__ __launch_bounds__(256) void reduce_wgrad_kernel(const float* __restrict__ partial, int slices, size_t stride, int M, int N, int ldc,
+                                                                  float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+    const int n4 = N / 4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * n4) return;
+    const int row = (int)(i / n4), c = (int)(i % n4) * 4;
+    const float* src = partial + (size_t)row * ldc + c;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(src);
+    for (int s = 1; s < slices; ++s) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)s * stride);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += v[k];
+    }
+    f32x4* out = reinterpret_cast<f32x4*>(dw + (size_t)row * N + c);
+    if (accumulate) {
+        const f32x4 o = *out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += o[k];
+    }
+    *out = acc;
+    if (db != nullptr && c == 0) {
+        float b = partial[(size_t)row * ldc + N];
+        for (int s = 1; s < slices; ++s) b += partial[(size_t)s * stride + (size_t)row * ldc + N];
+        db[row] = (accumulate ? db[row] : 0.f) + b;
+    }
+}
+
+hipError_t launch_reduce_wgrad(const float* partial, int slices, size_t stride, int M, int N, int ldc, float* dw, float* db, int accumulate,
+                               hipStream_t s) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    if ((N & 3) || (ldc & 3) || (reinterpret_cast<uintptr_t>(dw) & 15)) return hipErrorInvalidValue;
+    const size_t n = (size_t)M * (N / 4);
+    hipLaunchKernelGGL(reduce_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, partial, slices, stride, M, N, ldc, dw, db, accumulate);
+    return hipGetLastError();
+}
+
 // ---- launchers -----------------------------------------------------------------------------------------------------------
 static inline int n_chunks(int M) { return (M + kChunkRows - 1) / kChunkRows; }
 size_t train_col_scratch_bytes(int M, int N) { return (size_t)n_chunks(M) * 2 * N * sizeof(float); }

@@ -44,8 +44,18 @@ class BucketedGradSync:
         self.work: List[Optional[object]] = []
         self.armed = False
         self.launch_order: List[int] = []                 # diagnostics: order in which buckets went out this step
+        self._hooks = []
+        self._index = {}
         for i, (p, _, _) in enumerate(params):
-            p.register_post_accumulate_grad_hook(self._make_hook(i))
+            hook = self._make_hook(i)
+            self._hooks.append(hook)
+            self._index[id(p)] = i
+            p.register_post_accumulate_grad_hook(hook)
+
+    def mark(self, param):
+        """The gradient of ``param`` was written into the flat buffer by a backward kernel itself (TrainOps gradient sinks): autograd
+        accumulates nothing for it, so its post-accumulate hook never fires - this call stands in for it."""
+        self._hooks[self._index[id(param)]](param)
 
     def _make_hook(self, index: int):
         bucket = self.bucket_of[index]

@@ -5,7 +5,7 @@ PyTorch only records the tape and owns the memory; forward and backward math run
 names the reference op it stands for."""
 import ctypes as C
 import os
-from typing import Optional
+from typing import Dict, Optional
 
 import numpy as np
 import torch
@@ -36,6 +36,13 @@ class TrainOps:
         # GEMMs on the fp32 arrays as they lie, rounded / split (and transposed) in the kernel's staging path (some_train_gemm16)
         # instead of split_rows / transpose passes + the SPLIT32 kernels; SOME_AMD_TRAIN_GEMM16=0: A/B runs
         self.gemm16 = os.environ.get('SOME_AMD_TRAIN_GEMM16', '1') != '0'
+        # Gradient sinks: parameters whose gradient ARRAYS the backward kernels write themselves (FlatParams' views of the flat
+        # gradient buffer), accumulating in place - nn.Linear weights / biases (some_train_gemm16_wgrad) and LayerNorm gamma / beta.
+        # Their backward returns None for the parameter, so autograd launches no copy and no accumulation kernel for it
+        # (291 + 126 launches per step before); ``on_grad_ready(param)`` stands in for the post-accumulate hook (gradient sync).
+        self._sinks: Dict[int, torch.Tensor] = {}
+        self.on_grad_ready = None
+        self.use_sinks = os.environ.get('SOME_AMD_TRAIN_SINKS', '1') != '0'
 
     def set_mixed_precision(self, on: bool, operand: str = 'f16'):
         """Mixed-precision training (the reference's pl_trainer_precision '16-mixed' / 'bf16'): the matrix products read one
@@ -50,6 +57,34 @@ class TrainOps:
         self._hi = (_lib.GEMM_HI_ONLY | (_lib.GEMM_HI_BF16 if bf16 else 0)) if on else 0
         self._hi_mode = (2 if bf16 else 1) if on else 0
         self.operand = 'bf16' if bf16 else 'f16x2'
+
+    # ---- gradient sinks ---------------------------------------------------------------------------------------
+    def register_grad_sinks(self, params, on_grad_ready=None):
+        """params: iterable of leaf tensors whose ``.grad`` is preallocated (a contiguous fp32 view that is zeroed every step)."""
+        self._sinks = {id(p): p.grad for p in params}
+        self.on_grad_ready = on_grad_ready
+
+    def sink(self, param) -> Optional[torch.Tensor]:
+        if param is None or not self.use_sinks:
+            return None
+        return self._sinks.get(id(param))
+
+    def deposited(self, param):
+        if self.on_grad_ready is not None:
+            self.on_grad_ready(param)
+
+    def can_wgrad_into(self, N: int, K: int) -> bool:
+        return self.gemm16 and self.gemm_precision == 'f16x3' and N >= 32 and N % 2 == 0 and K % 4 == 0 and K >= 32
+
+    def gemm_dw_into(self, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor]):
+        """dw [N, K] += dy^T x, db [N] += column sums of dy, straight into the gradient arrays (some_train_gemm16_wgrad)."""
+        M, N = dy.shape
+        K = x.shape[1]
+        need = int(self.lib.some_train_gemm16_bytes(self.h, N, K, M, K + 4))
+        if self._partial is None or self._partial.numel() < need:
+            self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.check(self.lib.some_train_gemm16_wgrad(self.h, _p(dy), N, _p(x), K, _p(dw), _p(db), N, K, M, self._op16, 1, _p(self._partial),
+                                                    self._partial.numel(), self.stream()))
 
     # ---- plumbing -------------------------------------------------------------------------------------------
     def stream(self):
@@ -280,6 +315,7 @@ class _Linear(torch.autograd.Function):
         w2 = weight.reshape(weight.shape[0], -1)                  # Conv1d k = 1 weights are [N, K, 1]
         ctx.save_for_backward(x, w2)
         ctx.wshape, ctx.has_bias = weight.shape, bias is not None
+        ctx.wparam, ctx.bparam = weight, bias                     # identities only: looked up among the gradient sinks in backward
         return ops.gemm(x.contiguous(), w2.contiguous(), bias)
 
     @staticmethod
@@ -290,8 +326,16 @@ class _Linear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
             dx = ops.gemm_dx(dy, w2.contiguous())
-        if ctx.needs_input_grad[2]:
-            dw, db = ops.gemm_dw(dy, x.contiguous(), ctx.has_bias and ctx.needs_input_grad[3])
+        want_db = ctx.has_bias and ctx.needs_input_grad[3]
+        sw = ops.sink(ctx.wparam) if ctx.needs_input_grad[2] else None
+        sb = ops.sink(ctx.bparam) if want_db else None
+        if sw is not None and (sb is not None or not want_db) and ops.can_wgrad_into(dy.shape[1], x.shape[1]):
+            ops.gemm_dw_into(dy, x.contiguous(), sw, sb)          # written into the parameters' gradient arrays: nothing to return
+            ops.deposited(ctx.wparam)
+            if sb is not None:
+                ops.deposited(ctx.bparam)
+        elif ctx.needs_input_grad[2]:
+            dw, db = ops.gemm_dw(dy, x.contiguous(), want_db)
             dw = dw.reshape(ctx.wshape)
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             db = ops.colsum(dy)
@@ -306,6 +350,7 @@ class _LayerNorm(torch.autograd.Function):
         y, mean, rstd = torch.empty_like(x), ops.new(M), ops.new(M)
         ops.check(ops.lib.some_train_layernorm_fwd(ops.h, _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, ops.stream()))
         ctx.ops = ops
+        ctx.gparam, ctx.bparam = gamma, beta
         ctx.save_for_backward(x, gamma, mean, rstd)
         return y
 
@@ -315,8 +360,17 @@ class _LayerNorm(torch.autograd.Function):
         x, gamma, mean, rstd = ctx.saved_tensors
         dy = dy.contiguous()
         M = x.shape[0]
-        dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+        dx = torch.empty_like(x)
         sc = ops.scratch(M, 512)
+        sg, sb = ops.sink(ctx.gparam), ops.sink(ctx.bparam)
+        if sg is not None and sb is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
+            # the column reductions add straight into the parameters' gradient arrays
+            ops.check(ops.lib.some_train_layernorm_bwd(ops.h, _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(sg), _p(sb), 1, M,
+                                                       _p(sc), sc.numel(), ops.stream()))
+            ops.deposited(ctx.gparam)
+            ops.deposited(ctx.bparam)
+            return None, dx, None, None
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
         ops.check(ops.lib.some_train_layernorm_bwd(ops.h, _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), 0, M,
                                                    _p(sc), sc.numel(), ops.stream()))
         return None, dx, dg, db

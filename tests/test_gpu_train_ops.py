@@ -296,3 +296,51 @@ def test_mixed_linear_matches_the_split_kernels(ops, operand):
         ops.set_mixed_precision(False)
     for p, q in zip(res[True], res[False]):
         _close(p, q, {'f16': 5e-5, 'bf16': 3e-4, None: 5e-6}[operand])     # (bias gradient: fp32 sums here, 16-bit-rounded dy through the ones row there)
+
+
+@pytest.mark.parametrize('operand', [None, 'bf16'])
+def test_gradient_sinks_accumulate_in_place(ops, operand):
+    """Parameters registered as gradient sinks (the trainer's views of the flat gradient buffer) get their gradients written by
+    the backward kernels themselves - nn.Linear weight / bias through some_train_gemm16_wgrad, LayerNorm gamma / beta through
+    the accumulate flag of the column reductions: backward returns None for them (autograd launches nothing), two micro-batches add up
+    in the preallocated arrays, and the ready callback fires once per parameter and backward pass.  Checked against plain PyTorch
+    (fp32-equivalent mode) and against the same operators without sinks (autograd accumulation) in both modes."""
+    def make():
+        w, b = _rand(256, 512, seed=1, scale=512 ** -0.5), _rand(256, seed=2)
+        g, be = (_rand(512, seed=3).detach() * 0.1 + 1).requires_grad_(True), _rand(512, seed=4)
+        return [w, b, g, be]
+
+    def run(params):
+        w, b, g, be = params
+        for step in range(2):
+            x = _rand(300, 512, seed=10 + step).detach()
+            cot = _rand(300, 256, seed=20 + step).detach()
+            ops.linear(ops.layernorm(x, g, be), w, b).backward(cot)
+
+    sunk, plain, ref = make(), make(), make()
+    arrays = []
+    for p in sunk:
+        p.grad = torch.zeros_like(p)
+        arrays.append(p.grad.data_ptr())
+    ready = []
+    try:
+        if operand:
+            ops.set_mixed_precision(True, operand)
+        ops.register_grad_sinks(sunk, ready.append)
+        run(sunk)
+        ops.register_grad_sinks([], None)
+        run(plain)                                                     # same kernels for dx, autograd accumulation for the parameters
+    finally:
+        ops.set_mixed_precision(False)
+        ops.register_grad_sinks([], None)
+    assert [id(p) for p in ready].count(id(sunk[0])) == 2 and len(ready) == 8
+    for p, q, ptr in zip(sunk, plain, arrays):
+        assert p.grad.data_ptr() == ptr                                # still the preallocated array: nothing was swapped in
+        _close(p.grad, q.grad, 1e-5 if not operand else 2e-3)          # (bias gradient: fp32 sums vs the 16-bit ones-row)
+    if not operand:
+        for step in range(2):
+            x = _rand(300, 512, seed=10 + step).detach()
+            cot = _rand(300, 256, seed=20 + step).detach()
+            F.linear(F.layer_norm(x, (512,), ref[2], ref[3]), ref[0], ref[1]).backward(cot)
+        for p, r in zip(sunk, ref):
+            _close(p.grad, r.grad, 3e-5)
