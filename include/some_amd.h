@@ -239,7 +239,8 @@ size_t some_train_gemm16_bytes(const SomeHandle* h, int32_t M, int32_t N, int32_
 int some_train_gemm16(SomeHandle* h, const float* A_dev, int32_t lda, int32_t ta, const float* B_dev, int32_t ldb, int32_t tb,
                       const float* bias_dev, float* C_dev, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t operand,
                       int32_t sum_col, void* partial_dev, size_t partial_bytes, void* stream);
-/* The weight gradient of nn.Linear written where it belongs: dW[N, K] (+)= dY[frames, N]^T X[frames, K] and, if db_dev, db[N] (+)= the
+/* The weight gradient of nn.Linear (what autograd computes for every Linear / k = 1 Conv1d of modules/conform/Gconform.py in
+ * training/me_task.py:79-111's backward pass) written where it belongs: dW[N, K] (+)= dY[frames, N]^T X[frames, K] and, if db_dev, db[N] (+)= the
  * fp32 column sums of dY - the (1, 1) layout of some_train_gemm16 with the slice reduction storing straight into the parameter-
  * gradient arrays (accumulate = 1: added to their contents, i.e. to the flat gradient buffer across micro-batches), so that no
  * intermediate tensor, slice copy or autograd accumulation launch remains.  partial_dev: some_train_gemm16_bytes(N, K, frames, K + 4). */
