@@ -287,7 +287,11 @@ __device__ __forceinline__ void epilogue_tr(const GemmArgs& a, const GemmGroup& 
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + (wm * TM + i) * 32 + l31;      // rows >= M lie past num_records: dropped by the hardware
+#ifdef GEMM_TR_MUL24             // diagnostic: 24-bit multiply (v_mad_u32_u24: no SGPR carry-out) instead of v_mad_u64_u32
+            const uint32_t vc = __umul24((uint32_t)m, row_c) + (uint32_t)hi * (OUT_SPLIT ? 32u : 64u);
+#else
             const uint32_t vc = (uint32_t)m * row_c + (uint32_t)hi * (OUT_SPLIT ? 32u : 64u);
+#endif
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -319,10 +323,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     const int m0 = a.m_begin + m_tile * BM, n0 = n_tile * BN;
     if (m0 >= a.M || n0 >= g.N) return;
 
-    // (the wavefront index is left lane-derived: forcing it into an SGPR with readfirstlane removes the 64 one-trip waterfall
-    // loops hipcc wraps around the row-per-lane epilogue's stores, cdna guide T20 - measured: no gain, 1.0002 vs 1.0005 ms, AND
-    // run-to-run different results at 32 x 30 s; profiles/r02_experiments.md)
-#ifdef GEMM_WAVE_SGPR_EPI        // diagnostic builds only (profiles/r02_experiments.md): SGPR wave index for the epilogues in the bit mask
+    // The wavefront index stays lane-derived.  Forcing it into an SGPR (readfirstlane; removes the 64 one-trip waterfall loops hipcc
+    // wraps around the row-per-lane epilogue's stores) measured no gain (1.0002 vs 1.0005 ms) AND made the results run-dependent.
+    // Root cause (round 3, profiles/r03_sgpr_epilogue_hazard.md): the column offset then becomes the SGPR soffset of the 16-byte
+    // stores, and hipcc schedules `buffer_store_dwordx4 v[158:161], ..., s13 offen` directly in front of a VALU instruction that
+    // rewrites v158 - LLVM exempts SGPR-soffset stores from the ">64-bit store data" wait state, gfx950 does not honour the
+    // exemption (the store sometimes writes the new value; `s_nop 1` behind the stores cures it).  tools/isa_hazard_scan.py keeps
+    // that form out of the shipped library (CPU test suite).
+#ifdef GEMM_WAVE_SGPR_EPI        // diagnostic builds only: SGPR wave index for the epilogues in the bit mask
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = ((GEMM_WAVE_SGPR_EPI >> EPI) & 1) ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
 #else
