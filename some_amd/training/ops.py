@@ -74,7 +74,8 @@ class TrainOps:
             self.on_grad_ready(param)
 
     def can_wgrad_into(self, N: int, K: int) -> bool:
-        return self.gemm16 and self.gemm_precision == 'f16x3' and N >= 32 and N % 2 == 0 and K % 4 == 0 and K >= 32
+        # N % 4: dY is read with ld = N and the C entry points require ld % 4 == 0 (16-byte rows) - N = 130 bins takes the transpose path
+        return self.gemm16 and self.gemm_precision == 'f16x3' and N >= 32 and N % 4 == 0 and K % 4 == 0 and K >= 32
 
     def gemm_dw_into(self, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor]):
         """dw [N, K] += dy^T x, db [N] += column sums of dy, straight into the gradient arrays (some_train_gemm16_wgrad)."""
@@ -187,7 +188,7 @@ class TrainOps:
             sc = self.scratch(M, K)
             self.check(self.lib.some_train_weighted_colsum(self.h, _p(dy), 1, _p(x), M, K, K, _p(out), _p(ws), _p(sc), sc.numel(), self.stream()))
             return out, (ws[:1].clone() if with_bias else None)
-        if self.gemm16 and self.gemm_precision == 'f16x3' and N >= 32 and N % 2 == 0 and K % 4 == 0 and K >= 32:
+        if self.can_wgrad_into(N, K):
             # dy [M, N] and x [M, K] are both contraction-major as they lie; the bias gradient is the fp32 column sum of dy,
             # accumulated in the kernel's staging registers into column K of the output
             ldc = K + (4 if with_bias else 0)

@@ -68,13 +68,16 @@ class MIDIExtractionTrainer:
         if self.world > 1 and config.get('some_amd_ddp_overlap', True):
             P = self.model.params
             order = [(P.views[k], P.offsets[k], (P.views[k].numel() + 63) // 64 * 64) for k in P.param_names]
-            self.grad_sync = BucketedGradSync(P.grad, order, process_group, int(config.get('some_amd_ddp_bucket_mb', 32)) << 20)
-        # Single process: nn.Linear / LayerNorm parameter gradients are written into the flat buffer by the backward kernels themselves
-        # (ops.py, gradient sinks: no per-parameter copy / accumulation launches).  Under data parallelism the parameters keep
-        # autograd's accumulation path: with sinks feeding BucketedGradSync.mark() the two-rank test's replicas diverged
-        # (tests/test_gpu_train_step.py, not yet understood), so that combination stays off.
-        if self.world == 1:
-            self.ops.register_grad_sinks(self.model.params.views.values(), None)
+            self.grad_sync = BucketedGradSync(P.grad, order, process_group, int(config.get('some_amd_ddp_bucket_mb', 32)) << 20,
+                                              names=list(P.param_names))
+        # Gradient sinks: nn.Linear / LayerNorm parameter gradients are written into the flat buffer by the backward kernels themselves
+        # (ops.py: no per-parameter copy / accumulation launches).  Under data parallelism each deposit is reported to the bucketed
+        # sync through mark().  (Round 2 kept sinks off for world > 1 because the replicas diverged: autograd fires a parameter's
+        # post-accumulate hook even when backward returned None for it, so mark() + hook counted every sunk parameter twice and buckets
+        # were all-reduced when half of their gradients were in the buffer.  BucketedGradSync now ignores that echo and raises on any
+        # other double report - tests/test_train_host.py::test_gradient_sync_mark_stands_in_for_the_hook.)
+        if config.get('some_amd_grad_sinks', True):
+            self.ops.register_grad_sinks(self.model.params.views.values(), self.grad_sync.mark if self.grad_sync is not None else None)
 
     # ---- me_task.py:79-111 ------------------------------------------------------------------------------------
     def run_model(self, sample: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

@@ -602,7 +602,7 @@ def test_fullsize_batch_vs_reference_golden(golden_dir, name, precision):
     Every clip sits at four batch positions.  Gates: |d probs|, |d bounds| < 1e-4 (north star) at every position;
     the reference's own probs / bounds through the GPU decoder give the reference's notes bit for bit; end-to-end
     (waveform -> notes) note boundaries may differ from the reference's only where a bound cumsum sits within the
-    logit tolerance of a rounding boundary: bounded at 1 % of the boundaries, reported."""
+    logit tolerance of a rounding boundary: bounded at 0.1 % of the boundaries, reported."""
     from some_amd import _lib
     from some_amd.engine import ClipBatch, Engine
     meta = json.loads((golden_dir / 'fullsize.json').read_text())[name]
@@ -651,7 +651,9 @@ def test_fullsize_batch_vs_reference_golden(golden_dir, name, precision):
           f'reference end to end: {n_bound_diff} of {n_bound_ref} ({100.0 * n_bound_diff / n_bound_ref:.3f} %), '
           f'{n_identical}/32 clips with an identical duration sequence, max |d note_midi| on those {midi_err:.2e}')
     assert err_p < LOGIT_TOL and err_b < LOGIT_TOL
-    assert n_bound_diff <= 0.01 * n_bound_ref
+    # measured (round 2 / 3, log kept in profiles/r03_fullsize_parity_log.txt): f16x3 14 of 50 724 (0.028 %) and 14 of 33 748 (0.041 %), f32 0;
+    # the gate leaves a factor of ~3 for other seeds' rounding-boundary luck, not a factor of 30
+    assert n_bound_diff <= 0.001 * n_bound_ref
     # identical inputs -> identical notes at full size: the reference's probs / bounds of clip 0 through the GPU decoder
     k = f'{name}.clip0'
     d0 = eng.decode(torch.from_numpy(g[k + '.probs']).cuda(), torch.from_numpy(g[k + '.bounds']).cuda(), ClipBatch([T], 'cuda'), quantized=quant)

@@ -47,7 +47,8 @@ def _pair(fn_mine, fn_ref, inputs, tol=2e-5, seed=99):
 
 
 @pytest.mark.parametrize('M,K,N,bias', [(300, 512, 2048, True), (70, 80, 512, True), (129, 512, 1, True), (33, 2048, 512, True),
-                                         (257, 512, 1536, False), (1, 512, 128, True)])
+                                         (257, 512, 1536, False), (1, 512, 128, True),
+                                         (300, 512, 130, True), (300, 512, 129, True)])      # N % 4 != 0 (e.g. 130 / 129 bins): transpose + split-K weight-gradient path
 def test_linear(ops, M, K, N, bias):
     x, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
     b = _rand(N, seed=3) if bias else None

@@ -201,16 +201,41 @@ for skip_last in (False, True):
     want_two = local_two.clone()
     dist.all_reduce(want_two)
     assert torch.equal(grad, want_two), (grad - want_two).abs().max()
-    # last layers first: buckets complete in descending order while backward runs; a bucket whose parameters got no gradient
-    # (skip_last) is only sent by finish()
-    assert launched_in_backward == sorted(launched_in_backward, reverse=True) and len(launched_in_backward) >= 3
-    assert (len(launched_in_backward) < len(sync.bounds)) == skip_last
-    assert sorted(sync.launch_order) == list(range(len(sync.bounds)))
+    # last layers first, in a FIXED descending order (collectives pair up across ranks by issue order): bucket k leaves only after
+    # every bucket above it.  The first pass in which the top bucket's parameters get no gradient (skip_last) therefore sends
+    # everything from finish(); the parameters are then known to be absent and the next pass overlaps again.
+    assert launched_in_backward == sorted(launched_in_backward, reverse=True)
+    assert len(launched_in_backward) == (0 if skip_last else len(sync.bounds))
+    assert sync.launch_order == list(reversed(range(len(sync.bounds))))
+    assert sync.unreported() == (['param6', 'param7'] if skip_last else [])
     grad.zero_()
     sync.arm()
     loss_fn(skip_last).backward()
+    in_backward = list(sync.launch_order)
     sync.finish()
     assert torch.equal(grad, want)
+    assert len(in_backward) >= 3 and sync.launch_order == list(reversed(range(len(sync.bounds))))
+# a parameter counted as absent that reports after all (skip_last -> full model): its gradient is in the buffer before its bucket
+# leaves - correct result, and it is no longer absent afterwards
+grad.zero_()
+loss_fn(False).backward()
+want = grad.clone()
+dist.all_reduce(want)
+assert sync.absent == {6, 7}
+grad.zero_()
+sync.arm()
+loss_fn(False).backward()
+sync.finish()
+assert torch.equal(grad, want) and sync.absent == set()
+# a parameter that reports twice in one armed pass raises instead of launching its bucket early
+sync.arm()
+sync.mark(views[7])
+try:
+    sync.mark(views[7])
+    raise SystemExit('second report must raise')
+except RuntimeError as e:
+    assert 'twice' in str(e)
+sync.finish()
 try:
     sync.finish()
     raise SystemExit('finish() without arm() must raise')
@@ -281,7 +306,7 @@ class SinkLinear(torch.autograd.Function):
             with torch.no_grad():
                 ctx.wp.grad += dw
                 ctx.bp.grad += db
-            sync.mark(ctx.wp); sync.mark(ctx.bp)
+            active.mark(ctx.wp); active.mark(ctx.bp)
             return dx, None, None, None
         return dx, dw, db, None
 
@@ -291,17 +316,27 @@ def loss_fn(sink_layers):
         x = SinkLinear.apply(x, views[i], views[i + 1], (i // 2) in sink_layers)
     return (x * x).sum()
 
-for sink_layers in [(), (0, 1, 2, 3), (0, 2), (1, 3), (3,)]:
-    grad.zero_()
-    loss_fn(()).backward()
-    want = grad.clone(); dist.all_reduce(want)
-    grad.zero_()
-    sync.arm()
-    loss_fn(sink_layers).backward()
-    order = list(sync.launch_order)
-    sync.finish()
-    assert torch.equal(grad, want), (sink_layers, float((grad - want).abs().max()))
-    assert order == sorted(order, reverse=True) and len(order) >= 3, order          # still launched from inside backward, last layers first
+# `wide`: two layers (four parameters) per bucket - the shape that exposed round 2's bug: autograd fires a parameter's
+# post-accumulate hook even when the backward function returned None for it, so a marked parameter used to be counted twice and a
+# bucket left when HALF of its gradients were in the buffer (layer 3 marked twice -> bucket {2, 3} sent before layer 2's backward)
+wide = BucketedGradSync(grad, [(p, off, n) for p, off, n in zip(views, offs, sizes)], None, bucket_bytes=9000 * 4)
+assert wide.bounds == [(0, 8320), (8320, 16640)]
+for which in (sync, wide):
+    active = which
+    for sink_layers in [(), (0, 1, 2, 3), (0, 2), (1, 3), (3,)]:
+        grad.zero_()
+        loss_fn(()).backward()
+        want = grad.clone(); dist.all_reduce(want)
+        grad.zero_()
+        which.arm()
+        loss_fn(sink_layers).backward()
+        order = list(which.launch_order)
+        fired = list(which.fire_order)
+        which.finish()
+        assert torch.equal(grad, want), (sink_layers, float((grad - want).abs().max()))
+        assert order == list(reversed(range(len(which.bounds)))), order              # every bucket launched from inside backward, last layers first
+        assert sorted(fired) == list(range(8)) and which.unreported() == []          # every parameter counted exactly once
+        assert sum(which.echoed) == 2 * len(sink_layers)                             # the hooks behind the marks were seen and ignored
 dist.barrier(); dist.destroy_process_group()
 print('ok', rank)
 '''
@@ -311,8 +346,9 @@ def test_gradient_sync_mark_stands_in_for_the_hook(tmp_path):
     """BucketedGradSync.mark(param): a backward function that writes a parameter's gradient into the flat buffer itself and returns
     None for it (TrainOps' gradient sinks) reports the parameter through mark() instead of autograd's post-accumulate hook.  gloo,
     world size 2, CPU: any mix of marked and autograd-accumulated parameters - also inside one bucket - gives the single all-reduce
-    result bit for bit, buckets still go out during backward.  (On the GPU the trainer nevertheless keeps data-parallel runs on the
-    hook path: with sinks the two-rank replicas diverged there - the counting logic pinned here is not the cause.)"""
+    result bit for bit, buckets still go out during backward.  Pins the root cause of round 2's diverging replicas: autograd fires
+    the post-accumulate hook of a parameter even when backward returned None for it, so mark() + hook used to count twice; with several
+    layers per bucket (`wide`) the bucket then left before all its gradients were written."""
     import os
     import pathlib
     import socket
