@@ -14,6 +14,7 @@ Usage:  python oracle/make_golden.py            (from the repo root)
 """
 import importlib.util
 import json
+import os
 import pathlib
 import sys
 import types
@@ -23,7 +24,7 @@ import torch
 
 REPO = pathlib.Path(__file__).resolve().parents[1]
 REF = pathlib.Path('/root/reference')
-OUT = REPO / 'tests' / 'golden'
+OUT = pathlib.Path(os.environ['SOME_GOLDEN_OUT']) if os.environ.get('SOME_GOLDEN_OUT') else REPO / 'tests' / 'golden'   # override: regenerate elsewhere and diff
 
 sys.path.insert(0, str(REF))          # reference packages win name clashes (modules/, utils/, inference/)
 sys.path.append(str(REPO))
@@ -517,6 +518,12 @@ def _ref_training_utils():
         top.pytorch, pl.callbacks, pl.utilities, ut.rank_zero = pl, cb, ut, rz
         sys.modules.update({'lightning': top, 'lightning.pytorch': pl, 'lightning.pytorch.callbacks': cb,
                             'lightning.pytorch.utilities': ut, 'lightning.pytorch.utilities.rank_zero': rz})
+    # earlier generators (gen_batch_infer_fns / gen_batch_csv / gen_deploy) leave bare stub modules named `utils`, `utils.*` and
+    # `inference` in sys.modules ("'utils' is not a package" when the whole file runs in one process): drop every such entry that
+    # is not the reference's own file before importing the real package
+    for name in [n for n in sys.modules if n == 'utils' or n.startswith('utils.') or n == 'inference']:
+        if str(REF) not in str(getattr(sys.modules[name], '__file__', None) or ''):
+            del sys.modules[name]
     import utils.training_utils as tu          # the reference's (REF is first on sys.path)
     assert str(REF) in tu.__file__
     return tu

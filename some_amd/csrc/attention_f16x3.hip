@@ -27,33 +27,14 @@ constexpr int LDR = 68;                         // LDS row (dwords): 64 data + 4
 constexpr int K_DW = KT * LDR;                  // K tile: [64 keys][hi|lo hi|lo]
 constexpr int V_DW = kHeadDim * LDR;            // V^T tile: [64 d][64 keys hi | 64 keys lo]
 constexpr size_t LDS_BYTES = 2 * (K_DW + V_DW) * sizeof(float);
-#ifndef ATTN_LAZY_RESCALE
-#define ATTN_LAZY_RESCALE 0
-#endif
-constexpr float kLazy = 8.f;                    // lazy rescale threshold (log2 domain)
-constexpr float kPShift = ATTN_LAZY_RESCALE ? 14.f - kLazy : 14.f;   // P is carried as 2^kPShift p <= 2^14 (see softmax)
+constexpr float kPShift = 14.f;                 // P is carried as 2^kPShift p <= 2^14 (see softmax)
 
 __device__ __forceinline__ float exp2_(float x) { return __builtin_amdgcn_exp2f(x); }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-
-#ifndef ATTN_PIN_STAGING
-#define ATTN_PIN_STAGING 0
-#endif
-#ifndef ATTN_V_BUFFER
-#define ATTN_V_BUFFER 1         // V^T tiles through buffer loads with a scalar tile offset (inference kernels)
-#endif
-#ifndef ATTN_WAVE_SGPR
-#define ATTN_WAVE_SGPR 0        // 1: wavefront index as an SGPR (readfirstlane)
-#endif
-#ifndef ATTN_SETPRIO
-#define ATTN_SETPRIO 1          // 1: raised wave priority over the PV product (pure MFMA + LDS reads; measured -3 % together with
-                                // -fno-slp-vectorize, which also frees the registers the flips would otherwise spill), 2: over QK + softmax (+1 %), 0: off
-#endif
-#ifndef ATTN_PACKED_F32
-#define ATTN_PACKED_F32 0       // softmax / P split on v_pk_fma_f32 / v_pk_add_f32 (0: scalar fp32 VALU)
-#endif
+// Measured and not kept (profiles/r02_experiments.md; the switches live in the git history, not in the shipped source): lazy rescale
+// (2.59 vs 2.53 ms), packed-fp32 softmax (2.59), global loads pinned to the head of the step (noise), 64 queries per wavefront at
+// one wavefront per SIMD (3.21 vs 2.62), priority over QK + softmax instead of PV (+1 %).  Kept: V^T tiles through buffer loads,
+// s_setprio 1 over the PV product, scalar fp32 softmax arithmetic (-fno-slp-vectorize, build.py).
 
 // v_max3_f32 without the v_max_f32 x, x, x canonicalisation clang puts in front of every fmaxf operand (scores are
 // MFMA results or -inf, never signalling NaNs)
@@ -75,14 +56,8 @@ __device__ __forceinline__ void split8(const f32x16& p, int base, half8& h, half
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
         const float p0 = p[base + i], p1 = p[base + i + 1];      // (scalars: bit_cast of a vector element miscompiles)
-#if ATTN_PACKED_F32
-        const f32x2 pp = {p0, p1};
-        const f32x2 hf = {__uint_as_float(__float_as_uint(p0) & 0xFFFFE000u), __uint_as_float(__float_as_uint(p1) & 0xFFFFE000u)};
-        const f32x2 lf = pp - hf;
-#else
         const float hf[2] = {__uint_as_float(__float_as_uint(p0) & 0xFFFFE000u), __uint_as_float(__float_as_uint(p1) & 0xFFFFE000u)};
         const float lf[2] = {p0 - hf[0], p1 - hf[1]};
-#endif
         const half2_t hh = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(hf[0], hf[1]));
         const half2_t ll = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(lf[0], lf[1]));
         h[i] = hh[0]; h[i + 1] = hh[1];
@@ -99,12 +74,10 @@ __device__ __forceinline__ void split8_bf16(const f32x16& p, int base, half8& h)
 // TRAIN = true: the training forward (train_api: some_train_attention_fwd_f16x3) - Q / K rows come straight from
 // split_rows(qkv) (row stride 6144 B), V^T from transpose(qkv, split) (SPLIT32 over frames: 32-frame blocks [32 hi | 32 lo]),
 // the output is fp32 and the base-2 log-sum-exp is stored for the backward.
-// QT = query tiles (of 32) per wavefront.  QT = 1: 128 queries per workgroup, two workgroups per CU (two wavefronts per SIMD
-// cover each other's stalls).  QT = 2: 256 queries per workgroup, ONE wavefront per SIMD with the 512-register budget -
-// every K / V^T fragment read from LDS feeds two MFMA column tiles, staging traffic and barriers per MFMA halve.
-template <bool TRAIN, int TERMS = 3, int QT = 1, bool BF16 = false>      // BF16: bf16 hi halves, TERMS = 1 only (split.h)
-__global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3Args a, int nqb) {
-    constexpr int QB = 128 * QT;
+// 128 queries per workgroup (32 per wavefront), two workgroups per CU: two wavefronts per SIMD cover each other's stalls.
+template <bool TRAIN, int TERMS = 3, bool BF16 = false>      // BF16: bf16 hi halves, TERMS = 1 only (split.h)
+__global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb) {
+    constexpr int QB = 128;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int slot = jj / nqb, qb = jj % nqb;
@@ -117,7 +90,7 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
     const int q0 = qb * QB;
     if (q0 >= T) return;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = ATTN_WAVE_SGPR ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
     constexpr size_t ROW_B = TRAIN ? 6144 : 2048;       // bytes between consecutive frames of Q / K
     const char* __restrict__ Qp = reinterpret_cast<const char*>(a.q[g]) + head * 256;
@@ -126,20 +99,19 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
     const char* __restrict__ Vl = Vh + (size_t)kDim * a.ldv * 2;                          // (planes format only)
 
     // ---- Q fragments (B operand of S^T): slab s covers d = 16 s .. 16 s + 15; lane half kg holds 8 of them
-    half8 qh[QT][4], ql[QT][4];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        const int q = q0 + (wave * QT + t) * 32 + l31;
+    half8 qh[4], ql[4];
+    {
+        const int q = q0 + wave * 32 + l31;
         const bool qv = q < T;
         const char* row = Qp + (size_t)(f0 + (qv ? q : 0)) * ROW_B;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int off = (s >> 1) * 128 + (s & 1) * 32 + kg * 16;
-            qh[t][s] = *reinterpret_cast<const half8*>(row + off);
-            ql[t][s] = *reinterpret_cast<const half8*>(row + off + 64);
+            qh[s] = *reinterpret_cast<const half8*>(row + off);
+            ql[s] = *reinterpret_cast<const half8*>(row + off + 64);
             if (!qv) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { qh[t][s][i] = (half_t)0; ql[t][s][i] = (half_t)0; }
+                for (int i = 0; i < 8; ++i) { qh[s][i] = (half_t)0; ql[s][i] = (half_t)0; }
             }
         }
     }
@@ -169,7 +141,7 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
         voff_v[p] = (uint32_t)(srow + 16 * p) * (uint32_t)a.ldv * 2u + (uint32_t)(sc & 7) * 16u + (sc < 8 ? 0u : (uint32_t)kDim * (uint32_t)a.ldv * 2u);
     auto gload_v = [&](int i) {
         const int g0 = (gt0 + i) * KT;
-        if constexpr (!TRAIN && ATTN_V_BUFFER) {
+        if constexpr (!TRAIN) {
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 rv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, voff_v[p], (uint32_t)g0 * 2u, 0));
@@ -197,11 +169,9 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
     };
 
     // S^T = K Q^T (raw, unscaled) for tile i, both 32-key sub-tiles, then -inf outside the clip
-    auto qk = [&](int i, f32x16 (&s0)[QT], f32x16 (&s1)[QT]) {
+    auto qk = [&](int i, f32x16& s0, f32x16& s1) {
 #pragma unroll
-        for (int t = 0; t < QT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s0[t][r] = 0.f; s1[t][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
         const float* kp = kbuf(i) + l31 * LDR + kg * 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -211,52 +181,35 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
             const half8 kh1 = *reinterpret_cast<const half8*>(kp + 32 * LDR + off);
             const half8 kl1 = *reinterpret_cast<const half8*>(kp + 32 * LDR + off + 16);
             if (TERMS == 3) {
-#pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    s0[t] = mfma_hi<BF16>(kl0, qh[t][s], s0[t]);
-                    s1[t] = mfma_hi<BF16>(kl1, qh[t][s], s1[t]);
-                }
-#pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    s0[t] = mfma_hi<BF16>(kh0, ql[t][s], s0[t]);
-                    s1[t] = mfma_hi<BF16>(kh1, ql[t][s], s1[t]);
-                }
+                s0 = mfma_hi<BF16>(kl0, qh[s], s0);
+                s1 = mfma_hi<BF16>(kl1, qh[s], s1);
+                s0 = mfma_hi<BF16>(kh0, ql[s], s0);
+                s1 = mfma_hi<BF16>(kh1, ql[s], s1);
             }
-#pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                s0[t] = mfma_hi<BF16>(kh0, qh[t][s], s0[t]);
-                s1[t] = mfma_hi<BF16>(kh1, qh[t][s], s1[t]);
-            }
+            s0 = mfma_hi<BF16>(kh0, qh[s], s0);
+            s1 = mfma_hi<BF16>(kh1, qh[s], s1);
         }
     };
-    auto mask_tile = [&](int i, f32x16 (&s0)[QT], f32x16 (&s1)[QT]) {
+    auto mask_tile = [&](int i, f32x16& s0, f32x16& s1) {
         const int gbase = (gt0 + i) * KT;
         if (gbase < f0 || gbase + KT > f0 + T) {          // first and last global tile only
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k0 = gbase + (r & 3) + 8 * (r >> 2) + 4 * kg;
-#pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    if (k0 < f0 || k0 >= f0 + T) s0[t][r] = -INFINITY;
-                    if (k0 + 32 < f0 || k0 + 32 >= f0 + T) s1[t][r] = -INFINITY;
-                }
+                if (k0 < f0 || k0 >= f0 + T) s0[r] = -INFINITY;
+                if (k0 + 32 < f0 || k0 + 32 >= f0 + T) s1[r] = -INFINITY;
             }
         }
     };
 
-    f32x16 o0[QT], o1[QT];
-    float m_run[QT], l_run[QT];
+    f32x16 o0, o1;
 #pragma unroll
-    for (int t = 0; t < QT; ++t) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[t][r] = 0.f; o1[t][r] = 0.f; }
-        m_run[t] = -INFINITY;
-        l_run[t] = 0.f;
-    }
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
     const float c = 0.125f * 1.4426950408889634f;       // head_dim^-0.5 * log2(e)
 
     // online softmax of one tile's scores (lane = query; scale folded into the exponent): s0/s1 become P
-    auto softmax1 = [&](f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m_run, float& l_run) {
+    auto softmax = [&](f32x16& s0, f32x16& s1) {
         float mxa = max2_(s0[0], s1[0]), mxb = max2_(s0[1], s1[1]);
 #pragma unroll
         for (int r = 2; r < 16; r += 2) {
@@ -265,41 +218,11 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
         }
         float mx = max2_(mxa, mxb);
         mx = max2_(mx, __shfl_xor(mx, 32, 64));
-#if ATTN_LAZY_RESCALE
-        // cdna guide T13: the running maximum only moves (and O, l are only rescaled) when some query's tile maximum
-        // exceeds it by more than 2^kLazy; until then p may reach 2^kLazy (kPShift leaves that headroom in f16)
-        const float ms = mx * c;
-        if (!__all(ms - m_run <= kLazy)) {
-            const float m_up = max2_(m_run, ms);
-            const float alpha = exp2_(m_run - m_up);    // first tile: exp2(-inf) = 0
-            m_run = m_up;
-            l_run *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        }
-        const float m_new = m_run;
-        const float alpha = 1.f;
-#else
         const float m_new = max2_(m_run, mx * c);      // finite: every tile holds at least one key of the clip
         const float alpha = exp2_(m_run - m_new);       // first tile: exp2(-inf) = 0
         m_run = m_new;
-#endif
         // probabilities are kept scaled by 2^kPShift (<= 16384, inside f16): keys far below the running maximum
         // stay out of the f16 subnormal range when P is split; the scale cancels in O / l
-#if ATTN_PACKED_F32
-        const f32x2 c2 = {c, c}, nm2 = {kPShift - m_new, kPShift - m_new};
-        f32x2 ps = {0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const f32x2 t0 = __builtin_elementwise_fma(f32x2{s0[r], s0[r + 1]}, c2, nm2);
-            const f32x2 t1 = __builtin_elementwise_fma(f32x2{s1[r], s1[r + 1]}, c2, nm2);
-            const f32x2 e0 = {exp2_(t0[0]), exp2_(t0[1])};
-            const f32x2 e1 = {exp2_(t1[0]), exp2_(t1[1])};
-            s0[r] = e0[0]; s0[r + 1] = e0[1];
-            s1[r] = e1[0]; s1[r + 1] = e1[1];
-            ps += e0 + e1;
-        }
-#else
         const float nm = kPShift - m_new;
         float ps[2] = {0.f, 0.f};
 #pragma unroll
@@ -308,31 +231,21 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
             s1[r] = exp2_(fmaf(s1[r], c, nm));
             ps[r & 1] += s0[r] + s1[r];
         }
-#endif
         l_run = l_run * alpha + (ps[0] + ps[1]);
-#if !ATTN_LAZY_RESCALE
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-#endif
-    };
-    auto softmax = [&](f32x16 (&s0)[QT], f32x16 (&s1)[QT]) {
-#pragma unroll
-        for (int t = 0; t < QT; ++t) softmax1(s0[t], s1[t], o0[t], o1[t], m_run[t], l_run[t]);
     };
     // O^T += V^T P^T for tile i.  P slab (sub, s'): registers r = 8 s' .. 8 s' + 7 of the sub-tile hold keys
     // 16 s' + {0..3} + 4 kg and 16 s' + 8 + {0..3} + 4 kg  ->  two ds_read_b64 per V^T fragment
-    auto pv = [&](int i, const f32x16 (&s0)[QT], const f32x16 (&s1)[QT]) {
+    auto pv = [&](int i, const f32x16& s0, const f32x16& s1) {
         const float* vp = vbuf(i) + l31 * LDR + (TRAIN ? 2 : 4) * kg;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
-                half8 ph[QT], pl[QT];
-#pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    if constexpr (BF16) split8_bf16(sub == 0 ? s0[t] : s1[t], 8 * sp, ph[t]);
-                    else split8(sub == 0 ? s0[t] : s1[t], 8 * sp, ph[t], pl[t]);
-                }
+                half8 ph, pl;
+                if constexpr (BF16) split8_bf16(sub == 0 ? s0 : s1, 8 * sp, ph);
+                else split8(sub == 0 ? s0 : s1, 8 * sp, ph, pl);
                 // dword offset of key 32 sub + 16 s' and of its lo half: row = [64 hi | 64 lo] (planes) or
                 // [32 hi | 32 lo][32 hi | 32 lo] (SPLIT32 over frames)
                 constexpr int LO = TRAIN ? 16 : 32;
@@ -363,22 +276,13 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (TERMS == 3) {
-#pragma unroll
-                    for (int t = 0; t < QT; ++t) {
-                        o0[t] = mfma_hi<BF16>(vl0, ph[t], o0[t]);
-                        o1[t] = mfma_hi<BF16>(vl1, ph[t], o1[t]);
-                    }
-#pragma unroll
-                    for (int t = 0; t < QT; ++t) {
-                        o0[t] = mfma_hi<BF16>(vh0, pl[t], o0[t]);
-                        o1[t] = mfma_hi<BF16>(vh1, pl[t], o1[t]);
-                    }
+                    o0 = mfma_hi<BF16>(vl0, ph, o0);
+                    o1 = mfma_hi<BF16>(vl1, ph, o1);
+                    o0 = mfma_hi<BF16>(vh0, pl, o0);
+                    o1 = mfma_hi<BF16>(vh1, pl, o1);
                 }
-#pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    o0[t] = mfma_hi<BF16>(vh0, ph[t], o0[t]);
-                    o1[t] = mfma_hi<BF16>(vh1, ph[t], o1[t]);
-                }
+                o0 = mfma_hi<BF16>(vh0, ph, o0);
+                o1 = mfma_hi<BF16>(vh1, ph, o1);
             }
         }
     };
@@ -393,8 +297,8 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
     if (n > 1) { gload_k(1); lstore_k(1); gload_v(1); }
     if (n > 2) gload_k(2);
     __syncthreads();
-    f32x16 sa0[QT], sa1[QT], sb0[QT], sb1[QT];        // scores of even / odd tiles (ping-pong: no register copies)
-    auto step = [&](int i, f32x16 (&c0)[QT], f32x16 (&c1)[QT], f32x16 (&n0)[QT], f32x16 (&n1)[QT]) {
+    f32x16 sa0, sa1, sb0, sb1;        // scores of even / odd tiles (ping-pong: no register copies)
+    auto step = [&](int i, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
         if (i + 2 < n) lstore_k(i + 2);               // K ring slot i & 1: last read by QK(i) in the previous step
         lstore_v(i + 1);                              // V ring slot (i+1) & 1: last read by PV(i-1)
         if (i + 3 < n) gload_k(i + 3);
@@ -407,28 +311,16 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
     };
     // the same step for interior tiles (i + 3 < n): nothing conditional, tile i + 1 needs no masking - ONE basic block,
     // so the scheduler is free to spread the staging traffic and the fragment reads between the MFMAs
-    auto step_full = [&](int i, f32x16 (&c0)[QT], f32x16 (&c1)[QT], f32x16 (&n0)[QT], f32x16 (&n1)[QT]) {
+    auto step_full = [&](int i, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
         lstore_k(i + 2);
         lstore_v(i + 1);
         gload_k(i + 3);
         gload_v(i + 2);
-#if ATTN_PIN_STAGING
-        __builtin_amdgcn_sched_barrier(0);            // keep the global loads at the head (hipcc sinks them to the barrier)
-#endif
-#if ATTN_SETPRIO == 2
-        __builtin_amdgcn_s_setprio(1);
-#endif
         qk(i + 1, n0, n1);
         softmax(c0, c1);
-#if ATTN_SETPRIO == 2
+        __builtin_amdgcn_s_setprio(1);                // raised priority over the PV product (pure MFMA + LDS reads): -3 % with
+        pv(i, c0, c1);                                // -fno-slp-vectorize, which also frees the registers the flips would spill
         __builtin_amdgcn_s_setprio(0);
-#elif ATTN_SETPRIO == 1
-        __builtin_amdgcn_s_setprio(1);
-#endif
-        pv(i, c0, c1);
-#if ATTN_SETPRIO == 1
-        __builtin_amdgcn_s_setprio(0);
-#endif
         __syncthreads();
     };
     qk(0, sa0, sa1);
@@ -460,23 +352,21 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
 
     // ---- normalise, transpose through LDS (wave-private 32 x 64 patch), SPLIT32 row stores
     float* patch = lds + wave * (32 * LDR);
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32, 64);
+    {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
-        if (t > 0) __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = (r & 3) + 8 * (r >> 2) + 4 * kg;
-            patch[l31 * LDR + d] = o0[t][r] * inv;
-            patch[l31 * LDR + 32 + d] = o1[t][r] * inv;
+            patch[l31 * LDR + d] = o0[r] * inv;
+            patch[l31 * LDR + 32 + d] = o1[r] * inv;
         }
         __syncthreads();
         const int orow = lane >> 4, ocol = (lane & 15) * 4;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int ql_ = orow + 4 * p;
-            const int q = q0 + (wave * QT + t) * 32 + ql_;
+            const int q = q0 + wave * 32 + ql_;
             if (q < T) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(patch + ql_ * LDR + ocol);
                 if (TRAIN) {
@@ -493,8 +383,8 @@ __global__ __launch_bounds__(256, QT == 1 ? 2 : 1) void attention3_kernel(Attn3A
             }
         }
         if (TRAIN && kg == 0) {       // P was carried as 2^kPShift p: lse2 = max + log2(sum p)
-            const int q = q0 + (wave * QT + t) * 32 + l31;
-            if (q < T) a.lse[g][(size_t)head * a.M + f0 + q] = m_run[t] + __log2f(l_tot) - kPShift;
+            const int q = q0 + wave * 32 + l31;
+            if (q < T) a.lse[g][(size_t)head * a.M + f0 + q] = m_run + __log2f(l_tot) - kPShift;
         }
     }
 }
@@ -512,27 +402,18 @@ hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<true, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<false, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    // The wide variant (QT = 2: 256 queries per workgroup, one wavefront per SIMD, 488 registers) measured SLOWER with a
-    // compiler-scheduled stream (32 x 2584 frames: 3.21 vs 2.62 ms - without a partner wavefront every LDS / barrier
-    // wait idles the matrix pipe); it stays selectable for A/B runs with SOME_AMD_ATTN_QT=2, the default is QT = 1.
-    static int force_qt = -1;
-    if (force_qt < 0) { const char* e = getenv("SOME_AMD_ATTN_QT"); force_qt = e ? atoi(e) : 0; }
     const bool inference = a.out32[0] == nullptr;
-    const int qt = (inference && force_qt == 2) ? 2 : 1;
-    const int QB = 128 * qt;
+    constexpr int QB = 128;
     const int nqb = (a.max_frames + QB - 1) / QB;
     const int units = a.B * kHeads * a.groups;
     const int slots = (units + 7) / 8;
-    if (!inference && a.hi_only == 2) hipLaunchKernelGGL((attention3_kernel<true, 1, 1, true>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    if (!inference && a.hi_only == 2) hipLaunchKernelGGL((attention3_kernel<true, 1, true>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else if (!inference && a.hi_only) hipLaunchKernelGGL((attention3_kernel<true, 1>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else if (!inference) hipLaunchKernelGGL(attention3_kernel<true>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
-    else if (qt == 2) hipLaunchKernelGGL((attention3_kernel<false, 3, 2>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else hipLaunchKernelGGL(attention3_kernel<false>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     return hipGetLastError();
 }

@@ -61,8 +61,13 @@ def test_full_size_forward_is_bit_stable_across_repeats_and_launch_groupings(pre
             probs, bounds = eng.forward(units, batch, head_mode=_lib.HEAD_SIGMOID)
             dec = eng.decode(probs, bounds, batch, quantized=False)
             torch.cuda.synchronize()
-            got = (units.clone(), probs.clone(), bounds.clone(), dec['n_notes'].clone(), dec['note_dur'].clone(), dec['note_midi'].clone(),
-                   dec['note_rest'].clone())
+            # note arrays are packed per clip at its frame offset; entries behind a clip's n_notes are never written
+            n = dec['n_notes'].to(torch.int64)
+            pos = torch.arange(batch.total_frames, device='cuda')
+            clip = torch.repeat_interleave(torch.arange(batch.B, device='cuda'), torch.from_numpy(np.asarray(batch.frame_counts)).cuda().to(torch.int64))
+            valid = pos - batch.frame_offsets_dev.to(torch.int64)[clip] < n[clip]
+            got = (units.clone(), probs.clone(), bounds.clone(), dec['n_notes'].clone(), dec['note_dur'][valid].clone(),
+                   dec['note_midi'][valid].clone(), dec['note_rest'][valid].clone())
             if ref is None:
                 ref = got
             else:

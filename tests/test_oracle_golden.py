@@ -168,3 +168,24 @@ def test_mel_filterbank_analytic_properties():
         assert abs(fb[m, k] - 2.0 / (hi - lo) * (1 - abs(freqs[k] - c) / (c - lo if freqs[k] < c else hi - c))) < 1e-9 + 1e-6 * fb[m, k]
         if hi - lo > 8 * df:
             assert abs(fb[m].sum() * df - 1.0) < 0.05                            # unit area
+
+
+@pytest.mark.skipif(not __import__('pathlib').Path('/root/reference/utils/training_utils.py').exists(),
+                    reason='the reference tree is mounted in the build container only')
+def test_golden_recipe_reproduces_committed_fixtures_in_one_process(tmp_path, golden_dir):
+    """oracle/make_golden.py is ONE command: the generators that leave stub `utils` / `inference` modules behind
+    (gen_batch_infer_fns, gen_batch_csv, gen_deploy) followed by gen_samplers - which imports the reference's real `utils`
+    package - in the same process (round 2: "'utils' is not a package"), and what they write is byte-identical to the
+    committed fixtures.  The cheap generators only; the whole file was re-run the same way in round 3 (20 files, 0 differ)."""
+    import os
+    import subprocess
+    import sys
+    root = __import__('pathlib').Path(__file__).resolve().parents[1]
+    names = ['gen_batch_infer_fns', 'gen_batch_csv', 'gen_deploy', 'gen_samplers', 'gen_lr_schedule', 'gen_midi_msgs', 'gen_slicer']
+    r = subprocess.run([sys.executable, str(root / 'oracle' / 'make_golden.py')] + names, env=dict(os.environ, SOME_GOLDEN_OUT=str(tmp_path)),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    made = sorted(p.name for p in tmp_path.iterdir() if p.is_file())
+    assert len(made) >= 7, made
+    for name in made:
+        assert (tmp_path / name).read_bytes() == (golden_dir / name).read_bytes(), name
