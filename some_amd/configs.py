@@ -108,3 +108,17 @@ def get_config(name: str, **overrides) -> dict:
 
 def config_names():
     return sorted(_CONFIGS)
+
+
+def builtin_yaml(path):
+    """The built-in configs are addressable under the reference's file names: ``configs/base.yaml`` -> the shared keys,
+    ``configs/<name>.yaml`` -> the flattened built-in config - so ``python train.py --config configs/two_head_model.yaml`` and a
+    user's own file with ``base_config: configs/two_head_model.yaml`` work in a checkout that carries no YAML files.  Returns None
+    for any other path (the caller raises: there is no silent fallback to some default model)."""
+    import pathlib
+    p = pathlib.Path(path)
+    if p.suffix not in ('.yaml', '.yml') or p.parent.name != 'configs':
+        return None
+    if p.stem == 'base':
+        return copy.deepcopy(_BASE)
+    return get_config(p.stem) if p.stem in _CONFIGS else None

@@ -728,10 +728,16 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
         if (dual) {
             HIP_TRY(h, hipEventRecord(aux->fork, s));
             HIP_TRY(h, hipStreamWaitEvent(s2, aux->fork, 0));
-            if ((rc = run_block(layer, 0, 1, s))) return rc;
-            if ((rc = run_block(layer, 1, 1, s2))) return rc;
-            HIP_TRY(h, hipEventRecord(aux->join, s2));
-            HIP_TRY(h, hipStreamWaitEvent(s, aux->join, 0));
+            rc = run_block(layer, 0, 1, s);
+            const int rc2 = rc ? 0 : run_block(layer, 1, 1, s2);
+            // join ALWAYS, also on an error: a fork left open would stay in a stream capture of the caller's (and the helper
+            // stream would run on behind the failed call)
+            const hipError_t e1 = hipEventRecord(aux->join, s2);
+            const hipError_t e2 = hipStreamWaitEvent(s, aux->join, 0);
+            if (rc) return rc;
+            if (rc2) return rc2;
+            HIP_TRY(h, e1);
+            HIP_TRY(h, e2);
         } else if ((rc = run_block(layer, 0, kStreams, s))) {
             return rc;
         }

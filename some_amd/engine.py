@@ -53,6 +53,9 @@ def resolve_precision(config: dict) -> int:
     return PRECISIONS[name]
 
 
+MAX_FORWARD_FRAMES = 262143      # some_forward's limit (csrc/api.hip)
+
+
 class ClipBatch:
     """Packed var-len batch descriptor: clip b owns frames [frame_offsets[b], frame_offsets[b+1])."""
 
@@ -261,6 +264,9 @@ class Engine:
         assert units.is_cuda and units.dtype == torch.float32 and units.is_contiguous()
         assert units.shape == (batch.total_frames, self.indim), (units.shape, batch.total_frames)
         m = batch.total_frames
+        if m > MAX_FORWARD_FRAMES:
+            raise ValueError(f'{m} frames in one forward call: the library takes at most {MAX_FORWARD_FRAMES} (32-bit byte offsets into '
+                             f'the [frames, 2048] hidden activations; about 50 minutes of audio) - pack fewer clips per batch, or cut the clip')
         midi = torch.empty((m, self.outdim), dtype=torch.float32, device=self.device)
         bound = torch.empty((m,), dtype=torch.float32, device=self.device)
         mask_u8 = None

@@ -336,12 +336,12 @@ def test_cli_train_on_a_binarised_dataset(tmp_path, golden_dir):
     import sys
     import yaml
     root = pathlib.Path(__file__).resolve().parents[1]
-    user = {'base_config': ['configs/base.yaml'], 'binary_data_dir': str(golden_dir / 'binary'), 'max_batch_frames': 600, 'max_batch_size': 4,
+    user = {'base_config': ['configs/two_head_model.yaml'], 'binary_data_dir': str(golden_dir / 'binary'), 'max_batch_frames': 600, 'max_batch_size': 4,
             'accumulate_grad_batches': 2, 'val_check_interval': 4, 'max_val_batch_size': 1,
             'midi_extractor_args': dict(get_config('two_head_model')['midi_extractor_args'], lay=1),
             'lr_scheduler_args': {'scheduler_cls': 'lr_scheduler.scheduler.WarmupLR', 'warmup_steps': 2, 'min_lr': 1e-5}}
-    (tmp_path / 'two_head_model.yaml').write_text(yaml.safe_dump(user))
-    cmd = [sys.executable, str(root / 'train.py'), '--config', str(tmp_path / 'two_head_model.yaml'), '--exp_name', 'exp', '--work_dir', str(tmp_path),
+    (tmp_path / 'my_experiment.yaml').write_text(yaml.safe_dump(user))     # a user's own file name: nothing is inferred from the stem
+    cmd = [sys.executable, str(root / 'train.py'), '--config', str(tmp_path / 'my_experiment.yaml'), '--exp_name', 'exp', '--work_dir', str(tmp_path),
            '--log_interval', '1']
     r = subprocess.run(cmd + ['--max_updates', '8'], capture_output=True, text=True, cwd=root, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]

@@ -148,6 +148,44 @@ def test_config_inheritance(tmp_path, monkeypatch):
     assert cfg == {'a': 1, 'b': 2, 'c': 3, 'args': {'x': 1, 'y': 3}}
 
 
+def test_train_config_chains_resolve_like_the_reference(tmp_path, monkeypatch):
+    """train.py --config FILE: recursive base_config chains through read_full_config (utils/config_utils.py:19-41, train.py:33-35),
+    the built-in configs addressable as configs/<name>.yaml, unknown keys kept, and NO fallback to a default model."""
+    import sys
+    import click
+    from some_amd.configs import get_config
+    from some_amd.utils import config_utils
+    root = __import__('pathlib').Path(__file__).resolve().parents[1]
+    sys.path.insert(0, str(root))
+    import train
+    monkeypatch.chdir(tmp_path)
+    config_utils._loaded.clear()
+    assert train._load_config('two_head_model') == get_config('two_head_model')
+    assert train._load_config('configs/quant_two_head_model.yaml') == get_config('quant_two_head_model')
+    (tmp_path / 'exp').mkdir()
+    (tmp_path / 'exp/mid.yaml').write_text('base_config: configs/two_head_model.yaml\nmax_batch_frames: 1234\nmy_own_key: {a: 1}\n'
+                                          'midi_extractor_args: {lay: 5}\n')
+    (tmp_path / 'exp/top.yaml').write_text('base_config:\n  - mid.yaml\noptimizer_args: {lr: 0.5}\n')       # relative to the including file
+    cfg = train._load_config(str(tmp_path / 'exp/top.yaml'))
+    want = get_config('two_head_model', lay=5)
+    want.update(max_batch_frames=1234, my_own_key={'a': 1})
+    want['optimizer_args']['lr'] = 0.5
+    assert cfg == want
+    # a model the built-ins do not know (the reference's continuous.yaml / discrete.yaml, a typo): an error, not two_head_model
+    (tmp_path / 'exp/other.yaml').write_text('base_config: configs/continuous.yaml\n')
+    with pytest.raises(FileNotFoundError, match='continuous.yaml'):
+        train._load_config(str(tmp_path / 'exp/other.yaml'))
+    (tmp_path / 'exp/partial.yaml').write_text('base_config: configs/base.yaml\nmax_batch_size: 2\n')
+    with pytest.raises(click.UsageError, match='task_cls'):
+        train._load_config(str(tmp_path / 'exp/partial.yaml'))
+    # a real configs/ tree on disk wins over the built-ins (the reference's own files, a user's edits)
+    (tmp_path / 'configs').mkdir()
+    (tmp_path / 'configs/two_head_model.yaml').write_text('base_config: configs/base.yaml\nfrom_disk: true\n')
+    (tmp_path / 'configs/base.yaml').write_text('hop_size: 256\n')
+    config_utils._loaded.clear()
+    assert config_utils.read_full_config('configs/two_head_model.yaml') == {'hop_size': 256, 'from_disk': True}
+
+
 def test_cpu_device_is_refused(tmp_path):
     import inference
     from some_amd.configs import get_config

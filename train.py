@@ -10,6 +10,7 @@ DsBatchSampler / DsEvalBatchSampler plans; ``--synthetic N`` trains on N synthet
 ``python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...`` - one process per GPU, rank 0's
 initial weights broadcast once, the flat gradient all-reduced in buckets overlapped with backward (RCCL), every rank its own
 DsBatchSampler column."""
+import copy
 import os
 import pathlib
 
@@ -20,16 +21,25 @@ import yaml
 from some_amd import configs
 
 
+# keys this command indexes directly (configs/base.yaml + the model YAML of the reference provide all of them)
+_REQUIRED = ('task_cls', 'midi_extractor_args', 'midi_num_bins', 'hop_size', 'win_size', 'audio_sample_rate', 'units_dim', 'seed',
+             'max_batch_frames', 'max_batch_size', 'sort_by_len', 'sampler_frame_count_grid', 'max_val_batch_frames', 'max_val_batch_size',
+             'train_set_name', 'valid_set_name')
+
+
 def _load_config(config: str) -> dict:
+    """``--config``: a built-in name, or a YAML file read as the reference reads it (train.py:33-35 -> utils/config_utils.py:19-41:
+    recursive ``base_config`` chains, deep-dict override, unknown keys kept).  No fallback to a default model: a file whose chain
+    does not provide the trainer's keys is an error naming them."""
+    from some_amd.utils.config_utils import read_full_config
     if config in configs.config_names():
         return configs.get_config(config)
-    p = pathlib.Path(config)
-    stem = p.stem
-    with open(p, 'r', encoding='utf8') as f:
-        user = yaml.safe_load(f) or {}
-    base = configs.get_config(stem) if stem in configs.config_names() else configs.get_config('two_head_model')
-    base.update({k: v for k, v in user.items() if k != 'base_config'})
-    return base
+    cfg = copy.deepcopy(read_full_config(pathlib.Path(config)))
+    missing = [k for k in _REQUIRED if k not in cfg]
+    if missing:
+        raise click.UsageError(f"config '{config}' (with its base_config chain) does not define: {', '.join(missing)} - "
+                               f"inherit from configs/base.yaml and a model config as the reference's configs do")
+    return cfg
 
 
 @click.command(help='Train a SOME model')
@@ -45,6 +55,9 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
     from some_amd.training.samplers import DsBatchSampler, DsEvalBatchSampler
     from some_amd.training.task import MIDIExtractionTrainer
     cfg = _load_config(config)
+    if cfg['task_cls'] != 'training.MIDIExtractionTask':
+        # training/me_quant_task.py (129-way cross-entropy head) has no HIP training step here; its INFERENCE class is built
+        raise click.UsageError(f"task_cls {cfg['task_cls']!r}: only training.MIDIExtractionTask can be trained by this command")
     work = (pathlib.Path(work_dir) if work_dir else pathlib.Path(__file__).parent / 'experiments') / exp_name
     assert not work.exists() or work.is_dir(), f'Path \'{work}\' is not a directory.'
     world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
