@@ -41,6 +41,9 @@ def infer(wav, infer_ins, config):
     return batch_logic.notes_from_segments([c['offset'] for c in chunks], midis)
 
 
+LAST_STAGES: Dict[str, float] = {}        # host stage timers of the last process_rows call (tools/batch_infer_bench.py, bench.py --e2e)
+
+
 def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, infer_ins, config,
                  round_midi: bool, max_batch_frames: int = 131072, io_threads: int = 8, prefetch: int = 256,
                  flush_batches: int = 8, align_workers: int = 8) -> Dict[int, tuple]:
@@ -125,6 +128,8 @@ def process_rows(rows: List[dict], indices: List[int], data_path: pathlib.Path, 
         t_d = time.perf_counter()
         out.update(align_pool.close())
         stage_s['align_drain'] = time.perf_counter() - t_d
+    LAST_STAGES.clear()
+    LAST_STAGES.update(stage_s, files=len(jobs))
     if os.environ.get('SOME_AMD_PROFILE_HOST'):
         print('host stages [s]: ' + ', '.join(f'{k} {v:.2f}' for k, v in stage_s.items()) + f' ({len(jobs)} files)')
     return out

@@ -72,6 +72,71 @@ def _offline_evidence(kernel_name: str) -> dict:
     return out
 
 
+def _live_pmc(kernel_name: str, config_args) -> dict:
+    """Hardware counters of the roofline kernel read IN THIS RUN: three one-step child runs of this script under
+    ``rocprofv3 --kernel-trace --pmc ...`` (separate passes as MI355X_MICROARCH.md prescribes: MFMA-busy, FETCH_SIZE, WRITE_SIZE;
+    serial grouped launches so that every dispatch is the kernel alone).  HBM bytes per launch = FETCH_SIZE x 2 (the gfx950
+    correction for wide coalesced reads) + WRITE_SIZE, both in KiB; MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs
+    x 1024 SIMDs).  Returns {} when rocprofv3 is absent or a pass fails (the committed passes stay under offline_evidence)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    key = {'attention': 'attention3_kernel'}.get(kernel_name)
+    exe = shutil.which('rocprofv3')
+    if key is None or exe is None or os.environ.get('SOME_AMD_BENCH_CHILD'):
+        return {}
+    child = [sys.executable, str(ROOT / 'bench.py'), '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--no-kernel-profile', '--no-latency',
+             '--no-f32-leg', '--no-secondary', '--no-live-pmc'] + list(config_args)
+    env = dict(os.environ, SOME_AMD_DUAL_STREAM='0', SOME_AMD_BENCH_CHILD='1', TMPDIR='/tmp')
+    sums = {}
+    with tempfile.TemporaryDirectory(dir='/tmp') as tmp:
+        for tag, counters in (('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE']), ('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE'])):
+            out_dir = os.path.join(tmp, tag)
+            try:
+                r = subprocess.run([exe, '--kernel-trace', '--pmc'] + counters + ['--output-format', 'csv', '-d', out_dir, '--'] + child,
+                                   env=env, cwd='/tmp', capture_output=True, text=True, timeout=240)
+            except (subprocess.TimeoutExpired, OSError):
+                return {}
+            if r.returncode != 0:
+                return {}
+            for f in glob.glob(out_dir + '/**/*counter_collection.csv', recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if key not in row['Kernel_Name']:
+                        continue
+                    a = sums.setdefault(row['Counter_Name'], [0.0, 0, 0.0])
+                    a[0] += float(row['Counter_Value'])
+                    a[1] += 1
+                    a[2] += float(row['End_Timestamp']) - float(row['Start_Timestamp'])
+    out = {}
+    if 'FETCH_SIZE' in sums and 'WRITE_SIZE' in sums:
+        out['traffic_bytes_per_launch'] = int((2.0 * sums['FETCH_SIZE'][0] / sums['FETCH_SIZE'][1] + sums['WRITE_SIZE'][0] / sums['WRITE_SIZE'][1]) * 1024)
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in sums and sums.get('GRBM_GUI_ACTIVE', [0])[0] > 0:
+        busy, gui = sums['SQ_VALU_MFMA_BUSY_CYCLES'], sums['GRBM_GUI_ACTIVE']
+        out['mfma_busy_frac'] = round(busy[0] / (gui[0] / 8 * 1024), 4)
+        out['effective_clock_mhz'] = round(gui[0] / 8 / gui[2] * 1e3)
+        out['dispatches_sampled'] = busy[1]
+    if out:
+        out['source'] = 'live: rocprofv3 --kernel-trace --pmc child runs of this command (1 step each, serial grouped launches)'
+    return out
+
+
+def _tool_json(cmd, timeout):
+    """Run a measurement tool as a child process (its own CUDA context) and return the JSON object on its last stdout line."""
+    import subprocess
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=str(ROOT))
+    except subprocess.TimeoutExpired:
+        return {'error': f'timed out after {timeout} s'}
+    if r.returncode != 0:
+        return {'error': (r.stdout[-600:] + r.stderr[-1200:]).strip()}
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith('{'):
+            return json.loads(line)
+    return {'error': 'no JSON in the output'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -88,6 +153,14 @@ def main():
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the secondary exact-f32 measurement')
     ap.add_argument('--no-secondary', action='store_true', help='skip the quant_two_head_model (BASELINE configs[2]) leg')
     ap.add_argument('--cpu-clips', type=int, default=4, help='clips in the bounded CPU-baseline sample')
+    ap.add_argument('--no-live-pmc', action='store_true', help='skip the rocprofv3 --pmc child passes for roofline.traffic / MFMA-busy')
+    ap.add_argument('--e2e', action='store_true', help='optional leg, BASELINE configs[3] at its own size on this GPU: batch_infer.py over '
+                    '--e2e-rows synthetic 30 s WAVs on disk -> CSV (tools/batch_infer_bench.py); minutes')
+    ap.add_argument('--e2e-rows', type=int, default=10000)
+    ap.add_argument('--train', action='store_true', help='optional leg, BASELINE configs[4] at its own size on this GPU: one epoch of train.py '
+                    'two_head_model bf16 over a synthetic 3 h binarised dataset (tools/train_epoch_bench.py); minutes')
+    ap.add_argument('--train-hours', type=float, default=3.0)
+    ap.add_argument('--scratch', default='/tmp/some_amd_bench', help='directory for the datasets of the --e2e / --train legs')
     args = ap.parse_args()
 
     import numpy as np
@@ -243,6 +316,21 @@ def main():
                         ev = _offline_evidence(dom['name'])
                         if ev:
                             result['offline_evidence'] = ev
+                    if world == 1 and not args.no_live_pmc:
+                        cfg_args = ['--config', args.config, '--batch', str(args.batch), '--seconds', str(args.seconds)]
+                        if args.lay is not None:
+                            cfg_args += ['--lay', str(args.lay)]
+                        if args.precision:
+                            cfg_args += ['--precision', args.precision]
+                        live = _live_pmc(dom['name'], cfg_args)
+                        if live:
+                            result['roofline']['traffic'] = live.get('traffic_bytes_per_launch')
+                            if dom['name'] == 'attention' and live.get('traffic_bytes_per_launch'):
+                                # Q | K SPLIT32 planes + V^T f16 planes read, SPLIT32 output written: 4 x 2048 B per frame and model stream
+                                algo = 2 * batch.total_frames * 8192
+                                result['roofline']['algorithmic_bytes_per_launch'] = algo
+                                result['roofline']['traffic_over_algorithmic_bytes'] = round(live['traffic_bytes_per_launch'] / algo, 3)
+                            result['live_pmc'] = live
                 else:
                     result['roofline'] = {
                         'kernel': dom['name'], 'bound': 'mfma', 'achieved': dom['tflops'], 'peak': F32_MATRIX_PEAK_TFLOPS,
@@ -331,6 +419,23 @@ def main():
                 'sample': f'{args.cpu_clips} x {args.seconds:g} s clips of the same workload, B=1 per clip '
                           f'(log-mel + forward + decode), torch-CPU fp32 oracle, {threads} threads',
             }
+        if world == 1 and args.e2e:
+            # BASELINE configs[3]: the batch_infer.py command from disk to CSV; a briefly trained checkpoint (realistic note counts);
+            # first run cold (torch.load + weight pack), second with the cached weight arena; 24 rows re-checked one by one
+            ds = os.path.join(args.scratch, f'e2e_{args.e2e_rows}')
+            tool = [sys.executable, str(ROOT / 'tools' / 'batch_infer_bench.py'), '--clips', str(args.e2e_rows), '--distinct',
+                    str(max(8, args.e2e_rows // 8)), '--seconds', '30', '--lay', str(lay), '--dir', ds, '--train_updates', '300', '--json']
+            cold = _tool_json(tool, 3000)
+            warm = _tool_json(tool + ['--check', '24'], 3000)
+            result['e2e_batch_infer'] = dict(warm, cold_start=cold)
+        if world == 1 and args.train:
+            ds = os.path.join(args.scratch, f'train_{args.train_hours:g}h')
+            if not os.path.exists(os.path.join(ds, 'train.lengths')):
+                made = _tool_json([sys.executable, str(ROOT / 'tools' / 'make_train_dataset.py'), '--dir', ds, '--hours', str(args.train_hours)], 3000)
+                if 'error' in made and 'no JSON' not in made['error']:
+                    result['train_epoch'] = made
+            if 'train_epoch' not in result:
+                result['train_epoch'] = _tool_json([sys.executable, str(ROOT / 'tools' / 'train_epoch_bench.py'), '--dir', ds], 3000)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

@@ -13,9 +13,10 @@ Items follow preprocessing/me_binarizer.py:22-29 (MIDI_EXTRACTION_ITEM_ATTRIBUTE
 [T], note_midi float32 [n], note_rest bool [n], note_dur int64 [n], unit2note int64 [T]; units come from the CPU oracle
 (oracle/restate.logmel) of the synthetic sung clips in some_amd/training/data.py.
 
-Usage:  python oracle/make_binary_fixture.py
+Usage:  python oracle/make_binary_fixture.py        (SOME_GOLDEN_OUT=DIR writes elsewhere; the containers carry libhdf5's object
+modification times, so a regenerated file differs from the committed one in those 4-byte fields and nowhere else)
 """
-import ctypes as C
+import os
 import pathlib
 import sys
 
@@ -28,57 +29,8 @@ from oracle import restate  # noqa: E402
 from some_amd.configs import get_config  # noqa: E402
 from some_amd.training import data  # noqa: E402
 
-OUT = REPO / 'tests' / 'golden' / 'binary'
-H5 = C.CDLL('/opt/conda/lib/libhdf5.so')
-hid = C.c_int64
-H5.H5open()
-for fn, res, args in [
-    ('H5Fcreate', hid, [C.c_char_p, C.c_uint, hid, hid]), ('H5Fclose', C.c_int, [hid]),
-    ('H5Gcreate2', hid, [hid, C.c_char_p, hid, hid, hid]), ('H5Gclose', C.c_int, [hid]),
-    ('H5Screate_simple', hid, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]), ('H5Sclose', C.c_int, [hid]),
-    ('H5Dcreate2', hid, [hid, C.c_char_p, hid, hid, hid, hid, hid]), ('H5Dclose', C.c_int, [hid]),
-    ('H5Dwrite', C.c_int, [hid, hid, hid, hid, hid, C.c_void_p]),
-    ('H5Pcreate', hid, [hid]), ('H5Pset_layout', C.c_int, [hid, C.c_int]), ('H5Pclose', C.c_int, [hid]),
-    ('H5Screate', hid, [C.c_int]),
-    ('H5Tenum_create', hid, [hid]), ('H5Tenum_insert', C.c_int, [hid, C.c_char_p, C.c_void_p]), ('H5Tclose', C.c_int, [hid]),
-]:
-    getattr(H5, fn).restype, getattr(H5, fn).argtypes = res, args
-
-
-def _g(name):
-    return C.c_int64.in_dll(H5, name).value
-
-
-def _bool_type():
-    t = H5.H5Tenum_create(_g('H5T_STD_I8LE_g'))               # h5py maps numpy bool to this enum
-    for name, v in ((b'FALSE', 0), (b'TRUE', 1)):
-        val = C.c_int8(v)
-        assert H5.H5Tenum_insert(t, name, C.byref(val)) >= 0
-    return t
-
-
-def write_items(path: pathlib.Path, items):
-    f = H5.H5Fcreate(str(path).encode(), 2, 0, 0)             # H5F_ACC_TRUNC, default fcpl / fapl (libver earliest, as h5py)
-    assert f >= 0
-    bool_t = _bool_type()
-    file_types = {np.dtype('float32'): _g('H5T_IEEE_F32LE_g'), np.dtype('int64'): _g('H5T_STD_I64LE_g'), np.dtype('bool'): bool_t}
-    mem_types = {np.dtype('float32'): _g('H5T_NATIVE_FLOAT_g'), np.dtype('int64'): _g('H5T_NATIVE_INT64_g'), np.dtype('bool'): bool_t}
-    for no, item in enumerate(items):
-        g = H5.H5Gcreate2(f, str(no).encode(), 0, 0, 0)       # the intermediate group of f'{item_no}/{k}'
-        assert g >= 0
-        for k, v in item.items():
-            v = np.ascontiguousarray(v)
-            dims = (C.c_uint64 * max(v.ndim, 1))(*v.shape)
-            s = H5.H5Screate_simple(v.ndim, dims, None)
-            d = H5.H5Dcreate2(g, k.encode(), file_types[v.dtype], s, 0, 0, 0)
-            assert s >= 0 and d >= 0
-            if v.size:
-                assert H5.H5Dwrite(d, mem_types[v.dtype], 0, 0, 0, v.ctypes.data_as(C.c_void_p)) >= 0
-            H5.H5Dclose(d)
-            H5.H5Sclose(s)
-        H5.H5Gclose(g)
-    H5.H5Tclose(bool_t)
-    assert H5.H5Fclose(f) >= 0
+OUT = pathlib.Path(os.environ['SOME_GOLDEN_OUT']) if os.environ.get('SOME_GOLDEN_OUT') else REPO / 'tests' / 'golden' / 'binary'
+from tools.h5_write import C, H5, _g, write_items  # noqa: E402,F401  (the ctypes binding of libhdf5 + the item writer)
 
 
 def write_misc(path: pathlib.Path):

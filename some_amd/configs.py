@@ -42,6 +42,8 @@ _BASE = {
     'val_check_interval': 1000,
     'num_ckpt_keep': 5,
     'max_updates': 100000,
+    'ds_workers': 4,                        # configs/base.yaml:52-53 (training/base_task.py:374-380: DataLoader workers / prefetch)
+    'dataloader_prefetch_factor': 2,
 }
 
 

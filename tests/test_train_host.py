@@ -362,3 +362,30 @@ def test_gradient_sync_mark_stands_in_for_the_hook(tmp_path):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_prefetch_loader_batches_equal_the_collater(golden_dir):
+    """training/loader.py (the reference's DataLoader role, training/base_task.py:374-380): batches built by worker threads (host
+    padding) + the device half of the collater equal MIDIExtractionDataset.collater (training/me_task.py:26-52) tensor for tensor,
+    in plan order, for any worker count - on the libhdf5-written fixture (tests/golden/binary)."""
+    from some_amd.configs import get_config
+    from some_amd.training import data
+    from some_amd.training.loader import PrefetchLoader
+    cfg = get_config('two_head_model')
+    ds = data.MIDIExtractionDataset(cfg, golden_dir / 'binary', 'train')
+    rng = np.random.default_rng(0)
+    plan = [list(map(int, rng.choice(len(ds), size=int(rng.integers(1, 6)), replace=False))) for _ in range(11)]
+    want = [ds.collater([ds[i] for i in idx]) for idx in plan]
+    for workers, pf in [(0, 1), (1, 1), (3, 2)]:
+        loader = PrefetchLoader(ds, cfg, 'cpu', workers=workers, prefetch_factor=pf)
+        got = list(loader.batches(plan))
+        loader.close()
+        assert len(got) == len(want) and loader.stats['batches'] == len(plan)
+        for a, b in zip(got, want):
+            assert set(a) == set(b)
+            for k in b:
+                if torch.is_tensor(b[k]):
+                    assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), k
+                else:
+                    assert a[k] == b[k]
+    assert list(PrefetchLoader(ds, cfg, 'cpu').batches([])) == []

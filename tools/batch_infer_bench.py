@@ -21,12 +21,22 @@ from some_amd.configs import get_config  # noqa: E402
 from some_amd.utils.audio import save_wav  # noqa: E402
 
 
-def build_dataset(root: pathlib.Path, clips: int, seconds: float):
+def build_dataset(root: pathlib.Path, clips: int, seconds: float, distinct: int = 0):
+    """``clips`` rows; the first ``distinct`` (default: all) are files of their own, the rest hard links to them (BASELINE configs[3]:
+    10 000 x 30 s = 26.5 GB as int16 - 1 250 distinct files keep the dataset at 3.3 GB while every row still opens, reads and
+    decodes a file)."""
     (root / 'wavs').mkdir(parents=True, exist_ok=True)
     base = [synth.synth_clip(700 + i, seconds, silence_every=8.0) for i in range(8)]
+    distinct = clips if distinct <= 0 else min(distinct, clips)
     rows = []
     for i in range(clips):
-        save_wav(root / 'wavs' / f'clip_{i:05d}.wav', base[i % 8], 44100)
+        path = root / 'wavs' / f'clip_{i:05d}.wav'
+        if i < distinct:
+            save_wav(path, base[i % 8], 44100)
+        else:
+            if path.exists():
+                path.unlink()
+            os.link(root / 'wavs' / f'clip_{i % distinct:05d}.wav', path)
         n_ph = 60
         rows.append({'name': f'clip_{i:05d}', 'ph_seq': ' '.join(['a'] * n_ph), 'ph_dur': ' '.join([f'{seconds / n_ph:.6f}'] * n_ph),
                      'ph_num': ' '.join(['2'] * (n_ph // 2))})
@@ -42,6 +52,9 @@ def main():
     ap.add_argument('--seconds', type=float, default=30.0)
     ap.add_argument('--lay', type=int, default=8)
     ap.add_argument('--dir', default=None, help='dataset directory to (re)use; default: a temporary directory')
+    ap.add_argument('--distinct', type=int, default=0, help='number of distinct WAV files (the other rows are hard links); 0: all')
+    ap.add_argument('--check', type=int, default=0, help='recompute this many sampled rows one by one (host Slicer + infer) and compare the CSV cells')
+    ap.add_argument('--json', action='store_true', help='print one JSON object instead of the sentence')
     ap.add_argument('--train_updates', type=int, default=0,
                     help='train the checkpoint for this many updates on synthetic sung clips first (train.py): random weights emit ~1500 '
                          'notes per clip, a trained model ~60, and the per-row word alignment scales with the note count')
@@ -58,7 +71,7 @@ def main():
         root = pathlib.Path(args.dir)
     if rank == 0 and not (root / 'transcriptions.csv').exists():
         t0 = time.perf_counter()
-        build_dataset(root, args.clips, args.seconds)
+        build_dataset(root, args.clips, args.seconds, args.distinct)
         if args.train_updates > 0:
             import subprocess
             import yaml
@@ -75,17 +88,18 @@ def main():
                                 '--work_dir', str(root), '--synthetic', '64', '--max_updates', str(args.train_updates), '--log_interval', '100'],
                                capture_output=True, text=True, cwd=repo)
             assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-            print([ln for ln in r.stdout.splitlines() if ln.startswith('validation')][-1:])
+            print([ln for ln in r.stdout.splitlines() if ln.startswith('validation')][-1:], file=sys.stderr)
             (root / 'model' / f'model_ckpt_steps_{args.train_updates}.ckpt').rename(root / 'model' / 'model.ckpt')
         else:
             synth.save_checkpoint(get_config('midi_conformer', lay=args.lay), root / 'model' / 'model.ckpt', seed=1)
-        print(f'dataset: {args.clips} x {args.seconds:g} s int16 WAVs written in {time.perf_counter() - t0:.1f} s')
+        print(f'dataset: {args.clips} x {args.seconds:g} s int16 WAVs written in {time.perf_counter() - t0:.1f} s', file=sys.stderr)
     import batch_infer as bi
     import torch
     import utils.config_utils
     utils.config_utils.print_config = lambda *_a, **_k: None          # keep the timing output readable
     if world > 1:
         time.sleep(0 if rank == 0 else 2)
+    cached = any((root / 'model').glob('*.arena'))
     t0 = time.perf_counter()
     bi.batch_infer.callback(dataset=str(root), model=str(root / 'model' / 'model.ckpt'), round_midi=False, csv=str(root / f'out.csv'), overwrite=True)
     if torch.cuda.is_available():
@@ -94,8 +108,40 @@ def main():
     if rank == 0:
         rows = list(csv.DictReader(open(root / 'out.csv', encoding='utf8')))
         filled = sum(1 for r in rows if r.get('note_seq'))
-        print(f'batch_infer.py end to end ({world} process(es), model load + weight pack included): {args.clips} x {args.seconds:g} s in '
-              f'{dt:.2f} s -> {args.clips * args.seconds / dt:.0f} audio-s/s; {filled}/{len(rows)} rows annotated')
+        res = {'workload': f'batch_infer.py --dataset DIR --model CKPT --csv: {args.clips} rows x {args.seconds:g} s int16 WAVs '
+                           f'({args.distinct or args.clips} distinct files) + transcriptions.csv -> CSV, lay {args.lay}, {world} process(es), '
+                           f'model load included ({"warm" if cached else "cold"} weight cache)',
+               'rows': args.clips, 'rows_annotated': filled, 'wall_s': round(dt, 3), 'rows_per_s': round(args.clips / dt, 1),
+               'audio_s_per_s': round(args.clips * args.seconds / dt, 1), 'host_stages_s_rank0': {k: round(float(v), 3) for k, v in bi.LAST_STAGES.items()}}
+        if args.check > 0:
+            # per-row recomputation through the reference's own granularity: Slicer.slice on the host + infer() per file
+            import yaml
+            import inference
+            from some_amd.utils.audio import load_wav
+            from some_amd import batch_logic
+            from some_amd.utils.slicer2 import Slicer
+            cfg = yaml.safe_load(open(root / 'model' / 'config.yaml'))
+            ins = inference.task_inference_mapping  # noqa: F841  (registry import keeps the dotted class paths resolvable)
+            from some_amd.inference.me_infer import MIDIExtractionInference
+            one = MIDIExtractionInference(cfg, root / 'model' / 'model.ckpt', device='cuda')
+            slicer = Slicer(sr=cfg['audio_sample_rate'], max_sil_kept=1000)
+            rng = np.random.default_rng(0)
+            picks = sorted(rng.choice(len(rows), size=min(args.check, len(rows)), replace=False).tolist())
+            bad = 0
+            for i in picks:
+                wave, _ = load_wav(root / 'wavs' / f"{rows[i]['name']}.wav", cfg['audio_sample_rate'])
+                chunks = slicer.slice(wave)
+                midis = one.infer([c['waveform'] for c in chunks])
+                seq, dur = batch_logic.align_job([c['offset'] for c in chunks], midis, rows[i]['ph_dur'], rows[i]['ph_num'], False)
+                bad += (seq != rows[i]['note_seq']) or (dur != rows[i]['note_dur'])
+            res['rows_rechecked_one_by_one'] = len(picks)
+            res['rows_rechecked_differing'] = int(bad)
+        if args.json:
+            import json
+            print(json.dumps(res))
+        else:
+            print(f'batch_infer.py end to end ({world} process(es), model load + weight pack included): {args.clips} x {args.seconds:g} s in '
+                  f'{dt:.2f} s -> {args.clips * args.seconds / dt:.0f} audio-s/s; {filled}/{len(rows)} rows annotated')
     if tmp is not None:
         tmp.cleanup()
 

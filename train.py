@@ -13,6 +13,7 @@ DsBatchSampler column."""
 import copy
 import os
 import pathlib
+import time
 
 import click
 import torch
@@ -52,6 +53,7 @@ def _load_config(config: str) -> dict:
 @click.option('--val_clips', type=int, default=8, help='held-out synthetic clips for the validation pass')
 def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_clips):
     from some_amd.training import data
+    from some_amd.training.loader import PrefetchLoader
     from some_amd.training.samplers import DsBatchSampler, DsEvalBatchSampler
     from some_amd.training.task import MIDIExtractionTrainer
     cfg = _load_config(config)
@@ -111,14 +113,25 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
         if rank == 0:
             print(f'resumed from {existing[-1].name} at step {trainer.global_step}')
     keep, interval = cfg.get('num_ckpt_keep', 5), cfg.get('val_check_interval', 1000)
-    saved, epoch = list(existing), trainer.global_step // max(1, len(sampler) // accumulate)
+    # training/base_task.py:374-380: DataLoader(num_workers=ds_workers, prefetch_factor=dataloader_prefetch_factor, pin_memory=True,
+    # persistent_workers=True) - here worker threads collating into pinned buffers + uploads on a copy stream (training/loader.py)
+    loader = PrefetchLoader(train_set, cfg, trainer.ops.device, workers=int(cfg.get('ds_workers', 4)),
+                            prefetch_factor=int(cfg.get('dataloader_prefetch_factor', 2)))
+    steps_per_epoch = max(1, len(sampler) // accumulate)
+    saved, epoch = list(existing), trainer.global_step // steps_per_epoch
+    skip = trainer.global_step % steps_per_epoch          # resumed inside an epoch: its first `skip` updates have been applied already
+    t_train = time.perf_counter()
     while trainer.global_step < total:
         sampler.set_epoch(epoch)
-        plan = list(sampler)
-        epoch += 1
-        for g in range(0, len(plan), accumulate):
-            micro = [train_set.collater([train_set[i] for i in idx]) for idx in plan[g:g + accumulate]]
+        plan = list(sampler)[skip * accumulate:]
+        epoch, skip = epoch + 1, 0
+        micro = []
+        for mb in loader.batches(plan):
+            micro.append(mb)
+            if len(micro) < accumulate:
+                continue
             out = trainer.training_step(micro if accumulate > 1 else micro[0])
+            micro = []
             step = trainer.global_step
             if rank == 0 and (step % log_interval == 0 or step == total):
                 print(f'step {step}: ' + ', '.join(f'{k}={float(v):.5f}' for k, v in out.items() if k.endswith('loss')) +
@@ -133,6 +146,13 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
                     saved.pop(0).unlink(missing_ok=True)
             if step >= total:
                 break
+    torch.cuda.synchronize()
+    if rank == 0:
+        wall = time.perf_counter() - t_train
+        st = loader.stats
+        print(f'loader: {st["batches"]} batches, waited {st["wait_s"]:.2f} s of {wall:.2f} s for data ({100.0 * st["wait_s"] / max(wall, 1e-9):.1f} %), '
+              f'host collate {st["host_collate_s"]:.2f} s in {loader.workers} worker threads')
+    loader.close()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
