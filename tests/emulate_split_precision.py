@@ -67,7 +67,7 @@ def _fp6_table(fmt):
     return torch.tensor(sorted(set(vals)), dtype=torch.float64)
 
 
-def fp6_mx(x, fmt, axis=-1, block=32):
+def fp6_mx(x, fmt, axis=-1, block=32, norm='max'):
     """MX FP6: shared power-of-two scale per 32-element block (block maximum just under the format's largest value), elements
     rounded to the nearest representable FP6 value - what v_mfma_scale_f32_*_f8f6f4 consumes at the FP4 rate (4x f16) on gfx950."""
     table = _fp6_table(fmt)
@@ -79,12 +79,38 @@ def fp6_mx(x, fmt, axis=-1, block=32):
         x = F.pad(x, (0, pad))
     xb = x.reshape(*x.shape[:-1], -1, block)
     amax = xb.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+    if norm == 'l2':            # a cheap upper bound of the block maximum: its Euclidean norm (16 v_dot2 instead of a 31-step max tree)
+        amax = xb.pow(2).sum(dim=-1, keepdim=True).sqrt().clamp_min(1e-300)
     scale = torch.exp2(torch.floor(torch.log2(fmax / amax)))
     y = (xb * scale).abs()
     mid = (table[1:] + table[:-1]) / 2
     q = table[torch.bucketize(y, mid)] * torch.sign(xb) / scale
     q = q.reshape(*x.shape[:-1], -1)[..., :shp[-1]]
     return q.movedim(-1, axis)
+
+
+def fp6_global(x, fmt, slack=1.0, reduce_dims=(-2, -1)):
+    """FP6 with ONE power-of-two scale per matrix (per head in the attention products): the maximum over all rows (times `slack`,
+    a deliberately loose bound) sits under the format's largest value; smaller elements fall into the subnormal range / flush."""
+    table = _fp6_table(fmt)
+    fmax = float(table[-1])
+    amax = x.abs().amax(dim=reduce_dims, keepdim=True).clamp_min(1e-300) * slack
+    scale = torch.exp2(torch.floor(torch.log2(fmax / amax)))
+    y = (x * scale).abs().clamp_max(fmax)
+    mid = (table[1:] + table[:-1]) / 2
+    return table[torch.bucketize(y.contiguous(), mid)] * torch.sign(x) / scale
+
+
+def _lo_from_hi(h, l, fmt, slack):
+    """Quantise the lo half with the scale implied by the hi half's maximum: |lo| <= 2^-11 * 2^ceil(log2 max|hi|)."""
+    table = _fp6_table(fmt)
+    fmax = float(table[-1])
+    amax = h.abs().amax(dim=(-2, -1), keepdim=True).clamp_min(1e-300) * slack
+    bound = torch.exp2(torch.floor(torch.log2(amax)) + 1 - 11)
+    scale = torch.exp2(torch.floor(torch.log2(fmax / bound)))
+    y = (l * scale).abs().clamp_max(fmax)
+    mid = (table[1:] + table[:-1]) / 2
+    return table[torch.bucketize(y.contiguous(), mid)] * torch.sign(l) / scale
 
 
 def split(x, kind='f16'):
@@ -124,6 +150,17 @@ def make_product(variant):
         elif variant in ('cross_fp6_e2m3', 'cross_fp6_e3m2'):
             f = variant[-4:]
             out = mm(ah, bh) + mm(fp6_mx(ah, f), fp6_mx(bl, f)) + mm(fp6_mx(al, f), fp6_mx(bh, f))
+        elif variant in ('cross_fp6l2_e2m3', 'cross_fp6l2_e3m2'):      # MX blocks, scale from the block's L2 norm, lo scale from the hi scale
+            f = variant[-4:]
+            out = mm(ah, bh) + mm(fp6_mx(ah, f, norm='l2'), fp6_mx(bl, f, norm='l2')) + mm(fp6_mx(al, f, norm='l2'), fp6_mx(bh, f, norm='l2'))
+        elif variant.startswith('cross_fp6g_'):        # cross_fp6g_<fmt>_<slack>: one scale per matrix / head, loosened by `slack`
+            _, _, f, slack = variant.split('_')
+            slack = float(slack)
+            # lo halves: scale derived from the hi scale (|lo| <= 2^-11 max|hi|), not from their own maximum
+            q = lambda h, l: (fp6_global(h, f, slack), fp6_global(l, f, slack) if False else _lo_from_hi(h, l, f, slack))     # noqa: E731
+            a6h, a6l = q(ah, al)
+            b6h, b6l = q(bh, bl)
+            out = mm(ah, bh) + mm(a6h, b6l) + mm(a6l, b6h)
         elif variant == 'a_lo_e4m3':                  # activations' lo term on the FP8 pipe, weights' lo term stays f16
             out = mm(ah, bh) + mm(ah, bl) + mm(fp8_mx(al, 'e4m3'), fp8_mx(bh, 'e4m3'))
         elif variant == 'b_lo_e4m3':
@@ -136,15 +173,19 @@ def make_product(variant):
     return prod
 
 
-COST = {'f32': None, 'bf16x3': 3.0, 'f16x3': 3.0, 'f16x2_drop_a_lo': 2.0, 'f16x2_drop_b_lo': 2.0, 'f16x1': 1.0, 'cross_e4m3': 2.0, 'cross_e5m2': 2.0,
+COST = {'cross_fp6l2_e2m3': 1.5, 'cross_fp6l2_e3m2': 1.5,
+        'cross_fp6g_e2m3_1': 1.5, 'cross_fp6g_e2m3_4': 1.5, 'cross_fp6g_e2m3_16': 1.5, 'cross_fp6g_e2m3_64': 1.5, 'cross_fp6g_e3m2_1': 1.5, 'cross_fp6g_e3m2_16': 1.5, 'cross_fp6g_e3m2_64': 1.5,
+        'f32': None, 'bf16x3': 3.0, 'f16x3': 3.0, 'f16x2_drop_a_lo': 2.0, 'f16x2_drop_b_lo': 2.0, 'f16x1': 1.0, 'cross_e4m3': 2.0, 'cross_e5m2': 2.0,
         'cross_fp6_e2m3': 1.5, 'cross_fp6_e3m2': 1.5, 'a_lo_e4m3': 2.5, 'b_lo_e4m3': 2.5, 'cross_bf16': 3.0}
 
 
 class Shim:
     """Stands in for torch.nn.functional inside oracle/restate.py: dense contractions go through `prod`, the rest through F."""
 
-    def __init__(self, prod, gemms=True, attention=True, dtype=torch.float32):
+    def __init__(self, prod, gemms=True, attention=True, dtype=torch.float32, qk=True, pv=True):
         self.prod, self.gemms, self.attention, self.dtype = prod, gemms, attention, dtype
+        base = make_product('f16x3')
+        self.prod_qk, self.prod_pv = (prod if qk else base), (prod if pv else base)      # the other product stays the shipped 3-term form
 
     def __getattr__(self, name):
         return getattr(F, name)
@@ -166,10 +207,10 @@ class Shim:
     def scaled_dot_product_attention(self, q, k, v):
         if not self.attention:
             return F.scaled_dot_product_attention(q, k, v)
-        s = self.prod(q, k).to(torch.float64) * q.shape[-1] ** -0.5
+        s = self.prod_qk(q, k).to(torch.float64) * q.shape[-1] ** -0.5
         p = torch.softmax(s, dim=-1)
         # the kernel carries P scaled by a power of two (<= 2^14) to keep its lo half out of the f16 subnormals; emulate the same
-        o = self.prod(p * 16384.0, v.transpose(-1, -2)).to(torch.float64) / 16384.0
+        o = self.prod_pv(p * 16384.0, v.transpose(-1, -2)).to(torch.float64) / 16384.0
         return o.to(self.dtype)
 
 
@@ -186,6 +227,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--lay', type=int, default=8)
     ap.add_argument('--seconds', type=float, default=30.0)
+    ap.add_argument('--where', default='all', help="all | attention")
     ap.add_argument('--variants', default='f32,f16x3,bf16x3,cross_bf16,cross_e4m3,cross_e5m2,a_lo_e4m3,b_lo_e4m3,f16x2_drop_a_lo,f16x2_drop_b_lo')
     a = ap.parse_args()
     torch.set_num_threads(8)
@@ -201,11 +243,16 @@ def main():
     print('| variant | where | issue cost (f16 products) | max abs d prob | max abs d bound | max abs d logit(midi) |')
     print('|---|---|---|---|---|---|')
     for v in a.variants.split(','):
-        for where, g, at in (('GEMMs + attention', True, True), ('GEMMs only', True, False), ('attention only', False, True)):
+        for where, g, at in (('GEMMs + attention', True, True), ('GEMMs only', True, False), ('attention only', False, True),
+                             ('attention P V only', False, 'pv'), ('attention Q K^T only', False, 'qk')):
             if v == 'f32' and where != 'GEMMs + attention':
                 continue
+            if a.where == 'attention' and not where.startswith('attention'):
+                continue
+            if a.where == 'all' and at in ('pv', 'qk'):
+                continue
             t0 = time.time()
-            out = run(sd, cfg, units, Shim(make_product(v), g, at))
+            out = run(sd, cfg, units, Shim(make_product(v), g, bool(at), qk=at != 'pv', pv=at != 'qk'))
             dp = float((out[0].double() - ref[0]).abs().max())
             db = float((out[1].double() - ref[1]).abs().max())
             lg = torch.logit(out[0].double().clamp(1e-12, 1 - 1e-12)) - torch.logit(ref[0].clamp(1e-12, 1 - 1e-12))

@@ -34,6 +34,13 @@ def test_scanner_recognises_the_pattern():
     assert len(scan.scan_text(glob)) == 1 and not scan.scan_text(glob)[0]['sgpr_soffset']
 
 
+def test_scanner_recognises_overlapping_pack_converts():
+    bad = '0000000000001000 <_Z1kv>:\n\tv_cvt_scalef32_2xpk16_fp6_f32 v[2:7], v[18:33], v[2:17], v137   // 0: 00\n'
+    good = bad.replace('v[2:7]', 'v[34:39]')
+    scale = bad.replace('v[2:7], v[18:33], v[2:17], v137', 'v[130:135], v[98:113], v[114:129], v130')
+    assert len(scan.scan_text(bad)) == 1 and scan.scan_text(good) == [] and len(scan.scan_text(scale)) == 1
+
+
 def test_no_unprotected_wide_store_hazard_in_the_built_library():
     from some_amd import _lib
     if not (scan.LLVM / 'llvm-objdump').exists():

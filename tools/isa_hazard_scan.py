@@ -72,8 +72,14 @@ def _defs(mn: str, ops):
     return _regs(ops[0].split()[0])
 
 
+PACK_CVT = re.compile(r'^v_cvt_scalef32_(2xpk16|pk32|sr_pk32|sr_2xpk16)_')
+
+
 def scan_text(text: str):
-    """-> list of (kernel, store line, following line, slot) for wide stores whose data registers are overwritten 1 slot later."""
+    """-> list of hits.  Rule 1: wide stores whose data registers are overwritten 1 slot later.  Rule 2 (round 3, tools/mx_probe2.hip):
+    a multi-register MX pack convert (v_cvt_scalef32_2xpk16_* / pk32_*) whose destination tuple overlaps one of its sources - hipcc
+    allocates such overlaps when the source dies at the instruction, and the multi-pass instruction then reads what it has already
+    overwritten (csrc/split.h cvt_fp6_2x16 keeps the sources alive)."""
     hits = []
     kernel = None
     lines = text.splitlines()
@@ -87,6 +93,11 @@ def scan_text(text: str):
         if p:
             insts.append((kernel, p[0], p[1], ln.split('//')[0].strip()))
     for i, (kern, mn, ops, txt) in enumerate(insts):
+        if PACK_CVT.match(mn) and len(ops) >= 2:
+            dst = _regs(ops[0])
+            if any(dst & _regs(o.split()[0]) for o in ops[1:]):
+                hits.append({'kernel': kern, 'store': txt, 'next': '(destination overlaps a source of the pack convert)', 'sgpr_soffset': False})
+            continue
         if not WIDE_STORE.match(mn) or not ops:
             continue
         # MUBUF / MTBUF: data first; FLAT / GLOBAL / SCRATCH: address first, data second
