@@ -180,7 +180,10 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     dist = None
-    if world > 1:
+    # under torch.distributed.run the process group is initialised even for ONE rank, so that a single-GPU box exercises the RCCL
+    # communicator, the arena broadcast, the barrier and the max-over-ranks all-reduce of the N > 1 path (tests/test_gpu_parity.py)
+    launched = 'RANK' in os.environ and 'MASTER_PORT' in os.environ
+    if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('SOME_AMD_DIST_BACKEND', 'nccl')   # "nccl" is RCCL on ROCm; gloo only for dry runs
@@ -203,7 +206,7 @@ def main():
     if rank == 0:
         sd = synth.synth_state_dict(cfg, seed=cfg.get('seed', 114514))
         arena.copy_(eng.pack_state_dict(sd))
-    if world > 1:
+    if dist is not None:
         dist.broadcast(arena, src=0)
     eng.attach_arena(arena)
 
@@ -226,7 +229,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -239,7 +242,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     n_notes = int(out['n_notes'].sum())
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -266,6 +269,8 @@ def main():
         'model_tflops': round(step_flops * world / (ms_per_step * 1e-3) / 1e12, 2),
         'notes_decoded_last_step': n_notes,
     }
+    if dist is not None:
+        result['process_group'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size()}
 
     if rank == 0:
         # ---- per-kernel leg: HIP events around every launch on the launch stream (some_profile_*) -------
@@ -437,7 +442,7 @@ def main():
             if 'train_epoch' not in result:
                 result['train_epoch'] = _tool_json([sys.executable, str(ROOT / 'tools' / 'train_epoch_bench.py'), '--dir', ds], 3000)
         print(json.dumps(result))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

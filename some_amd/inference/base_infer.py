@@ -33,7 +33,9 @@ class BaseInference:
         ).eval().to(self.device)
         prefix_in_ckpt = 'model'
         import torch.distributed as dist
-        sharded = (not local) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # (a process group of ONE rank - torch.distributed.run --nproc-per-node 1 - takes the same path: the broadcast is then RCCL's
+        # one-rank case, which keeps the collective path exercised on single-GPU boxes)
+        sharded = (not local) and dist.is_available() and dist.is_initialized()
         self.loaded_from_cache = False
         if hasattr(model, 'load_packed_arena'):
             # the packed arena is cached next to the checkpoint (some_amd/arena_cache.py) and, with one process per GPU,

@@ -13,7 +13,8 @@ def dist_env() -> Tuple[int, int, int]:
 def init_distributed(backend: str = None):
     """Initialise torch.distributed when launched with WORLD_SIZE > 1; returns the module or None."""
     rank, local_rank, world = dist_env()
-    if world <= 1:
+    launched = 'RANK' in os.environ and 'MASTER_PORT' in os.environ     # torch.distributed.run, also with one process: the RCCL
+    if world <= 1 and not launched:                                      # communicator / broadcast / gather path runs on a 1-GPU box too
         return None
     import torch
     import torch.distributed as dist
@@ -53,7 +54,7 @@ def partition(sizes: Sequence[float], rank: int, world: int) -> List[int]:
 def broadcast_arena(arena, src: int = 0):
     """In-place broadcast of the packed weight arena from ``src`` to every rank (one collective)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.broadcast(arena, src=src)
     return arena
 
@@ -61,7 +62,7 @@ def broadcast_arena(arena, src: int = 0):
 def gather_to_rank0(items: List[Tuple[int, Any]]) -> List[Tuple[int, Any]]:
     """Collect (row_index, payload) pairs from every rank on rank 0 (others get [])."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return list(items)
     world, rank = dist.get_world_size(), dist.get_rank()
     buckets = [None] * world if rank == 0 else None
