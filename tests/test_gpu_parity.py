@@ -780,3 +780,64 @@ def test_forward_is_capturable_in_a_hip_graph(engines):
     torch.cuda.synchronize()
     want = eng.forward(eng.logmel(other, batch), batch, head_mode=_lib.HEAD_SIGMOID)
     assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1]) and not torch.equal(out[0], eager[0])
+
+
+@pytest.mark.parametrize('quantized', [False, True])
+def test_decode_edge_cases_vs_oracle_bit_exact(quantized):
+    """Decode corner cases of utils/infer_utils.py:9-76 on the GPU vs the order-fixed oracle, bit for bit: exact argmax ties (first
+    maximum wins), the Gaussian window clipped at bins 0 and 127, all-zero probabilities (0-safe weighted mean), max(p) exactly at
+    the rest threshold, bound cumsums landing exactly on x.5 (round half to even), clips of 1 - 3 frames, a fully masked clip, notes
+    that lose exactly half of their frames to the mask (>= 0.5 keeps them), and the quantised head's class 128 = rest."""
+    from oracle import restate
+    from some_amd.engine import ClipBatch, Engine
+    cfg = get_config('quant_two_head_model' if quantized else 'midi_conformer', lay=0)
+    nb = cfg['midi_num_bins']
+    eng = Engine(cfg, device='cuda')
+    rng = np.random.default_rng(5)
+    probs, bounds, masks = [], [], []
+
+    def clip(t, p, b, m=None):
+        probs.append(np.asarray(p, np.float32).reshape(t, nb))
+        bounds.append(np.asarray(b, np.float32).reshape(t))
+        masks.append(np.ones(t, bool) if m is None else np.asarray(m, bool))
+
+    t = 64
+    p = np.zeros((t, nb), np.float32)
+    p[:, 60] = 0.5; p[:, 61] = 0.5                                   # exact ties: argmax = first maximum
+    p[8:16] = 0.0                                                    # all-zero frames
+    p[16:24, :] = 0.0; p[16:24, 0] = 0.9; p[16:24, 1] = 0.3          # window clipped at bin 0
+    p[24:32, :] = 0.0; p[24:32, 127] = 0.7; p[24:32, 126] = 0.7      # tie at the top edge, window clipped at 127
+    p[32:40, :] = 0.0; p[32:40, 64] = np.float32(0.1)                # max(p) == rest threshold exactly (not < 0.1: not a rest)
+    p[40:48, :] = 0.0; p[40:48, 64] = np.nextafter(np.float32(0.1), np.float32(0))   # just below
+    if quantized:
+        p[48:56, :] = 0.0; p[48:56, 128] = 1.0                       # class 128 = rest
+    b = np.zeros(t, np.float32)
+    b[[0, 3, 4, 10, 11]] = 0.5                                       # cumsum 0.5, 1.0, 1.5, 2.0, 2.5: half-to-even at every other step
+    b[20:28] = 0.25
+    b[40] = 1.0; b[41] = 1.0; b[42] = 1.0                            # three notes of one frame
+    clip(t, p, b)
+    for tt in (1, 2, 3):                                             # tiny clips
+        clip(tt, rng.uniform(0, 1, (tt, nb)), rng.uniform(0, 1, tt))
+    clip(20, rng.uniform(0, 1, (20, nb)), rng.uniform(0, 1, 20), np.zeros(20, bool))          # fully masked
+    t = 40                                                           # notes of 4 frames, masks removing exactly 2 / 3 / 1 of them
+    b = np.zeros(t, np.float32); b[::4] = 1.0
+    m = np.ones(t, bool); m[0:2] = False; m[4:7] = False; m[8] = False
+    clip(t, rng.uniform(0, 1, (t, nb)), b, m)
+    t = 300                                                          # random, coarse-grained probabilities: many ties
+    clip(t, np.round(rng.uniform(0, 1, (t, nb)) * 4) / 4, np.round(rng.uniform(0, 1, t) * 8) / 8, rng.uniform(size=t) > 0.2)
+    lens = [len(x) for x in bounds]
+    batch = ClipBatch(lens, 'cuda')
+    out = eng.decode(torch.from_numpy(np.concatenate(probs)).cuda(), torch.from_numpy(np.concatenate(bounds)).cuda(), batch,
+                     quantized=quantized, mask=torch.from_numpy(np.concatenate(masks)).cuda(), debug=True)
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    for i, t in enumerate(lens):
+        ref = restate.postprocess(probs[i], bounds[i], cfg, quantized=quantized, masks=masks[i])
+        s = batch.frame_offsets[i]
+        n = int(out['n_notes'][i])
+        np.testing.assert_array_equal(out['frame2item'][s:s + t], ref['_frame2item'], err_msg=f'clip {i}')
+        np.testing.assert_array_equal(out['values'][s:s + t], ref['_values'], err_msg=f'clip {i}')
+        np.testing.assert_array_equal(out['rest'][s:s + t].astype(bool), ref['_rest'], err_msg=f'clip {i}')
+        assert n == len(ref['note_midi']), i
+        np.testing.assert_array_equal(out['note_midi'][s:s + n], ref['note_midi'], err_msg=f'clip {i}')
+        np.testing.assert_array_equal(out['note_dur'][s:s + n] * (512 / 44100), ref['note_dur'], err_msg=f'clip {i}')
+        np.testing.assert_array_equal(out['note_rest'][s:s + n].astype(bool), ref['note_rest'], err_msg=f'clip {i}')

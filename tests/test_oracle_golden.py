@@ -189,3 +189,56 @@ def test_golden_recipe_reproduces_committed_fixtures_in_one_process(tmp_path, go
     assert len(made) >= 7, made
     for name in made:
         assert (tmp_path / name).read_bytes() == (golden_dir / name).read_bytes(), name
+
+
+@pytest.mark.skipif(not __import__('pathlib').Path('/root/reference/utils/infer_utils.py').exists(),
+                    reason='the reference tree is mounted in the build container only')
+def test_oracle_decode_equals_the_reference_functions_on_edge_cases():
+    """The decode corner cases the GPU test feeds the device decoder (tests/test_gpu_parity.py::test_decode_edge_cases_...) through
+    the REFERENCE's own utils/infer_utils.py (loaded file-level, mido stubbed) and through the oracle: integers identical, fp32 note
+    values to 1e-6 (the reference's torch.sum lane order is machine-dependent; the oracle fixes ascending order)."""
+    import importlib.util
+    import sys
+    import types
+    import torch
+    from oracle import restate
+    from some_amd.configs import get_config
+    sys.modules.setdefault('mido', types.SimpleNamespace(MidiFile=object, MidiTrack=object, MetaMessage=object, Message=object, bpm2tempo=lambda x: x))
+    spec = importlib.util.spec_from_file_location('ref_infer_utils_edge', '/root/reference/utils/infer_utils.py')
+    iu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(iu)
+    cfg = get_config('midi_conformer', lay=0)
+    rng = np.random.default_rng(5)
+    t, nb = 64, 128
+    p = np.zeros((t, nb), np.float32)
+    p[:, 60] = 0.5; p[:, 61] = 0.5
+    p[8:16] = 0.0
+    p[16:24, :] = 0.0; p[16:24, 0] = 0.9; p[16:24, 1] = 0.3
+    p[24:32, :] = 0.0; p[24:32, 127] = 0.7; p[24:32, 126] = 0.7
+    p[32:40, :] = 0.0; p[32:40, 64] = np.float32(0.1)
+    p[40:48, :] = 0.0; p[40:48, 64] = np.nextafter(np.float32(0.1), np.float32(0))
+    b = np.zeros(t, np.float32)
+    b[[0, 3, 4, 10, 11]] = 0.5
+    b[20:28] = 0.25
+    b[40:43] = 1.0
+    cases = [(p, b, np.ones(t, bool))]
+    b2 = np.zeros(40, np.float32); b2[::4] = 1.0
+    m2 = np.ones(40, bool); m2[0:2] = False; m2[4:7] = False; m2[8] = False
+    cases.append((rng.uniform(0, 1, (40, nb)).astype(np.float32), b2, m2))
+    cases.append(((np.round(rng.uniform(0, 1, (300, nb)) * 4) / 4).astype(np.float32), (np.round(rng.uniform(0, 1, 300) * 8) / 8).astype(np.float32),
+                  rng.uniform(size=300) > 0.2))
+    for pp, bb, mm in cases:
+        ref = restate.postprocess(pp, bb, cfg, quantized=False, masks=mm)
+        P, B, M = torch.from_numpy(pp)[None], torch.from_numpy(bb)[None], torch.from_numpy(mm)[None]
+        P, B = P * M[..., None], B * M                                                       # me_infer.py:80-82
+        f2i = iu.decode_bounds_to_alignment(B) * M
+        val, rest = iu.decode_gaussian_blurred_probs(P, vmin=0, vmax=127, deviation=1.0, threshold=0.1)
+        nm, nd, nmask = iu.decode_note_sequence(f2i, val, M & ~rest, threshold=0.5)
+        np.testing.assert_array_equal(f2i[0].numpy(), ref['_frame2item'])
+        np.testing.assert_array_equal(rest[0].numpy(), ref['_rest'])
+        np.testing.assert_allclose(val[0].numpy(), ref['_values'], rtol=1e-6, atol=0)
+        assert nm.shape[1] == len(ref['note_midi'])
+        np.testing.assert_array_equal(nd[0].numpy() * (512 / 44100), ref['note_dur'])
+        np.testing.assert_array_equal(~nmask[0].numpy(), ref['note_rest'])
+        keep = nmask[0].numpy()
+        np.testing.assert_allclose(nm[0].numpy()[keep], ref['note_midi'][keep], rtol=1e-6, atol=0)
