@@ -1,0 +1,46 @@
+#!/bin/bash
+# round 3, GPU call 8: ping-pong attention kernel - correctness (bitwise vs the 4-wave kernel), parity subset, A/B timing
+O=gpurun_out/r03j; mkdir -p $O
+python - <<'PY' 2>&1 | grep -v amdgpu.ids
+import ctypes as C, os, sys, subprocess, json
+import numpy as np, torch
+sys.path.insert(0, '.')
+code = r"""
+import ctypes as C, os, sys, torch, numpy as np
+sys.path.insert(0, '.')
+from some_amd import _lib
+from some_amd.configs import get_config
+from some_amd.engine import ClipBatch, Engine
+p = lambda t: C.c_void_p(t.data_ptr())
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+eng = Engine(get_config('midi_conformer', lay=1), device='cuda')
+def split(x):
+    out = torch.empty_like(x); _lib.check(eng.handle, eng.lib.some_op_split_rows(eng.handle, p(x), p(out), x.shape[0], x.shape[1], st())); return out
+res = {}
+for lens in ([64], [1], [33], [130, 257], [128, 1, 300, 65], [862], [2584, 100], [2584] * 9 + [64, 200], [255], [256], [257], [511, 513]):
+    g = torch.Generator(device='cuda').manual_seed(100 + sum(lens))
+    batch = ClipBatch(lens, 'cuda'); M = batch.total_frames
+    h = torch.randn(M, 512, device='cuda', generator=g); W = torch.randn(1536, 512, device='cuda', generator=g) / 512 ** 0.5; W[:512] *= 3.0
+    ldv = (M + 255) // 256 * 256
+    ws = torch.empty(M * 4096 + 2048 * ldv, dtype=torch.uint8, device='cuda'); hs, Ws = split(h), split(W)
+    outs = []
+    for rep in range(3):
+        out = torch.full((M, 512), float('nan'), device='cuda')
+        _lib.check(eng.handle, eng.lib.some_op_qkv_attention_f16x3(eng.handle, p(hs), p(Ws), p(batch.frame_offsets_dev), batch.B, batch.max_frames, M, p(out), p(ws), ws.numel(), st()))
+        torch.cuda.synchronize(); outs.append(out.clone())
+    assert all(torch.equal(outs[0], o) for o in outs[1:]), ('not repeatable', lens)
+    res[str(lens)] = outs[0].cpu()
+torch.save(res, sys.argv[1])
+"""
+open('/tmp/pp_run.py', 'w').write(code)
+for pp in ('0', '1'):
+    r = subprocess.run([sys.executable, '/tmp/pp_run.py', f'/tmp/pp_{pp}.pt'], env=dict(os.environ, SOME_AMD_ATTN_PP=pp), capture_output=True, text=True)
+    print('pp', pp, 'rc', r.returncode, r.stderr[-600:] if r.returncode else '')
+a, b = torch.load('/tmp/pp_0.pt'), torch.load('/tmp/pp_1.pt')
+for k in a:
+    same = torch.equal(a[k], b[k])
+    fin = bool(torch.isfinite(b[k].view(torch.float16).float()).all())
+    print(k[:40], 'bit-identical' if same else 'DIFFERENT: %d of %d elements' % (int((a[k] != b[k]).sum()), a[k].numel()), 'finite' if fin else 'NONFINITE')
+PY
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_determinism.py -x -q -k "qkv_attention or full_size_forward or full_size_qkv" > $O/pytest_a.txt 2>&1; tail -3 $O/pytest_a.txt
+tools/exp_ab.sh r03j/ab "pp0|SOME_AMD_ATTN_PP=0" "pp1|SOME_AMD_ATTN_PP=1" "pp0_b|SOME_AMD_ATTN_PP=0" "pp1_b|SOME_AMD_ATTN_PP=1" 2>&1 | cut -c1-120
