@@ -89,7 +89,10 @@ def _live_pmc(kernel_name: str, config_args) -> dict:
         return {}
     child = [sys.executable, str(ROOT / 'bench.py'), '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--no-kernel-profile', '--no-latency',
              '--no-f32-leg', '--no-secondary', '--no-live-pmc'] + list(config_args)
-    env = dict(os.environ, SOME_AMD_DUAL_STREAM='0', SOME_AMD_BENCH_CHILD='1', TMPDIR='/tmp')
+    # (a child must not join the parent's process group: drop the torch.distributed.run variables)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'GROUP_RANK',
+                                                              'LOCAL_WORLD_SIZE', 'ROLE_RANK', 'ROLE_WORLD_SIZE') and not k.startswith('TORCHELASTIC')}
+    env.update(SOME_AMD_DUAL_STREAM='0', SOME_AMD_BENCH_CHILD='1', TMPDIR='/tmp')
     sums = {}
     with tempfile.TemporaryDirectory(dir='/tmp') as tmp:
         for tag, counters in (('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE']), ('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE'])):
