@@ -247,6 +247,30 @@ int some_train_gemm16(SomeHandle* h, const float* A_dev, int32_t lda, int32_t ta
 int some_train_gemm16_wgrad(SomeHandle* h, const float* dY_dev, int32_t ldy, const float* X_dev, int32_t ldx, float* dW_dev, float* db_dev,
                             int32_t N, int32_t K, int32_t frames, int32_t operand, int32_t accumulate, void* partial_dev, size_t partial_bytes,
                             void* stream);
+/* ---- 16-bit STORED operands (mixed-precision training: under the reference's autocast, training/base_task.py:260-283 with
+ * pl_trainer_precision 'bf16' / '16-mixed', nn.Linear reads and writes 16-bit tensors) ----------------------------------------
+ * operand: 1 = f16, 2 = bf16 - the storage format of every `16` array of a call.
+ * some_train_cast16:      y16[i] = rn16(x[i]), n % 8 == 0, 16-byte aligned arrays.
+ * some_train_transpose16: W[N, K] fp32 -> W16[N, K] (forward operand) and / or W16T[K, N] (data-gradient operand); either may be NULL. */
+int some_train_cast16(SomeHandle* h, const float* x_dev, void* y16_dev, int64_t n, int32_t operand, void* stream);
+int some_train_transpose16(SomeHandle* h, const float* w_dev, void* w16_dev, void* w16t_dev, int32_t N, int32_t K, int32_t operand, void* stream);
+/* C[M, N] = A16[M, K] B16[N, K]^T, fp32 accumulation, both operands contraction-contiguous 16-bit arrays (K % 32 == 0, lda % 8 ==
+ * ldb % 8 == 0, 16-byte aligned) moved global -> LDS by DMA.  epilogue:
+ *   0  C fp32 [M, ldc] = acc (+ bias_dev[N] if not NULL)                                 nn.Linear forward / data gradient (B16 = W16T)
+ *   1  conform_ffn.forward's ln1 + act + drop1 (modules/conform/Gconform.py:29-32): C is TWO 16-bit planes, h16 = rn16(acc + bias) at C
+ *      and a16 = rn16(dropout_p(silu(h16))) at C + plane_elems elements (plane_elems >= M * ldc, even)
+ *   2  the gradient back through drop1 / act: C 16-bit [M, ldc] = rn16(acc * mask / (1 - p') * silu'(h16)), h16 = H16_dev [M, ldh] of the
+ *      forward call with the SAME (p, seed)
+ * Dropout: element (m, n) is zeroed when its 16 pseudo-random bits - a pure function of (seed, m, n) - are below round(65536 p); kept
+ * values are scaled by 1 / (1 - p'), p' = round(65536 p) / 65536, the rate actually applied.  p = 0: no dropout. */
+int some_train_gemm16s(SomeHandle* h, int32_t epilogue, const void* A16_dev, int32_t lda, const void* B16_dev, int32_t ldb, const float* bias_dev,
+                       void* C_dev, int32_t ldc, const void* H16_dev, int32_t ldh, int64_t plane_elems, int32_t M, int32_t N, int32_t K,
+                       int32_t operand, float p, uint64_t seed, void* stream);
+/* some_train_gemm16_wgrad on 16-bit stored operands: dW[N, K] (+)= dY16[frames, N]^T X16[frames, K], db[N] (+)= column sums of dY16
+ * (fp32 sums of the stored values).  ld % 4 == 0, 8-byte aligned operands; partial_dev as for some_train_gemm16_wgrad. */
+int some_train_gemm16_wgrad16(SomeHandle* h, const void* dY16_dev, int32_t ldy, const void* X16_dev, int32_t ldx, float* dW_dev, float* db_dev,
+                              int32_t N, int32_t K, int32_t frames, int32_t operand, int32_t accumulate, void* partial_dev, size_t partial_bytes,
+                              void* stream);
 /* out[n, m] = in[m, n] for m < M, 0 for M <= m < ld_out (the zero padding makes ld_out a valid contraction length).
  * split_out = 1: rows are written in SPLIT32 format (ready as a split-f16 GEMM operand; ld_out % 32 == 0);
  * split_out = 2: the same slots with bf16 hi halves (SOME_OPERAND_BF16). */

@@ -786,10 +786,13 @@ template <int MODE> struct Gemm16Cfg {
     static constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LDR * sizeof(float);
 };
 
-template <bool TA, bool TB, int MODE>
+// S16 (weight-gradient layout, one-product modes): both operands are STORED as 16-bit values of the mode's format (the FFN's 16-bit
+// activations of train_gemm16s.hip) - half the bytes per k-block, no conversion; the register transposition is a byte permute.
+template <bool TA, bool TB, int MODE, bool S16 = false>
 __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
     using Cfg = Gemm16Cfg<MODE>;
     constexpr bool SPLIT = Cfg::SPLIT, BF16 = MODE == 2;
+    static_assert(!S16 || (TA && TB && !SPLIT), "16-bit stored operands: weight-gradient layout of the one-product modes");
     constexpr int WAVES_M = 2, WAVES_N = 2, TM = 2, TN = Cfg::TN;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, LDR = Cfg::LDR;
     constexpr int STAGE = (BM + BN) * LDR;               // dwords
@@ -831,15 +834,16 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
     // row-contiguous operand ([32 k][R]): wavefront kq = tid / 64 owns k rows 8 kq .. 8 kq + 7, lane c owns R / 64 adjacent columns
     constexpr int NA = TA ? 8 : BM / 32, NB = TB ? 8 : BN / 32;     // loads per thread and k-block
     constexpr int WA = TA ? BM / 64 : 4, WB = TB ? BN / 64 : 4;     // floats per load
-    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(a.A, (size_t)(TA ? a.K : a.M) * a.lda * 4);
-    const __amdgpu_buffer_rsrc_t rsb = make_rsrc(a.B, (size_t)(TB ? a.K : a.N) * a.ldb * 4);
+    constexpr uint32_t ES = S16 ? 2u : 4u;                          // bytes per stored element
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(a.A, (size_t)(TA ? a.K : a.M) * a.lda * ES);
+    const __amdgpu_buffer_rsrc_t rsb = make_rsrc(a.B, (size_t)(TB ? a.K : a.N) * a.ldb * ES);
     const int srow = tid >> 3, scol = tid & 7;
     uint32_t va[NA], vb[NB];                                         // byte offsets of k-block 0 (row-contiguous: of k row 8 kq + r)
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
         if constexpr (TA) {
             const int col = m0 + WA * lane;
-            va[p] = col < a.M ? (uint32_t)(kt0 * 32 + 8 * wave + p) * (uint32_t)a.lda * 4u + (uint32_t)col * 4u : kOob;
+            va[p] = col < a.M ? (uint32_t)(kt0 * 32 + 8 * wave + p) * (uint32_t)a.lda * ES + (uint32_t)col * ES : kOob;
         } else {
             va[p] = (uint32_t)(m0 + srow + 32 * p) * (uint32_t)a.lda * 4u + (uint32_t)kt0 * 128u + scol * 16u;
         }
@@ -848,13 +852,14 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
     for (int p = 0; p < NB; ++p) {
         if constexpr (TB) {
             const int col = n0 + WB * lane;
-            vb[p] = col < a.N ? (uint32_t)(kt0 * 32 + 8 * wave + p) * (uint32_t)a.ldb * 4u + (uint32_t)col * 4u : kOob;
+            vb[p] = col < a.N ? (uint32_t)(kt0 * 32 + 8 * wave + p) * (uint32_t)a.ldb * ES + (uint32_t)col * ES : kOob;
         } else {
             vb[p] = (uint32_t)(n0 + srow + 32 * p) * (uint32_t)a.ldb * 4u + (uint32_t)kt0 * 128u + scol * 16u;
         }
     }
-    const uint32_t stepa = TA ? 32u * (uint32_t)a.lda * 4u : 128u, stepb = TB ? 32u * (uint32_t)a.ldb * 4u : 128u;
-    float ra[NA][WA], rb[NB][WB];
+    const uint32_t stepa = TA ? 32u * (uint32_t)a.lda * ES : 128u, stepb = TB ? 32u * (uint32_t)a.ldb * ES : 128u;
+    float ra[S16 ? 1 : NA][WA], rb[S16 ? 1 : NB][WB];
+    uint32_t qa[S16 ? NA : 1][WA / 2], qb[S16 ? NB : 1][WB / 2];      // S16: dwords of two adjacent columns
     auto ldw = [](__amdgpu_buffer_rsrc_t r, uint32_t off, float* dst, auto width) {
         constexpr int W = decltype(width)::value;
         if constexpr (W == 4) {
@@ -865,13 +870,43 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
             dst[0] = t[0]; dst[1] = t[1];
         }
     };
+    auto ldq = [](__amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t* dst, auto width) {
+        constexpr int W = decltype(width)::value;                   // dwords
+        if constexpr (W == 2) {
+            const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+            dst[0] = t[0]; dst[1] = t[1];
+        } else {
+            dst[0] = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+        }
+    };
     auto gload = [&]() {                  // the next k-block (offsets advance with every call)
 #pragma unroll
-        for (int p = 0; p < NA; ++p) { ldw(rsa, va[p], ra[p], std::integral_constant<int, WA>{}); if (va[p] < kOob) va[p] += stepa; }
+        for (int p = 0; p < NA; ++p) {
+            if constexpr (S16) ldq(rsa, va[p], qa[p], std::integral_constant<int, WA / 2>{});
+            else ldw(rsa, va[p], ra[p], std::integral_constant<int, WA>{});
+            if (va[p] < kOob) va[p] += stepa;
+        }
 #pragma unroll
-        for (int p = 0; p < NB; ++p) { ldw(rsb, vb[p], rb[p], std::integral_constant<int, WB>{}); if (vb[p] < kOob) vb[p] += stepb; }
+        for (int p = 0; p < NB; ++p) {
+            if constexpr (S16) ldq(rsb, vb[p], qb[p], std::integral_constant<int, WB / 2>{});
+            else ldw(rsb, vb[p], rb[p], std::integral_constant<int, WB>{});
+            if (vb[p] < kOob) vb[p] += stepb;
+        }
     };
     float csum[TA ? WA : 1] = {};
+    const bool want_sum = a.sum_col >= 0 && n_tile == 0;            // only the first column tile writes the bias gradient
+    // S16: column c of eight k rows (dwords q[0..7] of the column pair holding c) -> the 16 bytes of one LDS row piece
+    auto put8q = [&](uint32_t* dst, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t q4, uint32_t q5, uint32_t q6, uint32_t q7, int c) {
+        const uint32_t sel = (c & 1) ? 0x07060302u : 0x05040100u;  // v_perm_b32: the chosen halves of (second, first)
+        const u32x4 v = {__builtin_amdgcn_perm(q1, q0, sel), __builtin_amdgcn_perm(q3, q2, sel), __builtin_amdgcn_perm(q5, q4, sel),
+                         __builtin_amdgcn_perm(q7, q6, sel)};
+        *reinterpret_cast<u32x4*>(dst) = v;
+    };
+    auto f16of = [](uint32_t q, int c) -> float {
+        const uint32_t b = (c & 1) ? q >> 16 : q & 0xffffu;
+        if constexpr (BF16) return __builtin_bit_cast(float, b << 16);
+        else return (float)__builtin_bit_cast(half_t, (uint16_t)b);
+    };
     // eight k values of one row -> 16 bytes of hi halves (and, split mode, 16 bytes of lo halves 16 dwords further)
     auto put8 = [&](uint32_t* dst, float k0, float k1, float k2, float k3, float k4, float k5, float k6, float k7) {
         uint32_t l0, l1, l2, l3;
@@ -887,23 +922,39 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
     };
     auto lstore = [&](int buf) {
         uint32_t* base = L + buf * STAGE;
-        if constexpr (TA) {
+        if constexpr (S16) {
 #pragma unroll
             for (int c = 0; c < WA; ++c) {
-                if constexpr (TB) csum[c] += ((ra[0][c] + ra[1][c]) + (ra[2][c] + ra[3][c])) + ((ra[4][c] + ra[5][c]) + (ra[6][c] + ra[7][c]));
-                put8(base + (WA * lane + c) * LDR + wave * 4, ra[0][c], ra[1][c], ra[2][c], ra[3][c], ra[4][c], ra[5][c], ra[6][c], ra[7][c]);
+                const int d = c >> 1;
+                if (want_sum)
+                    csum[c] += ((f16of(qa[0][d], c) + f16of(qa[1][d], c)) + (f16of(qa[2][d], c) + f16of(qa[3][d], c))) +
+                               ((f16of(qa[4][d], c) + f16of(qa[5][d], c)) + (f16of(qa[6][d], c) + f16of(qa[7][d], c)));
+                put8q(base + (WA * lane + c) * LDR + wave * 4, qa[0][d], qa[1][d], qa[2][d], qa[3][d], qa[4][d], qa[5][d], qa[6][d], qa[7][d], c);
+            }
+#pragma unroll
+            for (int c = 0; c < WB; ++c) {
+                const int d = c >> 1;
+                put8q(base + (BM + WB * lane + c) * LDR + wave * 4, qb[0][d], qb[1][d], qb[2][d], qb[3][d], qb[4][d], qb[5][d], qb[6][d], qb[7][d], c);
             }
         } else {
+            if constexpr (TA) {
 #pragma unroll
-            for (int p = 0; p < NA; ++p) put4(base + (srow + 32 * p) * LDR + scol * 2, ra[p]);
-        }
-        if constexpr (TB) {
+                for (int c = 0; c < WA; ++c) {
+                    if constexpr (TB) csum[c] += ((ra[0][c] + ra[1][c]) + (ra[2][c] + ra[3][c])) + ((ra[4][c] + ra[5][c]) + (ra[6][c] + ra[7][c]));
+                    put8(base + (WA * lane + c) * LDR + wave * 4, ra[0][c], ra[1][c], ra[2][c], ra[3][c], ra[4][c], ra[5][c], ra[6][c], ra[7][c]);
+                }
+            } else {
 #pragma unroll
-            for (int c = 0; c < WB; ++c)
-                put8(base + (BM + WB * lane + c) * LDR + wave * 4, rb[0][c], rb[1][c], rb[2][c], rb[3][c], rb[4][c], rb[5][c], rb[6][c], rb[7][c]);
-        } else {
+                for (int p = 0; p < NA; ++p) put4(base + (srow + 32 * p) * LDR + scol * 2, ra[p]);
+            }
+            if constexpr (TB) {
 #pragma unroll
-            for (int p = 0; p < NB; ++p) put4(base + (BM + srow + 32 * p) * LDR + scol * 2, rb[p]);
+                for (int c = 0; c < WB; ++c)
+                    put8(base + (BM + WB * lane + c) * LDR + wave * 4, rb[0][c], rb[1][c], rb[2][c], rb[3][c], rb[4][c], rb[5][c], rb[6][c], rb[7][c]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < NB; ++p) put4(base + (BM + srow + 32 * p) * LDR + scol * 2, rb[p]);
+            }
         }
     };
 
@@ -987,7 +1038,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
     if constexpr (TA && TB) {
         // bias gradient: sum over this slice's contraction rows of A's stored array, per output row; wavefront w holds the rows
         // 8 w .. 8 w + 7 of every k-block - combined in wavefront order (deterministic) by the first column tile
-        if (a.sum_col >= 0 && n_tile == 0) {
+        if (want_sum) {
             __syncthreads();
             float* red = lds;                            // [4][BM]
 #pragma unroll
@@ -999,11 +1050,11 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
     }
 }
 
-template <bool TA, bool TB, int MODE>
+template <bool TA, bool TB, int MODE, bool S16 = false>
 hipError_t launch_gemm16_cfg(const Gemm16Args& a_in, hipStream_t s) {
     using Cfg = Gemm16Cfg<MODE>;
     static bool attr_set = false;
-    auto kern = &gemm16_kernel<TA, TB, MODE>;
+    auto kern = &gemm16_kernel<TA, TB, MODE, S16>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -1090,14 +1141,16 @@ static hipError_t launch_gemm16_mode(const Gemm16Args& a, int ta, int tb, hipStr
 }
 
 hipError_t launch_gemm16(const float* A, int lda, int ta, const float* B, int ldb, int tb, const float* bias, float* C, int ldc,
-                         int M, int N, int K, int mode, int slices, size_t slice_stride, int sum_col, hipStream_t s) {
+                         int M, int N, int K, int mode, int slices, size_t slice_stride, int sum_col, hipStream_t s, int stored16) {
     if (M <= 0 || N <= 0 || K <= 0) return hipSuccess;
     if ((lda & 3) || (ldb & 3) || (!(ta && tb) && (K & 31)) || (ta && (M & 1)) || (tb && (N & 3))) return hipErrorInvalidValue;
     if ((!ta || !tb) && (slices > 1 || sum_col >= 0)) return hipErrorInvalidValue;
     if ((ta && !tb) || mode < 1 || mode > 3) return hipErrorInvalidValue;
+    if (stored16 && (!ta || !tb || mode == 3)) return hipErrorInvalidValue;
     Gemm16Args a{};
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.k_slices = slices; a.slice_stride = slice_stride; a.sum_col = sum_col;
+    if (stored16) return mode == 1 ? launch_gemm16_cfg<true, true, 1, true>(a, s) : launch_gemm16_cfg<true, true, 2, true>(a, s);
     if (mode == 1) return launch_gemm16_mode<1>(a, ta, tb, s);
     if (mode == 2) return launch_gemm16_mode<2>(a, ta, tb, s);
     return launch_gemm16_mode<3>(a, ta, tb, s);

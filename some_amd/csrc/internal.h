@@ -64,8 +64,14 @@ hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a, int tile, hipStream
 // GEMM on fp32 operands rounded / split in the staging path, either operand stored contraction-major (gemm16_kernel);
 // mode 1 f16, 2 bf16 (one product), 3 split-f16 (three products, fp32-equivalent)
 hipError_t launch_gemm16(const float* A, int lda, int ta, const float* B, int ldb, int tb, const float* bias, float* C, int ldc,
-                         int M, int N, int K, int mode, int slices, size_t slice_stride, int sum_col, hipStream_t s);
+                         int M, int N, int K, int mode, int slices, size_t slice_stride, int sum_col, hipStream_t s, int stored16 = 0);
 int gemm16_tile_n(int mode);
+// GEMMs on operands stored as 16-bit values (train_gemm16s.hip): C = A16 [M, K] B16 [N, K]^T through a DMA ring; epi 0 fp32 (+ bias),
+// 1 the FFN's first linear (bias, h16 | a16 = dropout(silu(h16)) planes), 2 the data gradient through dropout / SiLU (reads h16)
+hipError_t launch_gemm16s(int epi, const void* A16, int lda, const void* B16, int ldb, const float* bias, void* C, int ldc, const void* H16,
+                          int ldh, size_t plane_bytes, int M, int N, int K, int bf16, float p, uint64_t seed, hipStream_t s);
+hipError_t launch_cast16(const float* x, void* y16, int64_t n, int bf16, hipStream_t s);
+hipError_t launch_transpose16(const float* w, void* w16, void* w16t, int N, int K, int bf16, hipStream_t s);
 
 // ---- row ops --------------------------------------------------------------------------------------
 // y[g][m][:] = LayerNorm(x[g][m][:]) * gamma[g] + beta[g], eps 1e-5, rows of 512.

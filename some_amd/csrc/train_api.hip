@@ -129,6 +129,75 @@ int some_train_gemm16_wgrad(SomeHandle* h, const float* dY_dev, int32_t ldy, con
     return SOME_OK;
 }
 
+int some_train_cast16(SomeHandle* h, const float* x_dev, void* y16_dev, int64_t n, int32_t operand, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, n >= 0 && (n % 8) == 0 && (n == 0 || (x_dev && y16_dev)), "some_train_cast16: n % 8 == 0, non-null arrays");
+    T_CHECK(h, operand == 1 || operand == 2, "some_train_cast16: operand must be 1 (f16) or 2 (bf16)");
+    T_CHECK(h, ((reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(y16_dev)) & 15) == 0, "some_train_cast16: 16-byte aligned arrays");
+    T_TRY(h, launch_cast16(x_dev, y16_dev, n, operand == 2, st(stream)));
+    return SOME_OK;
+}
+
+int some_train_transpose16(SomeHandle* h, const float* w_dev, void* w16_dev, void* w16t_dev, int32_t N, int32_t K, int32_t operand, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, N > 0 && K > 0 && w_dev && (w16_dev || w16t_dev), "some_train_transpose16: bad argument");
+    T_CHECK(h, operand == 1 || operand == 2, "some_train_transpose16: operand must be 1 (f16) or 2 (bf16)");
+    T_TRY(h, launch_transpose16(w_dev, w16_dev, w16t_dev, N, K, operand == 2, st(stream)));
+    return SOME_OK;
+}
+
+int some_train_gemm16s(SomeHandle* h, int32_t epilogue, const void* A16_dev, int32_t lda, const void* B16_dev, int32_t ldb, const float* bias_dev,
+                       void* C_dev, int32_t ldc, const void* H16_dev, int32_t ldh, int64_t plane_elems, int32_t M, int32_t N, int32_t K,
+                       int32_t operand, float p, uint64_t seed, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M > 0 && N > 0 && K > 0 && A16_dev && B16_dev && C_dev, "some_train_gemm16s: bad argument");
+    T_CHECK(h, operand == 1 || operand == 2, "some_train_gemm16s: operand must be 1 (f16) or 2 (bf16)");
+    T_CHECK(h, epilogue >= 0 && epilogue <= 2, "some_train_gemm16s: epilogue must be 0 (fp32), 1 (FFN first linear) or 2 (SiLU / dropout gradient)");
+    T_CHECK(h, (K % 32) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && lda >= K && ldb >= K, "some_train_gemm16s: K % 32, ld % 8 (16-byte rows), ld >= K");
+    T_CHECK(h, (N % 2) == 0 && ldc >= N && (epilogue == 0 || (ldc % 2) == 0), "some_train_gemm16s: N even, ldc >= N (even for 16-bit outputs)");
+    T_CHECK(h, ((reinterpret_cast<uintptr_t>(A16_dev) | reinterpret_cast<uintptr_t>(B16_dev)) & 15) == 0 && (reinterpret_cast<uintptr_t>(C_dev) & 3) == 0,
+            "some_train_gemm16s: operands must be 16-byte aligned");
+    T_CHECK(h, p >= 0.f && p < 1.f, "some_train_gemm16s: dropout rate in [0, 1)");
+    const size_t lim = 0x7fffffffull;
+    size_t plane_bytes = 0;
+    if (epilogue == 0) {
+        T_CHECK(h, (size_t)M * ldc * 4 <= lim, "some_train_gemm16s: the output exceeds 2 GiB (split the batch)");
+    } else if (epilogue == 1) {
+        T_CHECK(h, bias_dev != nullptr, "some_train_gemm16s: the FFN epilogue needs the bias");
+        T_CHECK(h, plane_elems >= (int64_t)M * ldc && (plane_elems % 2) == 0, "some_train_gemm16s: plane_elems (h16 -> a16 distance) must cover M * ldc, even");
+        plane_bytes = (size_t)plane_elems * 2;
+        T_CHECK(h, plane_bytes + (size_t)M * ldc * 2 <= lim, "some_train_gemm16s: the two output planes exceed 2 GiB (split the batch)");
+    } else {
+        T_CHECK(h, H16_dev != nullptr && ldh >= N && (ldh % 2) == 0 && (reinterpret_cast<uintptr_t>(H16_dev) & 3) == 0, "some_train_gemm16s: h16 (ldh >= N, even)");
+        T_CHECK(h, (size_t)M * ldc * 2 <= lim && (size_t)M * ldh * 2 <= lim, "some_train_gemm16s: an array exceeds 2 GiB (split the batch)");
+    }
+    T_CHECK(h, (uint64_t)((M + 1) / 2) * (uint64_t)N <= 0xffffffffull, "some_train_gemm16s: more than 2^32 dropout cells");
+    T_TRY(h, launch_gemm16s(epilogue, A16_dev, lda, B16_dev, ldb, bias_dev, C_dev, ldc, H16_dev, ldh, plane_bytes, M, N, K, operand == 2, p, seed,
+                            st(stream)));
+    return SOME_OK;
+}
+
+int some_train_gemm16_wgrad16(SomeHandle* h, const void* dY16_dev, int32_t ldy, const void* X16_dev, int32_t ldx, float* dW_dev, float* db_dev,
+                              int32_t N, int32_t K, int32_t frames, int32_t operand, int32_t accumulate, void* partial_dev, size_t partial_bytes,
+                              void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, N > 0 && K > 0 && frames > 0 && dY16_dev && X16_dev && dW_dev && partial_dev, "some_train_gemm16_wgrad16: bad argument");
+    T_CHECK(h, operand == 1 || operand == 2, "some_train_gemm16_wgrad16: operand must be 1 (f16) or 2 (bf16)");
+    T_CHECK(h, (ldy % 4) == 0 && (ldx % 4) == 0 && ldy >= N && ldx >= K && (N % 2) == 0 && (K % 4) == 0, "some_train_gemm16_wgrad16: shapes (ld % 4, N even, K % 4)");
+    T_CHECK(h, (reinterpret_cast<uintptr_t>(dW_dev) & 15) == 0 && ((reinterpret_cast<uintptr_t>(dY16_dev) | reinterpret_cast<uintptr_t>(X16_dev)) & 7) == 0,
+            "some_train_gemm16_wgrad16: dW must be 16-byte, the operands 8-byte aligned");
+    const int ldc = K + 4;
+    const size_t lim = 0x7fffffffull;
+    T_CHECK(h, (size_t)frames * ldy * 2 <= lim && (size_t)frames * ldx * 2 <= lim && (size_t)N * ldc * 4 <= lim, "some_train_gemm16_wgrad16: an operand exceeds 2 GiB (split the batch)");
+    const int slices = gemm16_slices(N, K, frames, operand);
+    T_CHECK(h, partial_bytes >= (size_t)slices * (size_t)N * ldc * sizeof(float), "some_train_gemm16_wgrad16: partial buffer too small (some_train_gemm16_bytes(N, K, frames, K + 4))");
+    float* planes = static_cast<float*>(partial_dev);
+    T_TRY(h, launch_gemm16(static_cast<const float*>(dY16_dev), ldy, 1, static_cast<const float*>(X16_dev), ldx, 1, nullptr, planes, ldc, N, K, frames,
+                           operand, slices, (size_t)N * ldc, db_dev ? K : -1, st(stream), 1));
+    T_TRY(h, launch_reduce_wgrad(planes, slices, (size_t)N * ldc, N, K, ldc, dW_dev, db_dev, accumulate, st(stream)));
+    return SOME_OK;
+}
+
 int some_train_transpose(SomeHandle* h, const float* in_dev, int32_t M, int32_t N, int32_t ld_in, float* out_dev,
                          int32_t ld_out, int32_t split_out, void* stream) {
     if (!h) return SOME_EINVAL;

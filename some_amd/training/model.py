@@ -116,9 +116,7 @@ class TrainableMidiConforms:
     def _ffn(self, x, pre: str):
         """conform_ffn.forward (Gconform.py:29-34) WITHOUT its output dropout, which the caller fuses into the residual."""
         P, o = self.params, self.ops
-        h = o.linear(x, P[pre + '.ln1.weight'], P[pre + '.ln1.bias'])
-        h = o.silu_dropout(h, *self._drop('ffn_latent'))
-        return o.linear(h, P[pre + '.ln2.weight'], P[pre + '.ln2.bias'])
+        return o.ffn(x, P[pre + '.ln1.weight'], P[pre + '.ln1.bias'], P[pre + '.ln2.weight'], P[pre + '.ln2.bias'], *self._drop('ffn_latent'))
 
     def _attention(self, x, pre: str, batch):
         P, o = self.params, self.ops
@@ -148,6 +146,7 @@ class TrainableMidiConforms:
     def forward(self, units: torch.Tensor, batch: ClipBatch, mask: Optional[torch.Tensor] = None):
         """Gmidi_conform.forward (Gconform.py:119-140) + midi_conforms.forward(sig=False)."""
         P, o = self.params, self.ops
+        o.weights_version += 1                     # the parameters may have moved since the last pass: 16-bit weight images are re-derived
         units = units.reshape(-1, units.shape[-1]).contiguous()
         mask_u8 = None if mask is None else mask.reshape(-1).to(torch.uint8).contiguous()
         x = o.linear(units, P['model.inln.weight'], P['model.inln.bias'])

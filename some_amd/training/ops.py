@@ -43,6 +43,13 @@ class TrainOps:
         self._sinks: Dict[int, torch.Tensor] = {}
         self.on_grad_ready = None
         self.use_sinks = os.environ.get('SOME_AMD_TRAIN_SINKS', '1') != '0'
+        # Mixed precision only: the FFN's [M, 2048] intermediates live in memory as 16-bit arrays written / read by GEMM epilogues
+        # (csrc/train_gemm16s.hip) and its four matrix products read 16-bit operands through the DMA-ring kernel; the weights' 16-bit
+        # images are re-derived when ``weights_version`` moves (the model bumps it at the start of every forward pass).
+        # SOME_AMD_TRAIN_FFN16=0: the composition of linear / silu_dropout / linear on fp32 arrays (A/B runs).
+        self.ffn16 = os.environ.get('SOME_AMD_TRAIN_FFN16', '1') != '0'
+        self.weights_version = 0
+        self._shadows: Dict[int, tuple] = {}
 
     def set_mixed_precision(self, on: bool, operand: str = 'f16'):
         """Mixed-precision training (the reference's pl_trainer_precision '16-mixed' / 'bf16'): the matrix products read one
@@ -86,6 +93,56 @@ class TrainOps:
             self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
         self.check(self.lib.some_train_gemm16_wgrad(self.h, _p(dy), N, _p(x), K, _p(dw), _p(db), N, K, M, self._op16, 1, _p(self._partial),
                                                     self._partial.numel(), self.stream()))
+
+    # ---- 16-bit stored operands (mixed precision) ---------------------------------------------------------------------
+    @property
+    def dtype16(self):
+        return torch.bfloat16 if self._hi_mode == 2 else torch.float16
+
+    def cast16(self, x: torch.Tensor) -> torch.Tensor:
+        """fp32 -> the mode's 16-bit format, round to nearest even (some_train_cast16)."""
+        out = torch.empty(x.shape, dtype=self.dtype16, device=self.device)
+        if x.numel() % 8 or x.data_ptr() % 16:
+            return out.copy_(x)
+        self.check(self.lib.some_train_cast16(self.h, _p(x), _p(out), x.numel(), self._hi_mode, self.stream()))
+        return out
+
+    def shadow16(self, w: torch.Tensor):
+        """(W16 [N, K], W16T [K, N]) of the fp32 weight ``w`` [N, K], cached until ``weights_version`` moves."""
+        key = id(w)
+        hit = self._shadows.get(key)
+        if hit is not None and hit[0] == (self.weights_version, self._hi_mode, w.data_ptr()):
+            return hit[1], hit[2]
+        N, K = w.shape
+        if hit is not None and hit[1].dtype == self.dtype16 and hit[1].shape == w.shape:
+            w16, w16t = hit[1], hit[2]                                   # refreshed in place: same buffers every step
+        else:
+            w16 = torch.empty((N, K), dtype=self.dtype16, device=self.device)
+            w16t = torch.empty((K, N), dtype=self.dtype16, device=self.device)
+        self.check(self.lib.some_train_transpose16(self.h, _p(w), _p(w16), _p(w16t), N, K, self._hi_mode, self.stream()))
+        self._shadows[key] = ((self.weights_version, self._hi_mode, w.data_ptr()), w16, w16t, w)   # keeps ``w`` alive: id() stays unique
+        return w16, w16t
+
+    def gemm16s(self, epi: int, a16: torch.Tensor, b16: torch.Tensor, bias, out: torch.Tensor, ldc: int, M: int, N: int, K: int,
+                h16: Optional[torch.Tensor] = None, plane: int = 0, p: float = 0.0, seed: int = 0):
+        """out = epilogue(a16 [M, K] @ b16 [N, K]^T): some_train_gemm16s (0 fp32 (+ bias), 1 FFN first linear, 2 SiLU / dropout gradient)."""
+        self.check(self.lib.some_train_gemm16s(self.h, epi, _p(a16), a16.stride(0), _p(b16), b16.stride(0), _p(bias), _p(out), ldc, _p(h16),
+                                               h16.stride(0) if h16 is not None else 0, plane, M, N, K, self._hi_mode, float(p), C.c_uint64(seed),
+                                               self.stream()))
+
+    def wgrad16(self, dy16: torch.Tensor, x16: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor], accumulate: bool):
+        """dw [N, K] (+)= dy16^T x16, db [N] (+)= column sums of dy16 (some_train_gemm16_wgrad16)."""
+        M, N = dy16.shape
+        K = x16.shape[1]
+        need = int(self.lib.some_train_gemm16_bytes(self.h, N, K, M, K + 4))
+        if self._partial is None or self._partial.numel() < need:
+            self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.check(self.lib.some_train_gemm16_wgrad16(self.h, _p(dy16), N, _p(x16), K, _p(dw), _p(db), N, K, M, self._hi_mode, int(accumulate),
+                                                      _p(self._partial), self._partial.numel(), self.stream()))
+
+    def can_ffn16(self, M: int, K: int, H: int, N: int) -> bool:
+        return (self.ffn16 and self._hi_mode in (1, 2) and self.gemm16 and M >= 64 and K % 32 == 0 and H % 32 == 0 and N % 32 == 0
+                and 4 * M * H < 0x7fffffff)
 
     # ---- plumbing -------------------------------------------------------------------------------------------
     def stream(self):
@@ -259,6 +316,12 @@ class TrainOps:
         """nn.Linear / k = 1 Conv1d: x [M, K], weight [N, K] -> [M, N]."""
         return _Linear.apply(self, x, weight, bias)
 
+    def ffn(self, x, w1, b1, w2, b2, p: float, seed: int):
+        """conform_ffn.forward up to its output dropout (Gconform.py:29-33): ln2(drop1(silu(ln1(x))))."""
+        if self.can_ffn16(x.shape[0], x.shape[1], w1.shape[0], w2.shape[0]):
+            return _Ffn16.apply(self, x, w1, b1, w2, b2, p, seed)
+        return self.linear(self.silu_dropout(self.linear(x, w1, b1), p, seed), w2, b2)
+
     def layernorm(self, x, gamma, beta):
         return _LayerNorm.apply(self, x, gamma, beta)
 
@@ -341,6 +404,64 @@ class _Linear(torch.autograd.Function):
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             db = ops.colsum(dy)
         return None, dx, dw, db
+
+
+class _Ffn16(torch.autograd.Function):
+    """The FFN of a conformer block in mixed precision with 16-bit intermediates: x [M, K] fp32 -> y [M, N] fp32.
+    forward:  x16 = rn16(x);  (h16 | a16) = epilogue(x16 W1_16^T + b1) [h16 = rn16(.), a16 = rn16(dropout(silu(h16)))];  y = a16 W2_16^T + b2
+    backward: dy16 = rn16(dy);  dh16 = rn16((dy16 W2_16) * mask / (1 - p) * silu'(h16));  dx = dh16 W1_16;
+              dW2 += dy16^T a16, db2 += 1^T dy16, dW1 += dh16^T x16, db1 += 1^T dh16
+    - what nn.Linear / SiLU / Dropout compute under the reference's bf16 / fp16 autocast (16-bit linear outputs, fp32 accumulation)."""
+
+    @staticmethod
+    def forward(ctx, ops: TrainOps, x, w1, b1, w2, b2, p, seed):
+        M, K = x.shape
+        H, N = w1.shape[0], w2.shape[0]
+        x16 = ops.cast16(x.contiguous())
+        w1_16, _ = ops.shadow16(w1)
+        w2_16, _ = ops.shadow16(w2)
+        ha = torch.empty((2, M, H), dtype=ops.dtype16, device=ops.device)            # h16 plane, a16 plane
+        ops.gemm16s(1, x16, w1_16, b1, ha, H, M, H, K, plane=M * H, p=p, seed=seed)
+        y = ops.new(M, N)
+        ops.gemm16s(0, ha[1], w2_16, b2, y, N, M, N, H)
+        ctx.ops, ctx.p, ctx.seed = ops, p, seed
+        ctx.save_for_backward(x16, ha)
+        ctx.params = (w1, b1, w2, b2)                                                # identities: shadows and gradient sinks
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops: TrainOps = ctx.ops
+        x16, ha = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        M, K = x16.shape
+        H, N = w1.shape[0], w2.shape[0]
+        dy16 = ops.cast16(dy.contiguous())
+        dh16 = torch.empty((M, H), dtype=ops.dtype16, device=ops.device)
+        ops.gemm16s(2, dy16, ops.shadow16(w2)[1], None, dh16, H, M, H, N, h16=ha[0], p=ctx.p, seed=ctx.seed)
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = ops.new(M, K)
+            ops.gemm16s(0, dh16, ops.shadow16(w1)[1], None, dx, K, M, K, H)
+        grads = []
+        for (w, b, g16, in16, iw, ib) in ((w1, b1, dh16, x16, 2, 3), (w2, b2, dy16, ha[1], 4, 5)):
+            dw = db = None
+            want_w, want_b = ctx.needs_input_grad[iw], b is not None and ctx.needs_input_grad[ib]
+            sw = ops.sink(w) if want_w else None
+            sb = ops.sink(b) if want_b else None
+            if want_w and sw is not None and (sb is not None or not want_b):
+                ops.wgrad16(g16, in16, sw, sb, accumulate=True)                      # into the parameters' gradient arrays
+                ops.deposited(w)
+                if sb is not None:
+                    ops.deposited(b)
+            elif want_w or want_b:
+                dw = ops.new(*w.shape)
+                db = ops.new(w.shape[0]) if want_b else None
+                ops.wgrad16(g16, in16, dw, db, accumulate=False)
+                if not want_w:
+                    dw = None
+            grads += [dw, db]
+        return None, dx, grads[0], grads[1], grads[2], grads[3], None, None
 
 
 class _LayerNorm(torch.autograd.Function):

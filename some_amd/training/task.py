@@ -3,6 +3,7 @@ training/base_task.py optimiser wiring, lr_scheduler/scheduler.py:42-59, configs
 training operators.  Data-parallel: one process per GPU, gradients summed with ONE all-reduce of the flat gradient
 buffer (RCCL over xGMI on the GPUs, gloo in the CPU tests) and averaged inside the fused AdamW launch."""
 import ctypes as C
+import time
 from typing import Dict, Optional
 
 import torch
@@ -57,6 +58,7 @@ class MIDIExtractionTrainer:
         self.growth_interval = int(config.get('some_amd_loss_scale_growth_interval', 200))
         self._clean_steps = 0
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=self.ops.device)
+        self.host_enqueue_s = 0.0                 # cumulative host time spent enqueuing training steps (up to the step's one sync)
         self.pg = process_group
         self.world = 1
         if process_group is not None or torch.distributed.is_initialized():
@@ -99,6 +101,7 @@ class MIDIExtractionTrainer:
         """One optimiser update: forward, losses, backward, gradient all-reduce, AdamW with the WarmupLR rate.  A list of
         batches is one update over ``accumulate_grad_batches`` micro-batches (configs/base.yaml:50, train.py:89): their
         gradients accumulate in the flat buffer, each loss weighted 1 / n as Lightning does."""
+        t_begin = time.perf_counter()
         P = self.model.params
         P.zero_grad()
         self.model.train()
@@ -124,6 +127,7 @@ class MIDIExtractionTrainer:
         sc = self.ops.scratch(1, 1)
         self.ops.check(self.ops.lib.some_train_sumsq(self.ops.h, C.c_void_p(P.grad.data_ptr()), P.numel, C.c_void_p(self._sumsq.data_ptr()),
                                                      C.c_void_p(sc.data_ptr()), sc.numel(), self.ops.stream()))
+        self.host_enqueue_s += time.perf_counter() - t_begin      # host time to enqueue the step, up to its one synchronisation
         sumsq = float(self._sumsq.item())
         skipped = False
         grad_norm = float('nan')

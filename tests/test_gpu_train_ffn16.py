@@ -1,0 +1,161 @@
+"""The 16-bit-storage training kernels (csrc/train_gemm16s.hip, include/some_amd.h "16-bit STORED operands") against PyTorch restatements
+of the same arithmetic: fp64 products of the stored operands, 16-bit roundings where the kernels round, the kernels' own dropout mask
+(recovered from the forward output) in the backward check."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from some_amd import _lib
+from some_amd.configs import get_config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from some_amd.engine import Engine
+    from some_amd.training.ops import TrainOps
+    return TrainOps(Engine(get_config('two_head_model', lay=1), device='cuda'))
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    return torch.randn(*shape, device='cuda', generator=g) * scale
+
+
+def _silu(x):
+    return x * torch.sigmoid(x)
+
+
+def _dsilu(x):
+    s = torch.sigmoid(x)
+    return s * (1 + x * (1 - s))
+
+
+@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+@pytest.mark.parametrize('M,N,K', [(700, 2048, 512), (129, 96, 64), (64, 512, 2048)])
+def test_gemm16s_plain_matches_products_of_the_stored_operands(ops, operand, M, N, K):
+    ops.set_mixed_precision(True, operand)
+    try:
+        x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
+        x16 = ops.cast16(x)
+        w16, w16t = ops.shadow16(w)
+        assert torch.equal(x16, x.to(ops.dtype16)) and torch.equal(w16, w.to(ops.dtype16)) and torch.equal(w16t, w.to(ops.dtype16).t().contiguous())
+        y = ops.new(M, N)
+        ops.gemm16s(0, x16, w16, b, y, N, M, N, K)
+        want = x16.double() @ w16.double().t() + b.double()
+        assert float((y.double() - want).abs().max()) < 2e-6 * float(want.abs().max())
+        dy16 = ops.cast16(_rand(M, N, seed=4))
+        dx = ops.new(M, K)
+        ops.gemm16s(0, dy16, w16t, None, dx, K, M, K, N)                 # data gradient: the transposed image is the [K, N] operand
+        want = dy16.double() @ w16.double()
+        assert float((dx.double() - want).abs().max()) < 2e-6 * float(want.abs().max())
+        dw, db = ops.new(N, K), ops.new(N)
+        ops.wgrad16(dy16, x16, dw, db, accumulate=False)
+        want = dy16.double().t() @ x16.double()
+        assert float((dw.double() - want).abs().max()) < 2e-6 * float(want.abs().max())
+        assert float((db.double() - dy16.double().sum(0)).abs().max()) < 2e-6 * float(dy16.double().sum(0).abs().max()) + 1e-6
+        ops.wgrad16(dy16, x16, dw, db, accumulate=True)                  # (+)=
+        assert float((dw.double() - 2 * want).abs().max()) < 4e-6 * float(want.abs().max())
+    finally:
+        ops.set_mixed_precision(False)
+
+
+@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+@pytest.mark.parametrize('M,p', [(700, 0.0), (700, 0.1), (131, 0.5)])
+def test_ffn16_forward_and_backward_match_the_restated_arithmetic(ops, operand, M, p):
+    K, H, N = 512, 2048, 512
+    dt = torch.bfloat16 if operand == 'bf16' else torch.float16
+    ops.set_mixed_precision(True, operand)
+    try:
+        x = _rand(M, K, seed=5).requires_grad_()
+        w1, b1 = _rand(H, K, seed=6, scale=K ** -0.5).requires_grad_(), _rand(H, seed=7, scale=0.3).requires_grad_()
+        w2, b2 = _rand(N, H, seed=8, scale=H ** -0.5).requires_grad_(), _rand(N, seed=9, scale=0.3).requires_grad_()
+        ops.weights_version += 1
+        y = ops.ffn(x, w1, b1, w2, b2, p, seed=1234567)
+        assert y.grad_fn is not None and type(y.grad_fn).__name__.startswith('_Ffn16')
+        x16, ha = y.grad_fn.saved_tensors
+        h16, a16 = ha[0], ha[1]
+        # forward, stage by stage
+        hw = x.detach().to(dt).double() @ w1.detach().to(dt).double().t() + b1.detach().double()
+        assert torch.equal(x16, x.detach().to(dt))
+        err_h = (h16.double() - hw).abs().max() / hw.abs().max()
+        assert float(err_h) < (5e-3 if operand == 'bf16' else 6e-4)                   # one 16-bit rounding of h
+        kept = a16 != 0
+        act = _silu(h16.float())
+        unscaled = act.abs() > 1e-3                                                   # where a zero can only mean "dropped"
+        rate = 1.0 - float((kept & unscaled).sum()) / float(unscaled.sum())
+        thr = round(p * 65536)
+        keep = 65536.0 / (65536.0 - thr)
+        assert abs(rate - p) < 4 * (p * (1 - p) / float(unscaled.sum())) ** 0.5 + 1e-9
+        want_a = (act * keep).to(dt)
+        assert torch.equal(a16[kept], want_a[kept]) or float((a16[kept].float() - want_a[kept].float()).abs().max()) <= 2 * float(torch.finfo(dt).eps) * float(want_a.float().abs().max())
+        yw = a16.double() @ w2.detach().to(dt).double().t() + b2.detach().double()
+        assert float((y.detach().double() - yw).abs().max()) < 2e-6 * float(yw.abs().max())
+        # backward with the kernel's own mask
+        dy = _rand(M, N, seed=10)
+        y.backward(dy)
+        mask = torch.where(a16 != 0, keep, 0.0).double()
+        mask = torch.where(unscaled, mask, torch.full_like(mask, keep) if p == 0 else mask)
+        dy16 = dy.to(dt).double()
+        dh = (dy16 @ w2.detach().to(dt).double()) * mask * _dsilu(h16.double())
+        dh16 = dh.to(dt).double()
+        sure = unscaled | (p == 0)                                                    # cells whose mask bit is known
+        dxw = dh16 @ w1.detach().to(dt).double()
+        tol = 3e-2 if p > 0 else 2e-2                                                 # |silu| < 1e-3 cells: mask unknown, gradient tiny
+        assert float((x.grad.double() - dxw).abs().max()) < tol * float(dxw.abs().max())
+        assert float((w2.grad.double() - dy16.t() @ a16.double()).abs().max()) < 2e-6 * float((dy16.t() @ a16.double()).abs().max())
+        assert float((b2.grad.double() - dy16.sum(0)).abs().max()) < 2e-6 * float(dy16.sum(0).abs().max())
+        dw1 = dh16.t() @ x16.double()
+        assert float((w1.grad.double() - dw1).abs().max()) < tol * float(dw1.abs().max())
+        assert float((b1.grad.double() - dh16.sum(0)).abs().max()) < tol * float(dh16.sum(0).abs().max())
+        assert bool(sure.any())
+    finally:
+        ops.set_mixed_precision(False)
+
+
+def test_ffn16_equals_the_fp32_composition_within_16_bit_roundings(ops):
+    """Same weights, same input, dropout off: the 16-bit-intermediate FFN against linear / silu / linear on fp32 arrays in the same
+    mixed-precision mode (which already rounds every GEMM operand to bf16)."""
+    M, K, H, N = 1000, 512, 2048, 512
+    ops.set_mixed_precision(True, 'bf16')
+    try:
+        x = _rand(M, K, seed=11)
+        w1, b1, w2, b2 = _rand(H, K, seed=12, scale=K ** -0.5), _rand(H, seed=13, scale=0.3), _rand(N, H, seed=14, scale=H ** -0.5), _rand(N, seed=15)
+        outs = []
+        for on in (True, False):
+            ops.ffn16 = on
+            ops.weights_version += 1
+            leaves = [t.clone().requires_grad_() for t in (x, w1, b1, w2, b2)]
+            y = ops.ffn(*leaves, 0.0, 0)
+            y.backward(_rand(M, N, seed=16))
+            outs.append([y.detach()] + [t.grad for t in leaves])
+        for a, b in zip(*outs):
+            assert float((a - b).abs().max()) < 2e-2 * float(b.abs().max())
+        assert float((outs[0][0] - outs[1][0]).abs().max()) > 0                       # and it really is another path
+    finally:
+        ops.ffn16 = True
+        ops.set_mixed_precision(False)
+
+
+def test_dropout_bits_match_the_host_restatement(ops):
+    """The mask of the FFN epilogue is the documented pure function of (seed, row, column) that some_amd/training/dropout_bits.py restates
+    in numpy; here the kernel's zeros are compared with it cell by cell."""
+    from some_amd.training.dropout_bits import ffn_keep_mask
+    M, K, H, N, p, seed = 300, 512, 2048, 512, 0.25, 987654321
+    ops.set_mixed_precision(True, 'bf16')
+    try:
+        x = _rand(M, K, seed=17).requires_grad_()
+        w1, b1, w2, b2 = _rand(H, K, seed=18, scale=K ** -0.5), _rand(H, seed=19, scale=0.3) + 2.0, _rand(N, H, seed=20, scale=H ** -0.5), _rand(N, seed=21)
+        ops.weights_version += 1
+        y = ops.ffn(x, w1, b1, w2, b2, p, seed)
+        _, ha = y.grad_fn.saved_tensors
+        act = _silu(ha[0].float()).cpu().numpy()
+        kept = (ha[1] != 0).cpu().numpy()
+        want = ffn_keep_mask(seed, M, H, p)
+        clear = np.abs(act) > 1e-3
+        assert np.array_equal(kept[clear], want[clear])
+    finally:
+        ops.set_mixed_precision(False)

@@ -389,3 +389,25 @@ def test_prefetch_loader_batches_equal_the_collater(golden_dir):
                 else:
                     assert a[k] == b[k]
     assert list(PrefetchLoader(ds, cfg, 'cpu').batches([])) == []
+
+
+def test_ffn_dropout_generator_statistics():
+    """The fused FFN epilogues' dropout bits (csrc/train_gemm16s.hip, restated in some_amd/training/dropout_bits.py): keep rate at the
+    requested p, no visible correlation between neighbouring cells (columns, rows, the two halves of a word) or between call sites."""
+    from some_amd.training.dropout_bits import ffn_keep_mask, key_words, threshold
+    M, N = 512, 2048
+    for p in (0.1, 0.5):
+        a = ffn_keep_mask(12345, M, N, p).astype(np.float64)
+        q = 1.0 - threshold(p) / 65536.0
+        sd = (q * (1 - q) / a.size) ** 0.5
+        assert abs(a.mean() - q) < 4 * sd
+        c = a - q
+        for u, v in ((c[:, :-1], c[:, 1:]), (c[:-1], c[1:]), (c[0::2], c[1::2]), (c[:-2], c[2:]), (c[:, :-32], c[:, 32:])):
+            corr = float((u * v).mean()) / (q * (1 - q))
+            assert abs(corr) < 5 / u.size ** 0.5, corr
+        b = ffn_keep_mask(12346, M, N, p).astype(np.float64) - q                   # the next call site's seed
+        assert abs(float((c * b).mean()) / (q * (1 - q))) < 5 / a.size ** 0.5
+        assert abs(a.mean(0) - q).max() < 6 * (q * (1 - q) / M) ** 0.5             # per column and per row too
+        assert abs(a.mean(1) - q).max() < 6 * (q * (1 - q) / N) ** 0.5
+    assert ffn_keep_mask(1, 64, 64, 0.0).all()
+    assert key_words(1) != key_words(2)

@@ -48,6 +48,7 @@ def main():
     for _ in range(args.warmup):
         tr.training_step(sample)
     torch.cuda.synchronize()
+    host0 = tr.host_enqueue_s
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = tr.training_step(sample)
@@ -59,7 +60,8 @@ def main():
     if rank == 0:
         print(f'two_head_model lay {args.lay} ({("mixed " + tr.mixed_operand) if tr.mixed else "fp32-equivalent"}): {B} x {T} frames/GPU x {world} GPU: {dt * 1e3:.1f} ms/step, '
               f'{world * B * T / dt:.0f} frames/s, {world * B * T * 512 / 44100 / dt:.0f} audio-s/s trained, '
-              f'{flops / dt / 1e12:.1f} TFLOP/s/GPU (fwd+bwd model FLOPs), loss {out["total_loss"].item():.4f}')
+              f'{flops / dt / 1e12:.1f} TFLOP/s/GPU (fwd+bwd model FLOPs), host enqueue {(tr.host_enqueue_s - host0) / args.steps * 1e3:.1f} ms/step, '
+              f'loss {out["total_loss"].item():.4f}')
     if world > 1:
         torch.distributed.destroy_process_group()
 
