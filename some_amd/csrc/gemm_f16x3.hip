@@ -398,8 +398,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     const int a_off = (wm * TM * 32 + l31) * LDT + kg * 4;
     const int w_off = (BM + wn * TN * 32 + (TR ? pi32(l31) : l31)) * LDT + kg * 4;
     // TR: the W fragment is the first MFMA operand (accumulator rows <- n, lane <- m), see epilogue_tr
+    // GEMM_ABLATE_* (tools/build_variant.py builds only, wrong results): what each part of the k-loop costs
     auto mma = [](half8 x, half8 w, f32x16 c) {
+#ifdef GEMM_ABLATE_NO_MFMA
+        c[0] += (float)x[0] + (float)w[0];               // keeps the fragment reads alive
+        return c;
+#else
         return TR ? mfma_hi<BF16>(w, x, c) : mfma_hi<BF16>(x, w, c);
+#endif
     };
 
     // the MFMAs of one k-block out of LDS buffer `buf`
@@ -474,9 +480,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
             for (int o = 0; o < OPS; ++o) {
                 const int q = slot * OPS + o;
                 if (q < NLD && mode < 2) {
+#ifndef GEMM_ABLATE_NO_LDSW
                     *reinterpret_cast<f32x4*>(wbase + q * RPP * LDT) = stage[q];
+#endif
+#ifndef GEMM_ABLATE_NO_LOAD
                     if (mode == 0)
                         stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q * RPP < BM ? rsa : rsw, voff[q], koff, 0));
+#endif
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -526,6 +536,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
             for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mma(ah1[i], bh1[jn], acc[i][jn]);
     };
     int kt = 0;
+#ifdef GEMM_ABLATE_NO_LOOP
+    nk = 1;                                              // one k-block: the epilogue alone (plus the prologue loads)
+#endif
     for (; kt + 2 < nk; ++kt) {
         if constexpr (TERMS == 3) {
             compute_staged(kt & 1, kt + 2, 0);
@@ -554,6 +567,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     // Interior workgroups take the unguarded path (no per-element exec masking).  Residual values are fetched one
     // 32 x 32 MFMA tile (16 per lane) at a time BEFORE that tile's stores: C may alias res (in-place residual
     // update), which otherwise forces the compiler into load -> wait -> store per element.
+#ifdef GEMM_ABLATE_NO_EPI
+    {
+        float keep = 0.f;                                // every accumulator stays live: no product may be eliminated
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[i][jn][r];
+        if (keep == 12345.678f) g.C[0] = keep;
+        return;
+    }
+#endif
     if constexpr (TR) {
         if (n0 + BN <= g.N)      // rows beyond M fall outside the buffer descriptors (dropped by the hardware)
             epilogue_tr<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, true>(a, g, acc, m0, n0, wm, wn, lane);
