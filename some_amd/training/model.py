@@ -120,7 +120,7 @@ class TrainableMidiConforms:
 
     def _attention(self, x, pre: str, batch):
         P, o = self.params, self.ops
-        wqkv = torch.cat([P[pre + '.to_q.weight'], P[pre + '.to_kv.weight']], dim=0)        # q | k | v rows
+        wqkv = o.cat_rows(P[pre + '.to_q.weight'], P[pre + '.to_kv.weight'])                  # q | k | v rows
         out = o.attention(o.linear(x, wqkv), batch)
         return o.linear(out, P[pre + '.to_out.0.weight'], P[pre + '.to_out.0.bias'])
 
@@ -164,7 +164,7 @@ class TrainableMidiConforms:
                 x = o.mask_rows(x, mask_u8)
         x, x1 = self._block(x, 'model.att1', batch), self._block(x1, 'model.att2', batch)
         midi = o.linear(x, P['model.outln.weight'], P['model.outln.bias'])
-        bound = o.sigmoid(o.linear(x1, P['model.cutheard.weight'], P['model.cutheard.bias'])).reshape(-1)
+        bound = o.reshape(o.sigmoid(o.linear(x1, P['model.cutheard.weight'], P['model.cutheard.bias'])), -1)
         return midi, bound
 
     __call__ = forward

@@ -15,7 +15,7 @@ from ..engine import Engine
 
 
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()          # ctypes converts the int at the call (argtypes are c_void_p): no object per argument
 
 
 class TrainOps:
@@ -27,6 +27,8 @@ class TrainOps:
         self.engine = engine
         self.lib, self.h, self.device = engine.lib, engine.handle, engine.device
         self._scratch: Optional[torch.Tensor] = None
+        self._pinned_stream = None
+        self.tape: Optional['Tape'] = None        # set by the trainer for the duration of a forward + backward pass
         self._partial: Optional[torch.Tensor] = None
         self.gemm_precision = 'f16x3' if engine.c_config.precision == _lib.PRECISION_F16X3 else 'f32'
         self.attention_precision = self.gemm_precision      # forward + backward: split-f16 or exact-f32 MFMA kernels
@@ -146,7 +148,15 @@ class TrainOps:
 
     # ---- plumbing -------------------------------------------------------------------------------------------
     def stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # looking the current stream up costs 3.4 us - a third of an operator call's host time (tools/host_overhead_probe.py); a training
+        # step runs on ONE stream, so the trainer pins it for the duration of the step (forward and the autograd thread's backward)
+        return self._pinned_stream or C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def pin_stream(self):
+        self._pinned_stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def unpin_stream(self):
+        self._pinned_stream = None
 
     def scratch(self, M: int, N: int) -> torch.Tensor:
         need = int(self.lib.some_train_scratch_bytes(self.h, M, N))
@@ -312,64 +322,158 @@ class TrainOps:
         return out
 
     # ---- differentiable operators ---------------------------------------------------------------------------------------
+    def _apply(self, fn, *args):
+        """Run a differentiable operator: on the active tape (trainer, see ``Tape``) or through torch.autograd."""
+        tape = self.tape
+        return tape.apply(fn, self, *args) if tape is not None else fn.apply(self, *args)
+
+    def cat_rows(self, a, b):
+        """torch.cat([a, b], dim=0) of two weight matrices (the fused q | k | v projection)."""
+        return self._apply(_CatRows, a, b)
+
+    def reshape(self, x, *shape):
+        return self._apply(_Reshape, x, shape)
+
     def linear(self, x, weight, bias=None):
         """nn.Linear / k = 1 Conv1d: x [M, K], weight [N, K] -> [M, N]."""
-        return _Linear.apply(self, x, weight, bias)
+        return self._apply(_Linear, x, weight, bias)
 
     def ffn(self, x, w1, b1, w2, b2, p: float, seed: int):
         """conform_ffn.forward up to its output dropout (Gconform.py:29-33): ln2(drop1(silu(ln1(x))))."""
         if self.can_ffn16(x.shape[0], x.shape[1], w1.shape[0], w2.shape[0]):
-            return _Ffn16.apply(self, x, w1, b1, w2, b2, p, seed)
+            return self._apply(_Ffn16, x, w1, b1, w2, b2, p, seed)
         return self.linear(self.silu_dropout(self.linear(x, w1, b1), p, seed), w2, b2)
 
     def layernorm(self, x, gamma, beta):
-        return _LayerNorm.apply(self, x, gamma, beta)
+        return self._apply(_LayerNorm, x, gamma, beta)
 
     def silu(self, x):
-        return _Silu.apply(self, x)
+        return self._apply(_Silu, x)
 
     def sigmoid(self, x):
-        return _Sigmoid.apply(self, x)
+        return self._apply(_Sigmoid, x)
 
     def silu_dropout(self, x, p: float, seed: int):
         """dropout(silu(x)) in one pass (conform_ffn.forward: act + drop1, Gconform.py:31-32)."""
-        return _Silu.apply(self, x) if p <= 0.0 else _SiluDropout.apply(self, x, p, seed)
+        return self._apply(_Silu, x) if p <= 0.0 else self._apply(_SiluDropout, x, p, seed)
 
     def axpy_dropout(self, alpha: float, y, x, p: float, seed: int):
         """alpha * dropout(y) + x in one pass (the residual sites of conform_blocke.forward, Gconform.py:57-61)."""
-        return _Axpy.apply(self, alpha, y, x) if p <= 0.0 else _AxpyDropout.apply(self, alpha, y, x, p, seed)
+        return self._apply(_Axpy, alpha, y, x) if p <= 0.0 else self._apply(_AxpyDropout, alpha, y, x, p, seed)
 
     def glu(self, x):
-        return _Glu.apply(self, x)
+        return self._apply(_Glu, x)
 
     def axpy(self, alpha: float, y, x):
         """alpha * y + x (``x = f(x) * 0.5 + x``, Gconform.py:57,60)."""
-        return _Axpy.apply(self, alpha, y, x)
+        return self._apply(_Axpy, alpha, y, x)
 
     def mask_rows(self, x, mask_u8):
-        return _MaskRows.apply(self, x, mask_u8)
+        return self._apply(_MaskRows, x, mask_u8)
 
     def dropout(self, x, p: float, seed: int):
         if p <= 0.0:
             return x
-        return _Dropout.apply(self, x, p, seed)
+        return self._apply(_Dropout, x, p, seed)
 
     def dwconv(self, x, weight, bias, batch):
         """Depthwise Conv1d(C, C, 31, padding 15, groups C): weight [C, 1, 31] as in the state dict."""
-        return _DwConv.apply(self, x, weight, bias, batch)
+        return self._apply(_DwConv, x, weight, bias, batch)
 
     def batchnorm(self, x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
-        return _BatchNorm.apply(self, x, gamma, beta, running_mean, running_var, momentum, eps)
+        return self._apply(_BatchNorm, x, gamma, beta, running_mean, running_var, momentum, eps)
 
     def attention(self, qkv, batch):
         """F.scaled_dot_product_attention on the fused projection qkv [M, 1536] -> merged heads [M, 512]."""
-        return _Attention.apply(self, qkv, batch)
+        return self._apply(_Attention, qkv, batch)
 
     def bce_with_logits(self, logits, target):
-        return _Bce.apply(self, logits, target)
+        return self._apply(_Bce, logits, target)
 
     def binary_emd(self, pred, gt, B: int, T: int):
-        return _Emd.apply(self, pred, gt, B, T)
+        return self._apply(_Emd, pred, gt, B, T)
+
+
+class _Ctx:
+    """What the operator bodies below use of torch's FunctionCtx."""
+    saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class Tape:
+    """A minimal reverse-mode tape over the SAME ``forward`` / ``backward`` bodies torch.autograd would run.
+
+    Why: measured (tools/host_overhead_probe.py) an operator call costs the host 9 us, torch.autograd.Function.apply around it another
+    14 us and its backward node ~25 us more - 350 operators per step make the step HOST-bound at the reference's batch shape (8 phrases,
+    ~4 100 frames: 15 ms of host time per 16.5 ms step).  The model is a fixed sequence of these operators, so the trainer records them
+    itself: ``apply`` runs ``fn.forward`` (under torch.no_grad) and keeps (fn, ctx, inputs, output); ``backward`` walks the records in
+    reverse, hands each output gradient to ``fn.backward`` and routes the results - summed where a tensor feeds two operators, added
+    into ``.grad`` (the flat gradient buffer's views) for parameters, with ``ops.deposited`` standing in for the post-accumulate hook.
+    Same kernels, same order of additions: bit-identical gradients to the torch.autograd path (tests/test_gpu_train_step.py)."""
+
+    def __init__(self, ops: 'TrainOps'):
+        self.ops = ops
+        self.records = []
+        self.produced = set()
+
+    def apply(self, fn, *args):
+        ctx = _Ctx()
+        produced = self.produced
+        ctx.needs_input_grad = needs = tuple(isinstance(a, torch.Tensor) and (a.requires_grad or id(a) in produced) for a in args)
+        out = fn.forward(ctx, *args)
+        if True in needs:
+            self.records.append((fn, ctx, args, out))
+            produced.add(id(out))
+        return out
+
+    def backward(self, seeds):
+        """seeds: (tensor, gradient) pairs - the losses with their weights."""
+        grads = {}
+        for t, g in seeds:
+            grads[id(t)] = g if id(t) not in grads else grads[id(t)] + g
+        records, ops = self.records, self.ops
+        while records:
+            fn, ctx, args, out = records.pop()                  # releases the saved activations as the pass moves on
+            g = grads.pop(id(out), None)
+            if g is None:
+                continue                                        # an output nothing differentiable consumed
+            for a, ga, need in zip(args, fn.backward(ctx, g), ctx.needs_input_grad):
+                if ga is None or not need:
+                    continue
+                if a.requires_grad:                             # a parameter: accumulate where autograd's AccumulateGrad would
+                    if a.grad is None:
+                        a.grad = ga.clone()
+                    else:
+                        a.grad.add_(ga)
+                    ops.deposited(a)
+                else:
+                    prev = grads.get(id(a))
+                    grads[id(a)] = ga if prev is None else prev + ga
+        self.produced.clear()
+
+
+class _CatRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, a, b):
+        ctx.rows = a.shape[0]
+        return torch.cat([a, b], dim=0)
+
+    @staticmethod
+    def backward(ctx, d):
+        return None, d[:ctx.rows], d[ctx.rows:]
+
+
+class _Reshape(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, x, shape):
+        ctx.shape = x.shape
+        return x.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, d):
+        return None, d.reshape(ctx.shape), None
 
 
 class _Linear(torch.autograd.Function):

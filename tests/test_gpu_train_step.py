@@ -373,3 +373,30 @@ def test_gradient_accumulation_averages_the_micro_batch_gradients():
     for k in ('midi_loss', 'bound_loss', 'total_loss'):
         assert abs(float(oa[k]) - 0.5 * (float(o0[k]) + float(o1[k]))) < 1e-5 * abs(float(oa[k]))
     assert oa['grad_norm'] == pytest.approx(float(want.norm()), rel=1e-4)
+
+
+@pytest.mark.parametrize('precision,dropout', [(None, False), ('bf16', True), ('16-mixed', True)])
+def test_trainer_tape_equals_torch_autograd_bit_for_bit(precision, dropout):
+    """The trainer records and replays its operators itself (ops.Tape: the same forward / backward bodies, none of torch.autograd's per-node
+    host cost).  Same kernels in the same order with the same additions: after two updates - the second over two micro-batches - losses,
+    gradients and parameters equal the torch.autograd path's exactly."""
+    from some_amd.training.task import MIDIExtractionTrainer
+    cfg = _cfg() if not dropout else get_config('two_head_model', lay=1)
+    if precision:
+        cfg = dict(cfg, pl_trainer_precision=precision)
+    outs = []
+    for tape in (True, False):
+        tr = MIDIExtractionTrainer(dict(cfg, some_amd_tape=tape), device='cuda', seed=7)
+        assert tr.use_tape == tape
+        tr.model.params.load_state_dict(synth.synth_state_dict(_cfg(), 31))
+        a = tr.training_step(_sample())
+        g1 = tr.model.params.grad.clone()
+        b = tr.training_step([_sample(), _sample()])
+        outs.append((a, g1, b, tr.model.params.grad.clone(), tr.model.params.flat.clone()))
+        assert not a['skipped'] and not b['skipped']
+    (a0, g0, b0, h0, p0), (a1, g1, b1, h1, p1) = outs
+    for k in ('bound_loss', 'midi_loss', 'total_loss'):
+        assert float(a0[k]) == float(a1[k]) and float(b0[k]) == float(b1[k]), k
+    assert a0['grad_norm'] == a1['grad_norm'] and b0['grad_norm'] == b1['grad_norm']
+    assert torch.equal(g0, g1) and torch.equal(h0, h1) and torch.equal(p0, p1)
+    assert float(g0.abs().sum()) > 0

@@ -45,12 +45,17 @@ def run(data_dir, precision='bf16', max_batch_frames=80000, max_batch_size=8, wo
     hop_s = cfg['hop_size'] / cfg['audio_sample_rate']
     frames_valid = frames_padded = 0
     step_ms, losses = [], []
-    # warm-up outside the clock: first-use allocations, kernel attribute calls, pinned-buffer pool
+    # warm-up outside the clock: first-use allocations, kernel attribute calls, pinned-buffer pool - on the two LARGEST batches of the
+    # plan, so the caching allocator already holds blocks of every size the epoch asks for (what every epoch after the first sees;
+    # `device_allocs_during_epoch` reports what is left)
     warm = PrefetchLoader(train_set, cfg, trainer.ops.device, workers=0)
-    for mb in warm.batches(plan[:2]):
+    biggest = sorted(plan, key=lambda idx: len(idx) * max(int(train_set.sizes[i]) for i in idx))[-2:]
+    for mb in warm.batches(biggest):
         trainer.training_step(mb)
     torch.cuda.synchronize()
     skipped = 0
+    host0 = trainer.host_enqueue_s
+    segs0 = torch.cuda.memory_stats().get('num_device_alloc', 0) if torch.cuda.is_available() else 0
     t0 = time.perf_counter()
     last = t0
     for mb, idx in zip(loader.batches(plan), plan):
@@ -81,6 +86,9 @@ def run(data_dir, precision='bf16', max_batch_frames=80000, max_batch_size=8, wo
         'padding_overhead': round(frames_padded / max(frames_valid, 1), 4),
         'step_ms': {'mean': round(float(ms.mean()), 2), 'p10': round(float(np.percentile(ms, 10)), 2), 'p50': round(float(np.percentile(ms, 50)), 2),
                     'p90': round(float(np.percentile(ms, 90)), 2), 'max': round(float(ms.max()), 2)},
+        'host_enqueue_ms_mean': round((trainer.host_enqueue_s - host0) / max(len(step_ms), 1) * 1e3, 2),
+        'step_ms_first_quarter_mean': round(float(ms[:max(len(ms) // 4, 1)].mean()), 2), 'step_ms_last_quarter_mean': round(float(ms[-max(len(ms) // 4, 1):].mean()), 2),
+        'device_allocs_during_epoch': int(torch.cuda.memory_stats().get('num_device_alloc', 0) - segs0),
         'data_wait_s': round(st['wait_s'], 3), 'data_wait_frac_of_wall': round(st['wait_s'] / wall, 4),
         'host_collate_s_in_workers': round(st['host_collate_s'], 3), 'loader_workers': workers, 'prefetch_factor': prefetch_factor,
         'loss_first_last': [round(float(np.mean(losses[:5])), 4), round(float(np.mean(losses[-5:])), 4)],
