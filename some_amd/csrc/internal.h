@@ -191,6 +191,7 @@ hipError_t launch_pcm_gather(const void* src, int is_pcm16, const int64_t* src_o
 
 // ---- training operators (train_ops.hip) -------------------------------------------------------------------
 size_t train_col_scratch_bytes(int M, int N);
+size_t train_ln_scratch_bytes(int M);
 size_t train_dwconv_w_scratch_bytes(int M, int C);
 hipError_t launch_reduce_slices(const float* partial, int slices, size_t n, float* out, hipStream_t s);
 hipError_t launch_reduce_wgrad(const float* partial, int slices, size_t stride, int M, int N, int ldc, float* dw, float* db, int accumulate,

@@ -250,7 +250,7 @@ int some_train_layernorm_bwd(SomeHandle* h, const float* dy_dev, const float* x_
     T_CHECK(h, M >= 0 && dy_dev && x_dev && gamma_dev && mean_dev && rstd_dev && dx_dev && dgamma_dev && dbeta_dev,
             "some_train_layernorm_bwd: bad argument");
     if (M == 0) return SOME_OK;
-    T_CHECK(h, scratch_dev && scratch_bytes >= train_col_scratch_bytes(M, kDim), "some_train_layernorm_bwd: scratch too small");
+    T_CHECK(h, scratch_dev && scratch_bytes >= train_ln_scratch_bytes(M), "some_train_layernorm_bwd: scratch too small (some_train_scratch_bytes(M, 512))");
     T_TRY(h, launch_ln_bwd(dy_dev, x_dev, gamma_dev, mean_dev, rstd_dev, dx_dev, dgamma_dev, dbeta_dev, accumulate, M,
                            static_cast<float*>(scratch_dev), st(stream)));
     return SOME_OK;

@@ -122,14 +122,6 @@ struct ColStatsF {
     const float* x; int ld;
     __device__ void operator()(int m, int n, float& s1, float& s2) const { const float v = x[(size_t)m * ld + n]; s1 += v; s2 += v * v; }
 };
-struct LnGradF {         // s1 = sum dy (dbeta), s2 = sum dy * xhat (dgamma); per-ROW statistics
-    const float* dy; const float* x; const float* mean; const float* rstd; int ld;
-    __device__ void operator()(int m, int n, float& s1, float& s2) const {
-        const float d = dy[(size_t)m * ld + n];
-        s1 += d;
-        s2 += d * (x[(size_t)m * ld + n] - mean[m]) * rstd[m];
-    }
-};
 struct BnGradF {         // per-COLUMN statistics
     const float* dy; const float* x; const float* mean; const float* rstd; int ld;
     __device__ void operator()(int m, int n, float& s1, float& s2) const {
@@ -162,36 +154,68 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-// dx = rstd (g dy - mean(g dy) - xhat mean(g dy xhat))
-__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ g,
-                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         float* __restrict__ dx, int M) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= M) return;
-    const float mu = mean[row], rs = rstd[row];
-    float gd[8], xh[8];
-    float s1 = 0.f, s2 = 0.f;
+// dx = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)), and the column partials of dbeta = sum dy, dgamma = sum dy xhat, in ONE pass over
+// dy and x (a stand-alone column reduction would read both again: 210 -> 126 MB per call at 8 x 2584 frames, one launch less).  A workgroup
+// owns kLnChunk rows, its
+// wavefront w the rows w, w + 8, ...; every lane keeps the running sums of its 8 columns, the eight wavefronts' sums are combined in a fixed
+// tree through LDS and written as partial[chunk][2][512] for col_final_kernel (fixed order: deterministic).
+constexpr int kLnChunk = 128, kLnWaves = 8;
+__global__ __launch_bounds__(64 * kLnWaves) void ln_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ dx, float* __restrict__ partial, int M) {
+    __shared__ float red[2][kLnWaves][kLnDim];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * kLnChunk;
+    float gv[8], sb[8], sg[8];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int c = h * 256 + lane * 4;
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (size_t)row * kLnDim + c);
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * kLnDim + c);
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + c);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(g + h * 256 + lane * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            gd[h * 4 + i] = d[i] * gv[i];
-            xh[h * 4 + i] = (xv[i] - mu) * rs;
-            s1 += gd[h * 4 + i];
-            s2 += gd[h * 4 + i] * xh[h * 4 + i];
+        for (int i = 0; i < 4; ++i) { gv[h * 4 + i] = t[i]; sb[h * 4 + i] = 0.f; sg[h * 4 + i] = 0.f; }
+    }
+    for (int j = 0; j < kLnChunk / kLnWaves; ++j) {
+        const int row = r0 + wave + kLnWaves * j;
+        if (row >= M) break;
+        const float mu = mean[row], rs = rstd[row];
+        float gd[8], xh[8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = h * 256 + lane * 4;
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (size_t)row * kLnDim + c);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * kLnDim + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = h * 4 + i;
+                gd[k] = d[i] * gv[k];
+                xh[k] = (xv[i] - mu) * rs;
+                s1 += gd[k];
+                s2 += gd[k] * xh[k];
+                sb[k] += d[i];
+                sg[k] += d[i] * (xv[i] - mu) * rs;
+            }
+        }
+        const float c1 = wave_sum(s1) * (1.0f / kLnDim), c2 = wave_sum(s2) * (1.0f / kLnDim);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = rs * (gd[h * 4 + i] - c1 - xh[h * 4 + i] * c2);
+            *reinterpret_cast<f32x4*>(dx + (size_t)row * kLnDim + h * 256 + lane * 4) = o;
         }
     }
-    const float c1 = wave_sum(s1) * (1.0f / kLnDim), c2 = wave_sum(s2) * (1.0f / kLnDim);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        f32x4 o;
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = rs * (gd[h * 4 + i] - c1 - xh[h * 4 + i] * c2);
-        *reinterpret_cast<f32x4*>(dx + (size_t)row * kLnDim + h * 256 + lane * 4) = o;
+        for (int i = 0; i < 4; ++i) {
+            red[0][wave][h * 256 + lane * 4 + i] = sb[h * 4 + i];
+            red[1][wave][h * 256 + lane * 4 + i] = sg[h * 4 + i];
+        }
+    __syncthreads();
+    float* p = partial + (size_t)blockIdx.x * 2 * kLnDim;
+    for (int c = threadIdx.x; c < kLnDim; c += 64 * kLnWaves) {
+        p[c] = ((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])) + ((red[0][4][c] + red[0][5][c]) + (red[0][6][c] + red[0][7][c]));
+        p[kLnDim + c] = ((red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c])) + ((red[1][4][c] + red[1][5][c]) + (red[1][6][c] + red[1][7][c]));
     }
 }
 
@@ -605,6 +629,7 @@ hipError_t launch_reduce_wgrad(const float* partial, int slices, size_t stride, 
 // ---- launchers -----------------------------------------------------------------------------------------------------------
 static inline int n_chunks(int M) { return (M + kChunkRows - 1) / kChunkRows; }
 size_t train_col_scratch_bytes(int M, int N) { return (size_t)n_chunks(M) * 2 * N * sizeof(float); }
+size_t train_ln_scratch_bytes(int M) { return (size_t)((M + 127) / 128) * 2 * 512 * sizeof(float); }      // ln_bwd_fused_kernel: 128-row chunks
 size_t train_dwconv_w_scratch_bytes(int M, int C) { return (size_t)((M + kDwChunk - 1) / kDwChunk) * kTaps * C * sizeof(float); }
 
 hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, int split_out, hipStream_t s) {
@@ -643,8 +668,10 @@ hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* 
 hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx,
                          float* dgamma, float* dbeta, int accumulate, int M, float* scratch, hipStream_t s) {
     if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, dy, x, g, mean, rstd, dx, M);
-    return col_reduce(M, kLnDim, LnGradF{dy, x, mean, rstd, kLnDim}, dbeta, dgamma, accumulate, scratch, s);
+    const int P = (M + kLnChunk - 1) / kLnChunk;
+    hipLaunchKernelGGL(ln_bwd_fused_kernel, dim3((unsigned)P), dim3(64 * kLnWaves), 0, s, dy, x, g, mean, rstd, dx, scratch, M);
+    hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)(kLnDim / 64)), dim3(256), 0, s, scratch, P, kLnDim, dbeta, dgamma, accumulate);
+    return hipGetLastError();
 }
 
 hipError_t launch_bn_fwd(const float* x, const float* g, const float* b, int M, int C, float eps, float momentum, float* running_mean,
