@@ -265,7 +265,13 @@ int some_train_transpose16(SomeHandle* h, const float* w_dev, void* w16_dev, voi
  * values are scaled by 1 / (1 - p'), p' = round(65536 p) / 65536, the rate actually applied.  p = 0: no dropout. */
 int some_train_gemm16s(SomeHandle* h, int32_t epilogue, const void* A16_dev, int32_t lda, const void* B16_dev, int32_t ldb, const float* bias_dev,
                        void* C_dev, int32_t ldc, const void* H16_dev, int32_t ldh, int64_t plane_elems, int32_t M, int32_t N, int32_t K,
-                       int32_t operand, float p, uint64_t seed, void* stream);
+                       int32_t operand, float p, uint64_t seed, float alpha, void* stream);
+/* epilogue 3 of some_train_gemm16s: C fp32 [M, ldc] = R + alpha * dropout_p(acc + bias), R = H16_dev read as fp32 [M, ldh] - the conformer
+ * block's `x = ffn(x) * 0.5 + x` with conform_ffn's output dropout (modules/conform/Gconform.py:33,57,60) folded into the second linear.
+ * some_train_dropcast16 is its gradient w.r.t. the linear's output, written as the 16-bit operand of the data-gradient GEMM:
+ * y16[m, n] = rn16(alpha * mask(m, n) / (1 - p') * d[m, n]) with the SAME (p, seed); N % 4 == 0. */
+int some_train_dropcast16(SomeHandle* h, const float* d_dev, void* y16_dev, int32_t M, int32_t N, float alpha, float p, uint64_t seed,
+                          int32_t operand, void* stream);
 /* some_train_gemm16_wgrad on 16-bit stored operands: dW[N, K] (+)= dY16[frames, N]^T X16[frames, K], db[N] (+)= column sums of dY16
  * (fp32 sums of the stored values).  ld % 4 == 0, 8-byte aligned operands; partial_dev as for some_train_gemm16_wgrad. */
 int some_train_gemm16_wgrad16(SomeHandle* h, const void* dY16_dev, int32_t ldy, const void* X16_dev, int32_t ldx, float* dW_dev, float* db_dev,
@@ -290,6 +296,15 @@ int some_train_layernorm_bwd(SomeHandle* h, const float* dy_dev, const float* x_
                              const float* mean_dev, const float* rstd_dev, float* dx_dev, float* dgamma_dev,
                              float* dbeta_dev, int32_t accumulate, int32_t M, void* scratch_dev, size_t scratch_bytes,
                              void* stream);
+/* LayerNorm forward with the output written in 16 bits (operand 1 = f16, 2 = bf16): the FFN's GEMM operand without a cast pass. */
+int some_train_layernorm_fwd16(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                               void* y16_dev, float* mean_dev, float* rstd_dev, int32_t M, int32_t operand, void* stream);
+/* some_train_layernorm_bwd with a second gradient of x summed in: dx = add + (LayerNorm gradient); add_dev may be NULL.  The residual
+ * connection around the LayerNorm of a conformer sub-block (Gconform.py:57-61) reaches x twice; this removes the separate addition. */
+int some_train_layernorm_bwd_add(SomeHandle* h, const float* dy_dev, const float* x_dev, const float* gamma_dev,
+                                 const float* mean_dev, const float* rstd_dev, const float* add_dev, float* dx_dev, float* dgamma_dev,
+                                 float* dbeta_dev, int32_t accumulate, int32_t M, void* scratch_dev, size_t scratch_bytes,
+                                 void* stream);
 /* nn.BatchNorm1d(C) in train mode over the M rows (base_conv.py:56): batch statistics, running-stat update
  * (momentum, unbiased variance), saved mean / rstd for the backward. */
 int some_train_batchnorm_fwd(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,

@@ -79,7 +79,10 @@ SYMBOLS = {
     'some_train_cast16': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
     'some_train_transpose16': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     'some_train_gemm16s': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
-                                     C.c_int32, C.c_int32, C.c_float, C.c_uint64, _P]),
+                                     C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_float, _P]),
+    'some_train_dropcast16': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_uint64, C.c_int32, _P]),
+    'some_train_layernorm_fwd16': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
+    'some_train_layernorm_bwd_add': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
     'some_train_gemm16_wgrad16': (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
                                             C.c_size_t, _P]),
     'some_train_weighted_colsum': (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_size_t, _P]),

@@ -69,7 +69,8 @@ int gemm16_tile_n(int mode);
 // GEMMs on operands stored as 16-bit values (train_gemm16s.hip): C = A16 [M, K] B16 [N, K]^T through a DMA ring; epi 0 fp32 (+ bias),
 // 1 the FFN's first linear (bias, h16 | a16 = dropout(silu(h16)) planes), 2 the data gradient through dropout / SiLU (reads h16)
 hipError_t launch_gemm16s(int epi, const void* A16, int lda, const void* B16, int ldb, const float* bias, void* C, int ldc, const void* H16,
-                          int ldh, size_t plane_bytes, int M, int N, int K, int bf16, float p, uint64_t seed, hipStream_t s);
+                          int ldh, size_t plane_bytes, int M, int N, int K, int bf16, float p, uint64_t seed, float alpha, hipStream_t s);
+hipError_t launch_dropcast16(const float* d, void* y16, int M, int N, float alpha, float p, uint64_t seed, int bf16, hipStream_t s);
 hipError_t launch_cast16(const float* x, void* y16, int64_t n, int bf16, hipStream_t s);
 hipError_t launch_transpose16(const float* w, void* w16, void* w16t, int N, int K, int bf16, hipStream_t s);
 
@@ -199,8 +200,8 @@ hipError_t launch_reduce_wgrad(const float* partial, int slices, size_t stride, 
 hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, int split_out, hipStream_t s);
 hipError_t launch_colsum(const float* x, int M, int N, int ld, float* out, int accumulate, float* scratch, hipStream_t s);
 hipError_t launch_weighted_colsum(const float* w, int ldw, const float* x, int M, int N, int ld, float* out, float* wsum, float* scratch, hipStream_t s);
-hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, hipStream_t s);
-hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx,
+hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, void* y, float* mean, float* rstd, int M, int out16, hipStream_t s);
+hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, const float* add, float* dx,
                          float* dgamma, float* dbeta, int accumulate, int M, float* scratch, hipStream_t s);
 hipError_t launch_bn_fwd(const float* x, const float* g, const float* b, int M, int C, float eps, float momentum, float* running_mean,
                          float* running_var, float* y, float* save_mean, float* save_rstd, float* scratch, hipStream_t s);

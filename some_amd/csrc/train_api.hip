@@ -152,13 +152,13 @@ int some_train_transpose16(SomeHandle* h, const float* w_dev, void* w16_dev, voi
 
 int some_train_gemm16s(SomeHandle* h, int32_t epilogue, const void* A16_dev, int32_t lda, const void* B16_dev, int32_t ldb, const float* bias_dev,
                        void* C_dev, int32_t ldc, const void* H16_dev, int32_t ldh, int64_t plane_elems, int32_t M, int32_t N, int32_t K,
-                       int32_t operand, float p, uint64_t seed, void* stream) {
+                       int32_t operand, float p, uint64_t seed, float alpha, void* stream) {
     if (!h) return SOME_EINVAL;
     T_CHECK(h, M > 0 && N > 0 && K > 0 && A16_dev && B16_dev && C_dev, "some_train_gemm16s: bad argument");
     T_CHECK(h, operand == 1 || operand == 2, "some_train_gemm16s: operand must be 1 (f16) or 2 (bf16)");
-    T_CHECK(h, epilogue >= 0 && epilogue <= 2, "some_train_gemm16s: epilogue must be 0 (fp32), 1 (FFN first linear) or 2 (SiLU / dropout gradient)");
+    T_CHECK(h, epilogue >= 0 && epilogue <= 3, "some_train_gemm16s: epilogue must be 0 (fp32), 1 (FFN first linear), 2 (SiLU / dropout gradient) or 3 (residual + dropout)");
     T_CHECK(h, (K % 32) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && lda >= K && ldb >= K, "some_train_gemm16s: K % 32, ld % 8 (16-byte rows), ld >= K");
-    T_CHECK(h, (N % 2) == 0 && ldc >= N && (epilogue == 0 || (ldc % 2) == 0), "some_train_gemm16s: N even, ldc >= N (even for 16-bit outputs)");
+    T_CHECK(h, (N % 2) == 0 && ldc >= N && (epilogue == 0 || epilogue == 3 || (ldc % 2) == 0), "some_train_gemm16s: N even, ldc >= N (even for 16-bit outputs)");
     T_CHECK(h, ((reinterpret_cast<uintptr_t>(A16_dev) | reinterpret_cast<uintptr_t>(B16_dev)) & 15) == 0 && (reinterpret_cast<uintptr_t>(C_dev) & 3) == 0,
             "some_train_gemm16s: operands must be 16-byte aligned");
     T_CHECK(h, p >= 0.f && p < 1.f, "some_train_gemm16s: dropout rate in [0, 1)");
@@ -171,13 +171,28 @@ int some_train_gemm16s(SomeHandle* h, int32_t epilogue, const void* A16_dev, int
         T_CHECK(h, plane_elems >= (int64_t)M * ldc && (plane_elems % 2) == 0, "some_train_gemm16s: plane_elems (h16 -> a16 distance) must cover M * ldc, even");
         plane_bytes = (size_t)plane_elems * 2;
         T_CHECK(h, plane_bytes + (size_t)M * ldc * 2 <= lim, "some_train_gemm16s: the two output planes exceed 2 GiB (split the batch)");
+    } else if (epilogue == 3) {
+        T_CHECK(h, H16_dev != nullptr && ldh >= N && (reinterpret_cast<uintptr_t>(H16_dev) & 3) == 0, "some_train_gemm16s: the residual (fp32 [M, ldh], ldh >= N)");
+        T_CHECK(h, (size_t)M * ldc * 4 <= lim && (size_t)M * ldh * 4 <= lim, "some_train_gemm16s: an array exceeds 2 GiB (split the batch)");
     } else {
         T_CHECK(h, H16_dev != nullptr && ldh >= N && (ldh % 2) == 0 && (reinterpret_cast<uintptr_t>(H16_dev) & 3) == 0, "some_train_gemm16s: h16 (ldh >= N, even)");
         T_CHECK(h, (size_t)M * ldc * 2 <= lim && (size_t)M * ldh * 2 <= lim, "some_train_gemm16s: an array exceeds 2 GiB (split the batch)");
     }
     T_CHECK(h, (uint64_t)((M + 1) / 2) * (uint64_t)N <= 0xffffffffull, "some_train_gemm16s: more than 2^32 dropout cells");
     T_TRY(h, launch_gemm16s(epilogue, A16_dev, lda, B16_dev, ldb, bias_dev, C_dev, ldc, H16_dev, ldh, plane_bytes, M, N, K, operand == 2, p, seed,
-                            st(stream)));
+                            alpha, st(stream)));
+    return SOME_OK;
+}
+
+int some_train_dropcast16(SomeHandle* h, const float* d_dev, void* y16_dev, int32_t M, int32_t N, float alpha, float p, uint64_t seed,
+                          int32_t operand, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M > 0 && N > 0 && (N % 4) == 0 && d_dev && y16_dev, "some_train_dropcast16: bad argument (N % 4 == 0)");
+    T_CHECK(h, operand == 1 || operand == 2, "some_train_dropcast16: operand must be 1 (f16) or 2 (bf16)");
+    T_CHECK(h, p >= 0.f && p < 1.f, "some_train_dropcast16: dropout rate in [0, 1)");
+    T_CHECK(h, (reinterpret_cast<uintptr_t>(d_dev) & 15) == 0 && (reinterpret_cast<uintptr_t>(y16_dev) & 7) == 0, "some_train_dropcast16: alignment (16 / 8 bytes)");
+    T_CHECK(h, (uint64_t)((M + 1) / 2) * (uint64_t)N <= 0xffffffffull, "some_train_dropcast16: more than 2^32 dropout cells");
+    T_TRY(h, launch_dropcast16(d_dev, y16_dev, M, N, alpha, p, seed, operand == 2, st(stream)));
     return SOME_OK;
 }
 
@@ -238,7 +253,16 @@ int some_train_layernorm_fwd(SomeHandle* h, const float* x_dev, const float* gam
                              float* y_dev, float* mean_dev, float* rstd_dev, int32_t M, void* stream) {
     if (!h) return SOME_EINVAL;
     T_CHECK(h, M >= 0 && x_dev && gamma_dev && beta_dev && y_dev && mean_dev && rstd_dev, "some_train_layernorm_fwd: bad argument");
-    T_TRY(h, launch_ln_fwd(x_dev, gamma_dev, beta_dev, y_dev, mean_dev, rstd_dev, M, st(stream)));
+    T_TRY(h, launch_ln_fwd(x_dev, gamma_dev, beta_dev, y_dev, mean_dev, rstd_dev, M, 0, st(stream)));
+    return SOME_OK;
+}
+
+int some_train_layernorm_fwd16(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                               void* y16_dev, float* mean_dev, float* rstd_dev, int32_t M, int32_t operand, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M >= 0 && x_dev && gamma_dev && beta_dev && y16_dev && mean_dev && rstd_dev, "some_train_layernorm_fwd16: bad argument");
+    T_CHECK(h, operand == 1 || operand == 2, "some_train_layernorm_fwd16: operand must be 1 (f16) or 2 (bf16)");
+    T_TRY(h, launch_ln_fwd(x_dev, gamma_dev, beta_dev, y16_dev, mean_dev, rstd_dev, M, operand, st(stream)));
     return SOME_OK;
 }
 
@@ -246,12 +270,20 @@ int some_train_layernorm_bwd(SomeHandle* h, const float* dy_dev, const float* x_
                              const float* mean_dev, const float* rstd_dev, float* dx_dev, float* dgamma_dev,
                              float* dbeta_dev, int32_t accumulate, int32_t M, void* scratch_dev, size_t scratch_bytes,
                              void* stream) {
+    return some_train_layernorm_bwd_add(h, dy_dev, x_dev, gamma_dev, mean_dev, rstd_dev, nullptr, dx_dev, dgamma_dev, dbeta_dev, accumulate, M,
+                                        scratch_dev, scratch_bytes, stream);
+}
+
+int some_train_layernorm_bwd_add(SomeHandle* h, const float* dy_dev, const float* x_dev, const float* gamma_dev,
+                                 const float* mean_dev, const float* rstd_dev, const float* add_dev, float* dx_dev, float* dgamma_dev,
+                                 float* dbeta_dev, int32_t accumulate, int32_t M, void* scratch_dev, size_t scratch_bytes,
+                                 void* stream) {
     if (!h) return SOME_EINVAL;
     T_CHECK(h, M >= 0 && dy_dev && x_dev && gamma_dev && mean_dev && rstd_dev && dx_dev && dgamma_dev && dbeta_dev,
             "some_train_layernorm_bwd: bad argument");
     if (M == 0) return SOME_OK;
     T_CHECK(h, scratch_dev && scratch_bytes >= train_ln_scratch_bytes(M), "some_train_layernorm_bwd: scratch too small (some_train_scratch_bytes(M, 512))");
-    T_TRY(h, launch_ln_bwd(dy_dev, x_dev, gamma_dev, mean_dev, rstd_dev, dx_dev, dgamma_dev, dbeta_dev, accumulate, M,
+    T_TRY(h, launch_ln_bwd(dy_dev, x_dev, gamma_dev, mean_dev, rstd_dev, add_dev, dx_dev, dgamma_dev, dbeta_dev, accumulate, M,
                            static_cast<float*>(scratch_dev), st(stream)));
     return SOME_OK;
 }

@@ -14,6 +14,8 @@
 //   G16S_FFN1   bias + h16 = rn16(acc), a16 = rn16(dropout(silu(h16)))   - conform_ffn.forward ln1 / act / drop1 (Gconform.py:29-32)
 //   G16S_DSILU  dh16 = rn16(acc * keep * silu'(h16))                      - the data gradient through drop1 / act into ln1
 //   G16S_F32    fp32 output (+ bias)
+//   G16S_RESDROP  fp32 output = residual + alpha * dropout(acc + bias)    - the block's `x = ffn(x) * 0.5 + x` (Gconform.py:57,60) with
+//               conform_ffn's output dropout, folded into the second linear
 // so the FFN's [M, 2048] intermediates exist ONLY as 16-bit arrays (h16 and a16 forward, dh16 backward) and no element-wise pass
 // runs between the four GEMMs.
 #include "internal.h"
@@ -67,8 +69,9 @@ struct G16sArgs {
     uint32_t plane;              // G16S_FFN1: byte distance from the h16 plane to the a16 plane
     uint32_t thr; float keep;    // dropout: an element is zeroed when its 16 random bits < thr, kept values are scaled by `keep`
     uint32_t k0, k1;
+    float alpha;                 // G16S_RESDROP
 };
-enum { G16S_F32 = 0, G16S_FFN1 = 1, G16S_DSILU = 2 };
+enum { G16S_F32 = 0, G16S_FFN1 = 1, G16S_DSILU = 2, G16S_RESDROP = 3 };
 
 // ---- epilogues.  C/D layout of v_mfma_f32_32x32x16: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
 // 16-bit outputs leave as DWORDS: lanes 2 j and 2 j + 1 (adjacent columns) exchange halves by DPP, after which the even lane holds
@@ -94,6 +97,38 @@ __device__ __forceinline__ void epilogue16s(const G16sArgs& a, f32x16 (&acc)[TM]
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][jn][r] + bias), rc, vc, rk(r) * row_c, 0);
+            }
+        }
+    } else if constexpr (EPI == G16S_RESDROP) {
+        const uint32_t row_c = (uint32_t)a.ldc * 4u, row_h = (uint32_t)a.ldh * 4u;
+        const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.C, (size_t)a.M * row_c);
+        const __amdgpu_buffer_rsrc_t rr = make_rsrc(a.H, (size_t)a.M * row_h);
+        const float ak = a.alpha * a.keep;
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int n = n0 + (wn * TN + jn) * 32 + l31;
+            const bool nv = FULL || n < a.N;
+            const float bias = (a.bias != nullptr && nv) ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row0 = m0 + (wm * TM + i) * 32 + 4 * hi;
+                const uint32_t vc = nv ? (uint32_t)row0 * row_c + (uint32_t)n * 4u : kOob;
+                const uint32_t vr = nv ? (uint32_t)row0 * row_h + (uint32_t)n * 4u : kOob;
+                const uint32_t cell0 = ((uint32_t)row0 >> 1) * (uint32_t)a.N + (uint32_t)n;
+                float res[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, vr, rk(r) * row_h, 0));
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    const uint32_t bits = drop_bits(cell0 + (rk(2 * rp) >> 1) * (uint32_t)a.N, a.k0, a.k1);   // rows (m, m + 1), m even
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = 2 * rp + e;
+                        const float k = (e ? bits >> 16 : bits & 0xffffu) >= a.thr ? ak : 0.f;
+                        const float v = __fadd_rn(res[r], __fmul_rn(k, acc[i][jn][r] + bias));       // alpha * dropout(y) + x, no contraction
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rc, vc, rk(r) * row_c, 0);
+                    }
+                }
             }
         }
     } else if constexpr (EPI == G16S_FFN1) {
@@ -316,6 +351,33 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ x
     *reinterpret_cast<u32x4*>(y + i * 4) = o;
 }
 
+// y16[m][n] = rn16(alpha * keep(m, n) * d[m][n]) with the G16S_RESDROP mask: the gradient of `alpha * dropout(y) + x` w.r.t. y, written
+// directly as the 16-bit operand of the data-gradient GEMM.  A thread owns rows (2 q, 2 q + 1) of four adjacent columns: one word of
+// dropout bits per column serves both rows.
+template <bool BF16>
+__global__ __launch_bounds__(256) void dropcast16_kernel(const float* __restrict__ d, uint16_t* __restrict__ y, int M, int N, float ak, uint32_t thr,
+                                                          uint32_t k0, uint32_t k1) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int nq = N >> 2;
+    const int q = (int)(t / nq), n = (int)(t % nq) * 4;
+    const int m = 2 * q;
+    if (m >= M) return;
+    uint32_t bits[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bits[i] = drop_bits((uint32_t)q * (uint32_t)N + (uint32_t)(n + i), k0, k1);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (m + e >= M) break;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(d + (size_t)(m + e) * N + n);
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = ((e ? bits[i] >> 16 : bits[i] & 0xffffu) >= thr ? ak : 0.f) * v[i];
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 w = {pack16<BF16>(o[0], o[1]), pack16<BF16>(o[2], o[3])};
+        *reinterpret_cast<u32x2*>(y + (size_t)(m + e) * N + n) = w;
+    }
+}
+
 // W [N, K] fp32 -> W16 [N, K] and W16T [K, N]: 64 x 64 tiles through LDS (both outputs leave as 128-byte row segments)
 template <bool BF16>
 __global__ __launch_bounds__(256) void transpose16_kernel(const float* __restrict__ w, uint16_t* __restrict__ w16, uint16_t* __restrict__ w16t,
@@ -346,26 +408,44 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const float* __restric
 
 }  // namespace
 
-hipError_t launch_gemm16s(int epi, const void* A16, int lda, const void* B16, int ldb, const float* bias, void* C, int ldc, const void* H16,
-                          int ldh, size_t plane_bytes, int M, int N, int K, int bf16, float p, uint64_t seed, hipStream_t s) {
-    if (M <= 0 || N <= 0 || K <= 0) return hipSuccess;
-    if ((K & 31) || (lda & 7) || (ldb & 7) || (N & 1) || epi < G16S_F32 || epi > G16S_DSILU) return hipErrorInvalidValue;
-    G16sArgs a{};
-    a.A = static_cast<const char*>(A16); a.B = static_cast<const char*>(B16); a.bias = bias; a.C = static_cast<char*>(C);
-    a.H = static_cast<const char*>(H16);
-    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldh = ldh; a.plane = (uint32_t)plane_bytes;
+// dropout threshold / scale / key words of a call site (shared by the GEMM epilogues and dropcast16_kernel)
+static void drop_params(float p, uint64_t seed, uint32_t& thr, float& keep, uint32_t& k0, uint32_t& k1) {
     // 16 random bits per element: dropped when < thr; the scale is 1 / (1 - thr / 65536), the rate actually applied
-    const uint32_t thr = p > 0.f ? (uint32_t)(p * 65536.0f + 0.5f) : 0u;
-    a.thr = thr > 65535u ? 65535u : thr;
-    a.keep = 65536.0f / (65536.0f - (float)a.thr);
+    const uint32_t t = p > 0.f ? (uint32_t)(p * 65536.0f + 0.5f) : 0u;
+    thr = t > 65535u ? 65535u : t;
+    keep = 65536.0f / (65536.0f - (float)thr);
     uint64_t z = seed + 0x9E3779B97F4A7C15ull;                     // splitmix64 of the call site's seed -> the two key words
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
-    a.k0 = (uint32_t)z; a.k1 = (uint32_t)(z >> 32);
+    k0 = (uint32_t)z; k1 = (uint32_t)(z >> 32);
+}
+
+hipError_t launch_dropcast16(const float* d, void* y16, int M, int N, float alpha, float p, uint64_t seed, int bf16, hipStream_t s) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    if (N & 3) return hipErrorInvalidValue;
+    uint32_t thr, k0, k1; float keep;
+    drop_params(p, seed, thr, keep, k0, k1);
+    const int64_t threads = (int64_t)((M + 1) / 2) * (N / 4);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (bf16) hipLaunchKernelGGL(dropcast16_kernel<true>, grid, dim3(256), 0, s, d, static_cast<uint16_t*>(y16), M, N, alpha * keep, thr, k0, k1);
+    else hipLaunchKernelGGL(dropcast16_kernel<false>, grid, dim3(256), 0, s, d, static_cast<uint16_t*>(y16), M, N, alpha * keep, thr, k0, k1);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm16s(int epi, const void* A16, int lda, const void* B16, int ldb, const float* bias, void* C, int ldc, const void* H16,
+                          int ldh, size_t plane_bytes, int M, int N, int K, int bf16, float p, uint64_t seed, float alpha, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0) return hipSuccess;
+    if ((K & 31) || (lda & 7) || (ldb & 7) || (N & 1) || epi < G16S_F32 || epi > G16S_RESDROP) return hipErrorInvalidValue;
+    G16sArgs a{};
+    a.A = static_cast<const char*>(A16); a.B = static_cast<const char*>(B16); a.bias = bias; a.C = static_cast<char*>(C);
+    a.H = static_cast<const char*>(H16);
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldh = ldh; a.plane = (uint32_t)plane_bytes;
+    drop_params(p, seed, a.thr, a.keep, a.k0, a.k1);
+    a.alpha = alpha;
 #define G16S_CASE(E) case E: return bf16 ? launch16s<E, true>(a, s) : launch16s<E, false>(a, s);
     switch (epi) {
-        G16S_CASE(G16S_F32) G16S_CASE(G16S_FFN1) G16S_CASE(G16S_DSILU)
+        G16S_CASE(G16S_F32) G16S_CASE(G16S_FFN1) G16S_CASE(G16S_DSILU) G16S_CASE(G16S_RESDROP)
     }
 #undef G16S_CASE
     return hipErrorInvalidValue;

@@ -132,8 +132,11 @@ struct BnGradF {         // per-COLUMN statistics
 };
 
 // ---- LayerNorm (width 512): one wave per row, lane owns columns 4 l .. 4 l + 3 and 256 + 4 l .. -------------------
+// OUT16: 0 fp32 output; 1 / 2: the output is written as f16 / bf16 (the 16-bit operand of the FFN's first GEMM, train_gemm16s.hip) - same
+// arithmetic, one rounding at the store
+template <int OUT16>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                                                      float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int M) {
+                                                      void* __restrict__ y_out, float* __restrict__ mean, float* __restrict__ rstd, int M) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + (size_t)row * kLnDim + lane * 4);
@@ -149,8 +152,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     f32x4 o0, o1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o0[i] = (a0[i] - mu) * rs * g0[i] + b0[i]; o1[i] = (a1[i] - mu) * rs * g1[i] + b1[i]; }
-    *reinterpret_cast<f32x4*>(y + (size_t)row * kLnDim + lane * 4) = o0;
-    *reinterpret_cast<f32x4*>(y + (size_t)row * kLnDim + 256 + lane * 4) = o1;
+    if constexpr (OUT16 == 0) {
+        float* y = static_cast<float*>(y_out);
+        *reinterpret_cast<f32x4*>(y + (size_t)row * kLnDim + lane * 4) = o0;
+        *reinterpret_cast<f32x4*>(y + (size_t)row * kLnDim + 256 + lane * 4) = o1;
+    } else {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        auto pk = [](float a, float c) -> uint32_t {
+            const f2 v = {a, c};
+            if constexpr (OUT16 == 2) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2));
+            else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2));
+        };
+        uint16_t* y = static_cast<uint16_t*>(y_out);
+        const u2 w0 = {pk(o0[0], o0[1]), pk(o0[2], o0[3])}, w1 = {pk(o1[0], o1[1]), pk(o1[2], o1[3])};
+        *reinterpret_cast<u2*>(y + (size_t)row * kLnDim + lane * 4) = w0;
+        *reinterpret_cast<u2*>(y + (size_t)row * kLnDim + 256 + lane * 4) = w1;
+    }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
@@ -162,7 +182,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 constexpr int kLnChunk = 128, kLnWaves = 8;
 __global__ __launch_bounds__(64 * kLnWaves) void ln_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ g,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            float* __restrict__ dx, float* __restrict__ partial, int M) {
+                                                            const float* __restrict__ add, float* __restrict__ dx, float* __restrict__ partial, int M) {
+    // add (may be null): a second gradient of x - the residual branch around the LayerNorm - summed into dx here instead of by a
+    // separate pass; (ln gradient) + add as its own rounding step (no FMA), i.e. the bits a separate addition would give
     __shared__ float red[2][kLnWaves][kLnDim];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = blockIdx.x * kLnChunk;
@@ -201,6 +223,11 @@ __global__ __launch_bounds__(64 * kLnWaves) void ln_bwd_fused_kernel(const float
             f32x4 o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = rs * (gd[h * 4 + i] - c1 - xh[h * 4 + i] * c2);
+            if (add != nullptr) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(add + (size_t)row * kLnDim + h * 256 + lane * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = __fadd_rn(a[i], o[i]);
+            }
             *reinterpret_cast<f32x4*>(dx + (size_t)row * kLnDim + h * 256 + lane * 4) = o;
         }
     }
@@ -659,17 +686,20 @@ hipError_t launch_weighted_colsum(const float* w, int ldw, const float* x, int M
     return col_reduce(M, N, RowWeightedF{w, ldw, x, ld}, out, wsum, 0, scratch, s);
 }
 
-hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, hipStream_t s) {
+hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, void* y, float* mean, float* rstd, int M, int out16, hipStream_t s) {
     if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, g, b, y, mean, rstd, M);
+    const dim3 grid((unsigned)((M + 3) / 4));
+    if (out16 == 0) hipLaunchKernelGGL(ln_fwd_kernel<0>, grid, dim3(256), 0, s, x, g, b, y, mean, rstd, M);
+    else if (out16 == 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, dim3(256), 0, s, x, g, b, y, mean, rstd, M);
+    else hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, s, x, g, b, y, mean, rstd, M);
     return hipGetLastError();
 }
 
-hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, float* dx,
+hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, const float* add, float* dx,
                          float* dgamma, float* dbeta, int accumulate, int M, float* scratch, hipStream_t s) {
     if (M <= 0) return hipSuccess;
     const int P = (M + kLnChunk - 1) / kLnChunk;
-    hipLaunchKernelGGL(ln_bwd_fused_kernel, dim3((unsigned)P), dim3(64 * kLnWaves), 0, s, dy, x, g, mean, rstd, dx, scratch, M);
+    hipLaunchKernelGGL(ln_bwd_fused_kernel, dim3((unsigned)P), dim3(64 * kLnWaves), 0, s, dy, x, g, mean, rstd, add, dx, scratch, M);
     hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)(kLnDim / 64)), dim3(256), 0, s, scratch, P, kLnDim, dbeta, dgamma, accumulate);
     return hipGetLastError();
 }

@@ -118,6 +118,14 @@ class TrainableMidiConforms:
         P, o = self.params, self.ops
         return o.ffn(x, P[pre + '.ln1.weight'], P[pre + '.ln1.bias'], P[pre + '.ln2.weight'], P[pre + '.ln2.bias'], *self._drop('ffn_latent'))
 
+    def _ffn_block(self, x, pre: str, i: int, name: str):
+        """x = ffn(norm_i(x)) * 0.5 + x (Gconform.py:57,60), the FFN's output dropout included - one fused operator in mixed precision."""
+        P, o = self.params, self.ops
+        f = pre + name
+        latent, out = self._drop('ffn_latent'), self._drop('ffn_out')                # the call order of the unfused composition
+        return o.ffn_block(x, P[f'{pre}.norm{i}.weight'], P[f'{pre}.norm{i}.bias'], P[f + '.ln1.weight'], P[f + '.ln1.bias'], P[f + '.ln2.weight'],
+                           P[f + '.ln2.bias'], 0.5, latent[0], latent[1], out[0], out[1])
+
     def _attention(self, x, pre: str, batch):
         P, o = self.params, self.ops
         wqkv = o.cat_rows(P[pre + '.to_q.weight'], P[pre + '.to_kv.weight'])                  # q | k | v rows
@@ -137,10 +145,10 @@ class TrainableMidiConforms:
         """conform_blocke.forward (Gconform.py:56-63)."""
         P, o = self.params, self.ops
         ln = lambda t, i: o.layernorm(t, P[f'{pre}.norm{i}.weight'], P[f'{pre}.norm{i}.bias'])   # noqa: E731
-        x = o.axpy_dropout(0.5, self._ffn(ln(x, 1), pre + '.ffn1'), x, *self._drop('ffn_out'))
+        x = self._ffn_block(x, pre, 1, '.ffn1')
         x = o.axpy_dropout(1.0, self._attention(ln(x, 2), pre + '.att', batch), x, *self._drop('attention'))
         x = o.axpy_dropout(1.0, self._conv(ln(x, 3), pre + '.conv', batch), x, *self._drop('conv'))
-        x = o.axpy_dropout(0.5, self._ffn(ln(x, 4), pre + '.ffn2'), x, *self._drop('ffn_out'))
+        x = self._ffn_block(x, pre, 4, '.ffn2')
         return ln(x, 5)
 
     def forward(self, units: torch.Tensor, batch: ClipBatch, mask: Optional[torch.Tensor] = None):

@@ -126,10 +126,11 @@ class TrainOps:
         return w16, w16t
 
     def gemm16s(self, epi: int, a16: torch.Tensor, b16: torch.Tensor, bias, out: torch.Tensor, ldc: int, M: int, N: int, K: int,
-                h16: Optional[torch.Tensor] = None, plane: int = 0, p: float = 0.0, seed: int = 0):
-        """out = epilogue(a16 [M, K] @ b16 [N, K]^T): some_train_gemm16s (0 fp32 (+ bias), 1 FFN first linear, 2 SiLU / dropout gradient)."""
+                h16: Optional[torch.Tensor] = None, plane: int = 0, p: float = 0.0, seed: int = 0, alpha: float = 1.0):
+        """out = epilogue(a16 [M, K] @ b16 [N, K]^T): some_train_gemm16s (0 fp32 (+ bias), 1 FFN first linear, 2 SiLU / dropout gradient,
+        3 residual ``h16`` (fp32) + alpha * dropout(. + bias))."""
         self.check(self.lib.some_train_gemm16s(self.h, epi, _p(a16), a16.stride(0), _p(b16), b16.stride(0), _p(bias), _p(out), ldc, _p(h16),
-                                               h16.stride(0) if h16 is not None else 0, plane, M, N, K, self._hi_mode, float(p), C.c_uint64(seed),
+                                               h16.stride(0) if h16 is not None else 0, plane, M, N, K, self._hi_mode, float(p), seed, float(alpha),
                                                self.stream()))
 
     def wgrad16(self, dy16: torch.Tensor, x16: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor], accumulate: bool):
@@ -343,6 +344,13 @@ class TrainOps:
         if self.can_ffn16(x.shape[0], x.shape[1], w1.shape[0], w2.shape[0]):
             return self._apply(_Ffn16, x, w1, b1, w2, b2, p, seed)
         return self.linear(self.silu_dropout(self.linear(x, w1, b1), p, seed), w2, b2)
+
+    def ffn_block(self, x, gamma, beta, w1, b1, w2, b2, alpha: float, p_latent: float, seed_latent: int, p_out: float, seed_out: int):
+        """One FFN sub-block of conform_blocke.forward (Gconform.py:57,60): ``x + alpha * dropout(ffn(LayerNorm(x)))``."""
+        if self.can_ffn16(x.shape[0], x.shape[1], w1.shape[0], w2.shape[0]) and x.shape[1] == 512 and w2.shape[0] == 512:
+            return self._apply(_FfnBlock16, x, gamma, beta, w1, b1, w2, b2, alpha, p_latent, seed_latent, p_out, seed_out)
+        y = self.ffn(self.layernorm(x, gamma, beta), w1, b1, w2, b2, p_latent, seed_latent)
+        return self.axpy_dropout(alpha, y, x, p_out, seed_out)
 
     def layernorm(self, x, gamma, beta):
         return self._apply(_LayerNorm, x, gamma, beta)
@@ -566,6 +574,82 @@ class _Ffn16(torch.autograd.Function):
                     dw = None
             grads += [dw, db]
         return None, dx, grads[0], grads[1], grads[2], grads[3], None, None
+
+
+class _FfnBlock16(torch.autograd.Function):
+    """x + alpha * dropout(ffn(LayerNorm(x))) in mixed precision, every intermediate written once and in 16 bits where a GEMM reads it:
+    forward:  n16 = rn16(LayerNorm(x)) (one kernel, no cast pass);  (h16 | a16) = FFN1 epilogue;  out = x + alpha * dropout(a16 W2^T + b2)
+              in FFN2's epilogue (no separate residual pass)
+    backward: dy16 = rn16(alpha * mask / (1 - p) * d) (one kernel);  dh16, weight gradients as in _Ffn16;  dn = dh16 W1;
+              dx = d + LayerNorm'(dn) with the addition inside the LayerNorm-backward kernel."""
+
+    @staticmethod
+    def forward(ctx, ops: TrainOps, x, gamma, beta, w1, b1, w2, b2, alpha, p_latent, seed_latent, p_out, seed_out):
+        x = x.contiguous()
+        M, K = x.shape
+        H, N = w1.shape[0], w2.shape[0]
+        n16 = torch.empty((M, K), dtype=ops.dtype16, device=ops.device)
+        mean, rstd = ops.new(M), ops.new(M)
+        ops.check(ops.lib.some_train_layernorm_fwd16(ops.h, _p(x), _p(gamma), _p(beta), _p(n16), _p(mean), _p(rstd), M, ops._hi_mode, ops.stream()))
+        ha = torch.empty((2, M, H), dtype=ops.dtype16, device=ops.device)            # h16 plane, a16 plane
+        ops.gemm16s(1, n16, ops.shadow16(w1)[0], b1, ha, H, M, H, K, plane=M * H, p=p_latent, seed=seed_latent)
+        out = ops.new(M, N)
+        ops.gemm16s(3, ha[1], ops.shadow16(w2)[0], b2, out, N, M, N, H, h16=x, p=p_out, seed=seed_out, alpha=alpha)
+        ctx.ops = ops
+        ctx.drop = (alpha, p_latent, seed_latent, p_out, seed_out)
+        ctx.save_for_backward(x, gamma, mean, rstd, n16, ha)
+        ctx.params = (gamma, beta, w1, b1, w2, b2)                                   # identities: shadows and gradient sinks
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        ops: TrainOps = ctx.ops
+        x, gamma_t, mean, rstd, n16, ha = ctx.saved_tensors
+        gamma, beta, w1, b1, w2, b2 = ctx.params
+        alpha, p_latent, seed_latent, p_out, seed_out = ctx.drop
+        d = d.contiguous()
+        M, K = x.shape
+        H, N = w1.shape[0], w2.shape[0]
+        dy16 = torch.empty((M, N), dtype=ops.dtype16, device=ops.device)
+        ops.check(ops.lib.some_train_dropcast16(ops.h, _p(d), _p(dy16), M, N, float(alpha), float(p_out), seed_out, ops._hi_mode, ops.stream()))
+        dh16 = torch.empty((M, H), dtype=ops.dtype16, device=ops.device)
+        ops.gemm16s(2, dy16, ops.shadow16(w2)[1], None, dh16, H, M, H, N, h16=ha[0], p=p_latent, seed=seed_latent)
+        dn = ops.new(M, K)
+        ops.gemm16s(0, dh16, ops.shadow16(w1)[1], None, dn, K, M, K, H)
+        grads = []
+        for (w, b, g16, in16, iw, ib) in ((w1, b1, dh16, n16, 4, 5), (w2, b2, dy16, ha[1], 6, 7)):
+            dw = db = None
+            want_w, want_b = ctx.needs_input_grad[iw], b is not None and ctx.needs_input_grad[ib]
+            sw = ops.sink(w) if want_w else None
+            sb = ops.sink(b) if want_b else None
+            if want_w and sw is not None and (sb is not None or not want_b):
+                ops.wgrad16(g16, in16, sw, sb, accumulate=True)                      # into the parameters' gradient arrays
+                ops.deposited(w)
+                if sb is not None:
+                    ops.deposited(b)
+            elif want_w or want_b:
+                dw = ops.new(*w.shape)
+                db = ops.new(w.shape[0]) if want_b else None
+                ops.wgrad16(g16, in16, dw, db, accumulate=False)
+                if not want_w:
+                    dw = None
+            grads += [dw, db]
+        # dx = d (the residual branch) + LayerNorm'(dn); gamma / beta gradients as in _LayerNorm
+        dx = torch.empty_like(x)
+        sc = ops.scratch(M, 512)
+        sg, sbeta = ops.sink(gamma), ops.sink(beta)
+        add = d if ctx.needs_input_grad[1] else None
+        if sg is not None and sbeta is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
+            ops.check(ops.lib.some_train_layernorm_bwd_add(ops.h, _p(dn), _p(x), _p(gamma_t), _p(mean), _p(rstd), _p(add), _p(dx), _p(sg), _p(sbeta), 1, M,
+                                                           _p(sc), sc.numel(), ops.stream()))
+            ops.deposited(gamma)
+            ops.deposited(beta)
+            dg = dbeta = None
+        else:
+            dg, dbeta = torch.empty_like(gamma_t), torch.empty_like(gamma_t)
+            ops.check(ops.lib.some_train_layernorm_bwd_add(ops.h, _p(dn), _p(x), _p(gamma_t), _p(mean), _p(rstd), _p(add), _p(dx), _p(dg), _p(dbeta), 0, M,
+                                                           _p(sc), sc.numel(), ops.stream()))
+        return None, dx, dg, dbeta, grads[0], grads[1], grads[2], grads[3], None, None, None, None, None
 
 
 class _LayerNorm(torch.autograd.Function):

@@ -159,3 +159,63 @@ def test_dropout_bits_match_the_host_restatement(ops):
         assert np.array_equal(kept[clear], want[clear])
     finally:
         ops.set_mixed_precision(False)
+
+
+@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+def test_ffn_block_equals_the_unfused_composition(ops, operand):
+    """x + 0.5 * ffn(LayerNorm(x)) as ONE operator (LayerNorm writing the 16-bit GEMM operand, residual in FFN2's epilogue, the residual
+    gradient summed inside LayerNorm-backward) against layernorm -> ffn -> axpy on the same kernels otherwise; latent dropout on (both
+    paths draw the same mask), output dropout off."""
+    M, K, H = 777, 512, 2048
+    ops.set_mixed_precision(True, operand)
+    try:
+        x = _rand(M, K, seed=31)
+        g, b = _rand(K, seed=32, scale=0.1) + 1.0, _rand(K, seed=33, scale=0.1)
+        w1, b1, w2, b2 = _rand(H, K, seed=34, scale=K ** -0.5), _rand(H, seed=35, scale=0.3), _rand(K, H, seed=36, scale=H ** -0.5), _rand(K, seed=37)
+        d = _rand(M, K, seed=38)
+        outs = []
+        for fused in (True, False):
+            ops.weights_version += 1
+            leaves = [t.clone().requires_grad_() for t in (x, g, b, w1, b1, w2, b2)]
+            if fused:
+                y = ops.ffn_block(*leaves, 0.5, 0.1, 4242, 0.0, 0)
+                assert type(y.grad_fn).__name__.startswith('_FfnBlock16')
+            else:
+                xx, gg, bb = leaves[:3]
+                y = ops.axpy_dropout(0.5, ops.ffn(ops.layernorm(xx, gg, bb), *leaves[3:], 0.1, 4242), xx, 0.0, 0)
+            y.backward(d)
+            outs.append([y.detach()] + [t.grad for t in leaves])
+        names = ['y', 'dx', 'dgamma', 'dbeta', 'dw1', 'db1', 'dw2', 'db2']
+        for n, a, c in zip(names, *outs):
+            assert float((a - c).abs().max()) <= 2e-6 * float(c.abs().max()), n
+    finally:
+        ops.set_mixed_precision(False)
+
+
+def test_ffn_block_output_dropout_and_its_gradient(ops):
+    """Output dropout folded into FFN2's epilogue: dropped cells keep exactly the residual, the rate is the requested one, the mask is the
+    documented function of (seed, row, column), and the backward pass applies the SAME mask (checked on the bias gradient of FFN2, the
+    column sums of rn16(0.5 * mask / (1 - p) * d))."""
+    from some_amd.training.dropout_bits import ffn_keep_mask, threshold
+    M, K, H, p, seed = 500, 512, 2048, 0.3, 99
+    ops.set_mixed_precision(True, 'bf16')
+    try:
+        x = _rand(M, K, seed=41)
+        g, b = torch.ones(K, device='cuda'), torch.zeros(K, device='cuda')
+        w1, b1, w2, b2 = _rand(H, K, seed=44, scale=K ** -0.5), _rand(H, seed=45, scale=0.3), _rand(K, H, seed=46, scale=H ** -0.5), _rand(K, seed=47) + 3.0
+        ops.weights_version += 1
+        leaves = [t.clone().requires_grad_() for t in (x, g, b, w1, b1, w2, b2)]
+        y = ops.ffn_block(*leaves, 0.5, 0.0, 0, p, seed)
+        kept = (y.detach() != x).cpu().numpy()                      # b2 = 3 + noise: a kept cell always moves the residual
+        want = ffn_keep_mask(seed, M, K, p)
+        assert np.array_equal(kept, want)
+        assert abs(kept.mean() - (1 - threshold(p) / 65536.0)) < 4 * (p * (1 - p) / kept.size) ** 0.5
+        d = _rand(M, K, seed=48)
+        y.backward(d)
+        keep = 65536.0 / (65536.0 - threshold(p))
+        dy16 = (torch.from_numpy(want).cuda() * (0.5 * keep) * d).bfloat16().double()
+        assert float((leaves[6].grad.double() - dy16.sum(0)).abs().max()) < 2e-6 * float(dy16.sum(0).abs().max())
+        # the residual branch reaches dx unmasked: dx - d is the LayerNorm gradient, zero-mean over each row (gamma = 1)
+        assert float((leaves[0].grad - d).sum(1).abs().max()) < 1e-3 * float((leaves[0].grad - d).abs().sum(1).max())
+    finally:
+        ops.set_mixed_precision(False)

@@ -103,10 +103,10 @@ def bench16s(M=20672, operand=2, iters=20):
         flops = 2.0 * M * N * K
 
         def fwd():
-            _lib.check(h, lib.some_train_gemm16s(h, 0, p(x16), K, p(w16), K, p(b), p(y), N, None, 0, 0, M, N, K, operand, 0.0, 0, st))
+            _lib.check(h, lib.some_train_gemm16s(h, 0, p(x16), K, p(w16), K, p(b), p(y), N, None, 0, 0, M, N, K, operand, 0.0, 0, 1.0, st))
 
         def dgrad():
-            _lib.check(h, lib.some_train_gemm16s(h, 0, p(dy16), N, p(w16t), N, None, p(dx), K, None, 0, 0, M, K, N, operand, 0.0, 0, st))
+            _lib.check(h, lib.some_train_gemm16s(h, 0, p(dy16), N, p(w16t), N, None, p(dx), K, None, 0, 0, M, K, N, operand, 0.0, 0, 1.0, st))
 
         def wgrad():
             _lib.check(h, lib.some_train_gemm16_wgrad16(h, p(dy16), N, p(x16), K, p(dw), p(db), N, K, M, operand, 0, p(part), part.numel(), st))
@@ -133,10 +133,10 @@ def bench16s(M=20672, operand=2, iters=20):
             wt2 = torch.empty(N, K, dtype=dt, device='cuda').normal_()        # W2^T image [2048, 512]
             for pdrop in (0.0, 0.1):
                 def ffn1():
-                    _lib.check(h, lib.some_train_gemm16s(h, 1, p(x16), K, p(w16), K, p(b), p(ha), N, None, 0, M * N, M, N, K, operand, pdrop, 77, st))
+                    _lib.check(h, lib.some_train_gemm16s(h, 1, p(x16), K, p(w16), K, p(b), p(ha), N, None, 0, M * N, M, N, K, operand, pdrop, 77, 1.0, st))
 
                 def dsilu():
-                    _lib.check(h, lib.some_train_gemm16s(h, 2, p(g16), K, p(wt2), K, None, p(dh16), N, p(ha[0]), N, 0, M, N, K, operand, pdrop, 77, st))
+                    _lib.check(h, lib.some_train_gemm16s(h, 2, p(g16), K, p(wt2), K, None, p(dh16), N, p(ha[0]), N, 0, M, N, K, operand, pdrop, 77, 1.0, st))
                 for lab, fn in ((f'ffn1 epilogue p={pdrop}', ffn1), (f'dsilu epilogue p={pdrop}', dsilu)):
                     ms = timed(fn, iters)
                     print(f'16s {lab:26s} M={M} N={N} K={K}: {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TF', flush=True)
