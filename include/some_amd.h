@@ -253,6 +253,8 @@ int some_train_gemm16_wgrad(SomeHandle* h, const float* dY_dev, int32_t ldy, con
  * some_train_cast16:      y16[i] = rn16(x[i]), n % 8 == 0, 16-byte aligned arrays.
  * some_train_transpose16: W[N, K] fp32 -> W16[N, K] (forward operand) and / or W16T[K, N] (data-gradient operand); either may be NULL. */
 int some_train_cast16(SomeHandle* h, const float* x_dev, void* y16_dev, int64_t n, int32_t operand, void* stream);
+/* y16[i] = rn16(silu(x[i])): conform_conv's activation (modules/conv/base_conv.py:68) as the 16-bit operand of pointwise_conv2; n % 8 == 0. */
+int some_train_silu16(SomeHandle* h, const float* x_dev, void* y16_dev, int64_t n, int32_t operand, void* stream);
 int some_train_transpose16(SomeHandle* h, const float* w_dev, void* w16_dev, void* w16t_dev, int32_t N, int32_t K, int32_t operand, void* stream);
 /* C[M, N] = A16[M, K] B16[N, K]^T, fp32 accumulation, both operands contraction-contiguous 16-bit arrays (K % 32 == 0, lda % 8 ==
  * ldb % 8 == 0, 16-byte aligned) moved global -> LDS by DMA.  epilogue:

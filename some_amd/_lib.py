@@ -77,6 +77,7 @@ SYMBOLS = {
     'some_train_gemm16_wgrad': (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
     'some_train_transpose': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
     'some_train_cast16': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
+    'some_train_silu16': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
     'some_train_transpose16': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     'some_train_gemm16s': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_float, _P]),

@@ -72,6 +72,7 @@ hipError_t launch_gemm16s(int epi, const void* A16, int lda, const void* B16, in
                           int ldh, size_t plane_bytes, int M, int N, int K, int bf16, float p, uint64_t seed, float alpha, hipStream_t s);
 hipError_t launch_dropcast16(const float* d, void* y16, int M, int N, float alpha, float p, uint64_t seed, int bf16, hipStream_t s);
 hipError_t launch_cast16(const float* x, void* y16, int64_t n, int bf16, hipStream_t s);
+hipError_t launch_silu16(const float* x, void* y16, int64_t n, int bf16, hipStream_t s);
 hipError_t launch_transpose16(const float* w, void* w16, void* w16t, int N, int K, int bf16, hipStream_t s);
 
 // ---- row ops --------------------------------------------------------------------------------------

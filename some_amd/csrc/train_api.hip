@@ -142,6 +142,15 @@ int some_train_cast16(SomeHandle* h, const float* x_dev, void* y16_dev, int64_t 
     return SOME_OK;
 }
 
+int some_train_silu16(SomeHandle* h, const float* x_dev, void* y16_dev, int64_t n, int32_t operand, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, n >= 0 && (n % 8) == 0 && (n == 0 || (x_dev && y16_dev)), "some_train_silu16: n % 8 == 0, non-null arrays");
+    T_CHECK(h, operand == 1 || operand == 2, "some_train_silu16: operand must be 1 (f16) or 2 (bf16)");
+    T_CHECK(h, ((reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(y16_dev)) & 15) == 0, "some_train_silu16: 16-byte aligned arrays");
+    T_TRY(h, launch_silu16(x_dev, y16_dev, n, operand == 2, st(stream)));
+    return SOME_OK;
+}
+
 int some_train_transpose16(SomeHandle* h, const float* w_dev, void* w16_dev, void* w16t_dev, int32_t N, int32_t K, int32_t operand, void* stream) {
     if (!h) return SOME_EINVAL;
     T_CHECK(h, N > 0 && K > 0 && w_dev && (w16_dev || w16t_dev), "some_train_transpose16: bad argument");

@@ -351,6 +351,19 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ x
     *reinterpret_cast<u32x4*>(y + i * 4) = o;
 }
 
+// y16 = rn16(silu(x)): the conv module's activation (modules/conv/base_conv.py:68) written as the 16-bit operand of pointwise_conv2's GEMM
+template <bool BF16>
+__global__ __launch_bounds__(256) void silu16_kernel(const float* __restrict__ x, uint32_t* __restrict__ y, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // eight elements per thread
+    if (i >= n8) return;
+    const f32x4 u = *reinterpret_cast<const f32x4*>(x + i * 8), v = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o[k] = u[k] * sigmoidf_(u[k]); o[4 + k] = v[k] * sigmoidf_(v[k]); }
+    const u32x4 w = {pack16<BF16>(o[0], o[1]), pack16<BF16>(o[2], o[3]), pack16<BF16>(o[4], o[5]), pack16<BF16>(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(y + i * 4) = w;
+}
+
 // y16[m][n] = rn16(alpha * keep(m, n) * d[m][n]) with the G16S_RESDROP mask: the gradient of `alpha * dropout(y) + x` w.r.t. y, written
 // directly as the 16-bit operand of the data-gradient GEMM.  A thread owns rows (2 q, 2 q + 1) of four adjacent columns: one word of
 // dropout bits per column serves both rows.
@@ -449,6 +462,16 @@ hipError_t launch_gemm16s(int epi, const void* A16, int lda, const void* B16, in
     }
 #undef G16S_CASE
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_silu16(const float* x, void* y16, int64_t n, int bf16, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n & 7) return hipErrorInvalidValue;
+    const int64_t n8 = n / 8;
+    const dim3 grid((unsigned)((n8 + 255) / 256));
+    if (bf16) hipLaunchKernelGGL(silu16_kernel<true>, grid, dim3(256), 0, s, x, static_cast<uint32_t*>(y16), n8);
+    else hipLaunchKernelGGL(silu16_kernel<false>, grid, dim3(256), 0, s, x, static_cast<uint32_t*>(y16), n8);
+    return hipGetLastError();
 }
 
 hipError_t launch_cast16(const float* x, void* y16, int64_t n, int bf16, hipStream_t s) {

@@ -113,11 +113,6 @@ class TrainableMidiConforms:
         return p, (self._seed * 1000003 + self._calls) * 4294967311 % (1 << 62)
 
     # ---- blocks (Gconform.py) ------------------------------------------------------------------------------------------
-    def _ffn(self, x, pre: str):
-        """conform_ffn.forward (Gconform.py:29-34) WITHOUT its output dropout, which the caller fuses into the residual."""
-        P, o = self.params, self.ops
-        return o.ffn(x, P[pre + '.ln1.weight'], P[pre + '.ln1.bias'], P[pre + '.ln2.weight'], P[pre + '.ln2.bias'], *self._drop('ffn_latent'))
-
     def _ffn_block(self, x, pre: str, i: int, name: str):
         """x = ffn(norm_i(x)) * 0.5 + x (Gconform.py:57,60), the FFN's output dropout included - one fused operator in mixed precision."""
         P, o = self.params, self.ops
@@ -126,28 +121,20 @@ class TrainableMidiConforms:
         return o.ffn_block(x, P[f'{pre}.norm{i}.weight'], P[f'{pre}.norm{i}.bias'], P[f + '.ln1.weight'], P[f + '.ln1.bias'], P[f + '.ln2.weight'],
                            P[f + '.ln2.bias'], 0.5, latent[0], latent[1], out[0], out[1])
 
-    def _attention(self, x, pre: str, batch):
-        P, o = self.params, self.ops
-        wqkv = o.cat_rows(P[pre + '.to_q.weight'], P[pre + '.to_kv.weight'])                  # q | k | v rows
-        out = o.attention(o.linear(x, wqkv), batch)
-        return o.linear(out, P[pre + '.to_out.0.weight'], P[pre + '.to_out.0.bias'])
-
-    def _conv(self, x, pre: str, batch):
-        P, o = self.params, self.ops
-        h = o.glu(o.linear(x, P[pre + '.pointwise_conv1.weight'], P[pre + '.pointwise_conv1.bias']))
-        h = o.dwconv(h, P[pre + '.depthwise_conv.weight'], P[pre + '.depthwise_conv.bias'], batch)
-        h = o.batchnorm(h, P[pre + '.norm.weight'], P[pre + '.norm.bias'], P[pre + '.norm.running_mean'], P[pre + '.norm.running_var'])
-        with torch.no_grad():
-            P[pre + '.norm.num_batches_tracked'].add_(1)
-        return o.linear(o.silu(h), P[pre + '.pointwise_conv2.weight'], P[pre + '.pointwise_conv2.bias'])   # dropout: fused by the caller
-
     def _block(self, x, pre: str, batch):
         """conform_blocke.forward (Gconform.py:56-63)."""
         P, o = self.params, self.ops
         ln = lambda t, i: o.layernorm(t, P[f'{pre}.norm{i}.weight'], P[f'{pre}.norm{i}.bias'])   # noqa: E731
         x = self._ffn_block(x, pre, 1, '.ffn1')
-        x = o.axpy_dropout(1.0, self._attention(ln(x, 2), pre + '.att', batch), x, *self._drop('attention'))
-        x = o.axpy_dropout(1.0, self._conv(ln(x, 3), pre + '.conv', batch), x, *self._drop('conv'))
+        a, c = pre + '.att', pre + '.conv'
+        x = o.attention_block(x, P[f'{pre}.norm2.weight'], P[f'{pre}.norm2.bias'], P[a + '.to_q.weight'], P[a + '.to_kv.weight'],
+                              P[a + '.to_out.0.weight'], P[a + '.to_out.0.bias'], batch, *self._drop('attention'))
+        x = o.conv_block(x, P[f'{pre}.norm3.weight'], P[f'{pre}.norm3.bias'], P[c + '.pointwise_conv1.weight'], P[c + '.pointwise_conv1.bias'],
+                         P[c + '.depthwise_conv.weight'], P[c + '.depthwise_conv.bias'], P[c + '.norm.weight'], P[c + '.norm.bias'],
+                         P[c + '.norm.running_mean'], P[c + '.norm.running_var'], P[c + '.pointwise_conv2.weight'], P[c + '.pointwise_conv2.bias'],
+                         batch, *self._drop('conv'))
+        with torch.no_grad():
+            P[c + '.norm.num_batches_tracked'].add_(1)
         x = self._ffn_block(x, pre, 4, '.ffn2')
         return ln(x, 5)
 

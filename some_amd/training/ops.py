@@ -52,6 +52,7 @@ class TrainOps:
         self.ffn16 = os.environ.get('SOME_AMD_TRAIN_FFN16', '1') != '0'
         self.weights_version = 0
         self._shadows: Dict[int, tuple] = {}
+        self._joined: Dict[tuple, tuple] = {}
 
     def set_mixed_precision(self, on: bool, operand: str = 'f16'):
         """Mixed-precision training (the reference's pl_trainer_precision '16-mixed' / 'bf16'): the matrix products read one
@@ -115,8 +116,8 @@ class TrainOps:
         hit = self._shadows.get(key)
         if hit is not None and hit[0] == (self.weights_version, self._hi_mode, w.data_ptr()):
             return hit[1], hit[2]
-        N, K = w.shape
-        if hit is not None and hit[1].dtype == self.dtype16 and hit[1].shape == w.shape:
+        N, K = w.shape[0], w[0].numel()                                  # k = 1 Conv1d weights are [N, K, 1]
+        if hit is not None and hit[1].dtype == self.dtype16 and hit[1].shape == (N, K):
             w16, w16t = hit[1], hit[2]                                   # refreshed in place: same buffers every step
         else:
             w16 = torch.empty((N, K), dtype=self.dtype16, device=self.device)
@@ -140,8 +141,42 @@ class TrainOps:
         need = int(self.lib.some_train_gemm16_bytes(self.h, N, K, M, K + 4))
         if self._partial is None or self._partial.numel() < need:
             self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
-        self.check(self.lib.some_train_gemm16_wgrad16(self.h, _p(dy16), N, _p(x16), K, _p(dw), _p(db), N, K, M, self._hi_mode, int(accumulate),
+        self.check(self.lib.some_train_gemm16_wgrad16(self.h, _p(dy16), dy16.stride(0), _p(x16), x16.stride(0), _p(dw), _p(db), N, K, M, self._hi_mode, int(accumulate),
                                                       _p(self._partial), self._partial.numel(), self.stream()))
+
+    def silu16(self, x: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(x.shape, dtype=self.dtype16, device=self.device)
+        self.check(self.lib.some_train_silu16(self.h, _p(x), _p(out), x.numel(), self._hi_mode, self.stream()))
+        return out
+
+    def dropcast16(self, d: torch.Tensor, alpha: float, p: float, seed: int) -> torch.Tensor:
+        """rn16(alpha * mask / (1 - p) * d): the gradient through ``alpha * dropout(y) + x`` (gemm16s epilogue 3) w.r.t. y."""
+        M, N = d.shape
+        out = torch.empty((M, N), dtype=self.dtype16, device=self.device)
+        self.check(self.lib.some_train_dropcast16(self.h, _p(d), _p(out), M, N, float(alpha), float(p), seed, self._hi_mode, self.stream()))
+        return out
+
+    def joined(self, a: torch.Tensor, b: torch.Tensor):
+        """(weights, gradient sink) of two parameters that lie back to back in the flat buffers - to_q | to_kv of an attention module - as ONE
+        [Na + Nb, K] matrix, or None when they are not adjacent / have no sinks."""
+        key = (id(a), id(b))
+        hit = self._joined.get(key)
+        if hit is None:
+            sa, sb = self.sink(a), self.sink(b)
+            ok = (sa is not None and sb is not None and a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1] and a.is_contiguous() and b.is_contiguous()
+                  and b.data_ptr() == a.data_ptr() + a.numel() * 4 and sb.data_ptr() == sa.data_ptr() + sa.numel() * 4)
+            if ok:
+                shape, stride = (a.shape[0] + b.shape[0], a.shape[1]), (a.shape[1], 1)
+                hit = (torch.as_strided(a.detach(), shape, stride), torch.as_strided(sa, shape, stride), a, b)
+            else:
+                hit = (None, None, a, b)
+            self._joined[key] = hit
+        return hit[0], hit[1]
+
+    def can_block16(self, x: torch.Tensor, params) -> bool:
+        """The fused attention / conv sub-blocks need mixed precision, 512 channels and every Linear / LayerNorm parameter's gradient sink."""
+        return (self.ffn16 and self._hi_mode in (1, 2) and self.gemm16 and x.shape[0] >= 64 and x.shape[1] == 512 and 4 * x.shape[0] * 2048 < 0x7fffffff
+                and all(self.sink(q) is not None for q in params))
 
     def can_ffn16(self, M: int, K: int, H: int, N: int) -> bool:
         return (self.ffn16 and self._hi_mode in (1, 2) and self.gemm16 and M >= 64 and K % 32 == 0 and H % 32 == 0 and N % 32 == 0
@@ -351,6 +386,22 @@ class TrainOps:
             return self._apply(_FfnBlock16, x, gamma, beta, w1, b1, w2, b2, alpha, p_latent, seed_latent, p_out, seed_out)
         y = self.ffn(self.layernorm(x, gamma, beta), w1, b1, w2, b2, p_latent, seed_latent)
         return self.axpy_dropout(alpha, y, x, p_out, seed_out)
+
+    def attention_block(self, x, gamma, beta, wq, wkv, wo, bo, batch, p: float, seed: int):
+        """x + dropout(to_out(attention(to_q | to_kv of LayerNorm(x)))) - the attention sub-block of conform_blocke.forward (Gconform.py:58)."""
+        if self.can_block16(x, (gamma, beta, wq, wkv, wo, bo)) and self.joined(wq, wkv)[0] is not None:
+            return self._apply(_AttnBlock16, x, gamma, beta, wq, wkv, wo, bo, batch, p, seed)
+        n = self.layernorm(x, gamma, beta)
+        out = self.linear(self.attention(self.linear(n, self.cat_rows(wq, wkv)), batch), wo, bo)
+        return self.axpy_dropout(1.0, out, x, p, seed)
+
+    def conv_block(self, x, gamma, beta, pw1_w, pw1_b, dw_w, dw_b, bn_g, bn_b, bn_rm, bn_rv, pw2_w, pw2_b, batch, p: float, seed: int):
+        """x + dropout(conform_conv(LayerNorm(x))) - the conv sub-block (Gconform.py:59, modules/conv/base_conv.py:63-70)."""
+        if self.can_block16(x, (gamma, beta, pw1_w, pw1_b, pw2_w, pw2_b)):
+            return self._apply(_ConvBlock16, x, gamma, beta, pw1_w, pw1_b, dw_w, dw_b, bn_g, bn_b, bn_rm, bn_rv, pw2_w, pw2_b, batch, p, seed)
+        h = self.glu(self.linear(self.layernorm(x, gamma, beta), pw1_w, pw1_b))
+        h = self.batchnorm(self.dwconv(h, dw_w, dw_b, batch), bn_g, bn_b, bn_rm, bn_rv)
+        return self.axpy_dropout(1.0, self.linear(self.silu(h), pw2_w, pw2_b), x, p, seed)
 
     def layernorm(self, x, gamma, beta):
         return self._apply(_LayerNorm, x, gamma, beta)
@@ -650,6 +701,130 @@ class _FfnBlock16(torch.autograd.Function):
             ops.check(ops.lib.some_train_layernorm_bwd_add(ops.h, _p(dn), _p(x), _p(gamma_t), _p(mean), _p(rstd), _p(add), _p(dx), _p(dg), _p(dbeta), 0, M,
                                                            _p(sc), sc.numel(), ops.stream()))
         return None, dx, dg, dbeta, grads[0], grads[1], grads[2], grads[3], None, None, None, None, None
+
+
+def _sub(fn, *args):
+    """Run the body of another operator inside a fused one: (output, its context for the backward body)."""
+    c = _Ctx()
+    c.needs_input_grad = tuple(isinstance(a, torch.Tensor) for a in args)
+    return fn.forward(c, *args), c
+
+
+def _ln16(ops: TrainOps, x, gamma, beta):
+    M = x.shape[0]
+    n16 = torch.empty(x.shape, dtype=ops.dtype16, device=ops.device)
+    mean, rstd = ops.new(M), ops.new(M)
+    ops.check(ops.lib.some_train_layernorm_fwd16(ops.h, _p(x), _p(gamma), _p(beta), _p(n16), _p(mean), _p(rstd), M, ops._hi_mode, ops.stream()))
+    return n16, mean, rstd
+
+
+def _ln_bwd_add_into_sinks(ops: TrainOps, dn, x, gamma_t, mean, rstd, add, gamma, beta):
+    """dx = add + LayerNorm'(dn); dgamma / dbeta accumulate in the parameters' gradient arrays."""
+    M = x.shape[0]
+    dx = torch.empty_like(x)
+    sc = ops.scratch(M, 512)
+    ops.check(ops.lib.some_train_layernorm_bwd_add(ops.h, _p(dn), _p(x), _p(gamma_t), _p(mean), _p(rstd), _p(add), _p(dx), _p(ops.sink(gamma)),
+                                                   _p(ops.sink(beta)), 1, M, _p(sc), sc.numel(), ops.stream()))
+    ops.deposited(gamma)
+    ops.deposited(beta)
+    return dx
+
+
+def _wgrad16_into_sinks(ops: TrainOps, g16, in16, w, b):
+    ops.wgrad16(g16, in16, ops.sink(w), ops.sink(b) if b is not None else None, accumulate=True)
+    ops.deposited(w)
+    if b is not None:
+        ops.deposited(b)
+
+
+class _AttnBlock16(torch.autograd.Function):
+    """x + dropout(Wo attention(Wqkv LayerNorm(x)) + bo) in mixed precision (ops.can_block16: every parameter has a gradient sink):
+    LayerNorm writes the 16-bit GEMM operand, to_q | to_kv are one [1536, 512] matrix (adjacent in the flat buffer: no concatenation),
+    residual + dropout sit in the output projection's epilogue, their gradient and the 16-bit cast in one kernel, the residual gradient is
+    summed inside LayerNorm-backward; the attention core is the _Attention operator's own forward / backward."""
+
+    @staticmethod
+    def forward(ctx, ops: TrainOps, x, gamma, beta, wq, wkv, wo, bo, batch, p, seed):
+        x = x.contiguous()
+        M = x.shape[0]
+        wqkv, _ = ops.joined(wq, wkv)
+        n16, mean, rstd = _ln16(ops, x, gamma, beta)
+        qkv = ops.new(M, 1536)
+        ops.gemm16s(0, n16, ops.shadow16(wqkv)[0], None, qkv, 1536, M, 1536, 512)
+        att, actx = _sub(_Attention, ops, qkv, batch)
+        att16 = ops.cast16(att)
+        out = ops.new(M, 512)
+        ops.gemm16s(3, att16, ops.shadow16(wo)[0], bo, out, 512, M, 512, 512, h16=x, p=p, seed=seed, alpha=1.0)
+        ctx.ops, ctx.actx, ctx.drop = ops, actx, (p, seed)
+        ctx.save_for_backward(x, gamma, mean, rstd, n16, att16)
+        ctx.params = (gamma, beta, wq, wkv, wo, bo)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        ops: TrainOps = ctx.ops
+        x, gamma_t, mean, rstd, n16, att16 = ctx.saved_tensors
+        gamma, beta, wq, wkv, wo, bo = ctx.params
+        d = d.contiguous()
+        M = x.shape[0]
+        dy16 = ops.dropcast16(d, 1.0, *ctx.drop)
+        datt = ops.new(M, 512)
+        ops.gemm16s(0, dy16, ops.shadow16(wo)[1], None, datt, 512, M, 512, 512)
+        _wgrad16_into_sinks(ops, dy16, att16, wo, bo)
+        dqkv16 = ops.cast16(_Attention.backward(ctx.actx, datt)[1])
+        wqkv, gqkv = ops.joined(wq, wkv)
+        dn = ops.new(M, 512)
+        ops.gemm16s(0, dqkv16, ops.shadow16(wqkv)[1], None, dn, 512, M, 512, 1536)
+        ops.wgrad16(dqkv16, n16, gqkv, None, accumulate=True)
+        ops.deposited(wq)
+        ops.deposited(wkv)
+        dx = _ln_bwd_add_into_sinks(ops, dn, x, gamma_t, mean, rstd, d, gamma, beta)
+        return None, dx, None, None, None, None, None, None, None, None, None
+
+
+class _ConvBlock16(torch.autograd.Function):
+    """x + dropout(pw2 silu(BatchNorm(dwconv(GLU(pw1 LayerNorm(x)))))) in mixed precision: LayerNorm and SiLU write the 16-bit GEMM operands,
+    residual + dropout sit in pointwise_conv2's epilogue; GLU, the depthwise convolution and BatchNorm are their operators' own bodies."""
+
+    @staticmethod
+    def forward(ctx, ops: TrainOps, x, gamma, beta, pw1_w, pw1_b, dw_w, dw_b, bn_g, bn_b, bn_rm, bn_rv, pw2_w, pw2_b, batch, p, seed):
+        x = x.contiguous()
+        M = x.shape[0]
+        n16, mean, rstd = _ln16(ops, x, gamma, beta)
+        p1 = ops.new(M, 1024)
+        ops.gemm16s(0, n16, ops.shadow16(pw1_w)[0], pw1_b, p1, 1024, M, 1024, 512)
+        g, gctx = _sub(_Glu, ops, p1)
+        c, cctx = _sub(_DwConv, ops, g, dw_w, dw_b, batch)
+        bn, bctx = _sub(_BatchNorm, ops, c, bn_g, bn_b, bn_rm, bn_rv, 0.1, 1e-5)
+        s16 = ops.silu16(bn)
+        out = ops.new(M, 512)
+        ops.gemm16s(3, s16, ops.shadow16(pw2_w)[0], pw2_b, out, 512, M, 512, 512, h16=x, p=p, seed=seed, alpha=1.0)
+        ctx.ops, ctx.sub, ctx.drop = ops, (gctx, cctx, bctx), (p, seed)
+        ctx.save_for_backward(x, gamma, mean, rstd, n16, bn, s16)
+        ctx.params = (gamma, beta, pw1_w, pw1_b, pw2_w, pw2_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        ops: TrainOps = ctx.ops
+        x, gamma_t, mean, rstd, n16, bn, s16 = ctx.saved_tensors
+        gamma, beta, pw1_w, pw1_b, pw2_w, pw2_b = ctx.params
+        gctx, cctx, bctx = ctx.sub
+        d = d.contiguous()
+        M = x.shape[0]
+        dy16 = ops.dropcast16(d, 1.0, *ctx.drop)
+        ds = ops.new(M, 512)
+        ops.gemm16s(0, dy16, ops.shadow16(pw2_w)[1], None, ds, 512, M, 512, 512)
+        _wgrad16_into_sinks(ops, dy16, s16, pw2_w, pw2_b)
+        dbn = ops.eltwise(_lib.ELT_SILU_BWD, ds, bn)
+        _, dc, dbn_g, dbn_b = _BatchNorm.backward(bctx, dbn)[:4]
+        _, dg, ddw_w, ddw_b = _DwConv.backward(cctx, dc)[:4]
+        dp1_16 = ops.cast16(_Glu.backward(gctx, dg)[1])
+        dn = ops.new(M, 512)
+        ops.gemm16s(0, dp1_16, ops.shadow16(pw1_w)[1], None, dn, 512, M, 512, 1024)
+        _wgrad16_into_sinks(ops, dp1_16, n16, pw1_w, pw1_b)
+        dx = _ln_bwd_add_into_sinks(ops, dn, x, gamma_t, mean, rstd, d, gamma, beta)
+        return None, dx, None, None, None, None, ddw_w, ddw_b, dbn_g, dbn_b, None, None, None, None, None, None, None
 
 
 class _LayerNorm(torch.autograd.Function):

@@ -219,3 +219,91 @@ def test_ffn_block_output_dropout_and_its_gradient(ops):
         assert float((leaves[0].grad - d).sum(1).abs().max()) < 1e-3 * float((leaves[0].grad - d).abs().sum(1).max())
     finally:
         ops.set_mixed_precision(False)
+
+
+def _flat_params(ops, shapes, seed):
+    """Parameters laid out back to back in ONE buffer with a gradient buffer beside it, registered as gradient sinks (what FlatParams gives
+    the trainer): returns (dict of leaf views, flat gradient)."""
+    n = sum(int(np.prod(s)) for _, s, _ in shapes)
+    flat = torch.empty(n, device='cuda')
+    grad = torch.zeros(n, device='cuda')
+    views, off = {}, 0
+    for i, (name, shape, scale) in enumerate(shapes):
+        k = int(np.prod(shape))
+        flat[off:off + k] = _rand(k, seed=seed + i, scale=scale) + (1.0 if name.endswith('gamma') else 0.0)
+        v = flat[off:off + k].view(shape).requires_grad_()
+        v.grad = grad[off:off + k].view(shape)
+        views[name] = v
+        off += k
+    ops.register_grad_sinks(views.values())
+    return views, grad
+
+
+def _clone_leaves(views):
+    return {k: v.detach().clone().requires_grad_() for k, v in views.items()}
+
+
+def test_attention_block_equals_the_unfused_composition(ops):
+    from some_amd.engine import ClipBatch
+    lens = [300, 257, 64]
+    batch, M = ClipBatch(lens, 'cuda'), sum(lens)
+    ops.set_mixed_precision(True, 'bf16')
+    try:
+        P, grad = _flat_params(ops, [('gamma', (512,), 0.1), ('beta', (512,), 0.1), ('wq', (512, 512), 512 ** -0.5), ('wkv', (1024, 512), 512 ** -0.5),
+                                     ('wo', (512, 512), 512 ** -0.5), ('bo', (512,), 0.3)], seed=60)
+        x, d = _rand(M, 512, seed=70), _rand(M, 512, seed=71)
+        ops.weights_version += 1
+        xf = x.clone().requires_grad_()
+        y = ops.attention_block(xf, P['gamma'], P['beta'], P['wq'], P['wkv'], P['wo'], P['bo'], batch, 0.0, 0)
+        assert type(y.grad_fn).__name__.startswith('_AttnBlock16')
+        y.backward(d)
+        ops.register_grad_sinks([])                                   # no sinks: attention_block falls back to the composition
+        Q = _clone_leaves(P)
+        xu = x.clone().requires_grad_()
+        yu = ops.attention_block(xu, Q['gamma'], Q['beta'], Q['wq'], Q['wkv'], Q['wo'], Q['bo'], batch, 0.0, 0)
+        assert not type(yu.grad_fn).__name__.startswith('_AttnBlock16')
+        yu.backward(d)
+        assert float((y.detach() - yu.detach()).abs().max()) <= 1e-5 * float(yu.detach().abs().max())
+        assert float((xf.grad - xu.grad).abs().max()) <= 1e-5 * float(xu.grad.abs().max())
+        for k in P:
+            # the fused path sums the STORED 16-bit gradient for a Linear's bias, the unfused one the fp32 gradient: 2^-9 per element
+            tol = 5e-3 if k == 'bo' else 1e-5
+            assert float((P[k].grad - Q[k].grad).abs().max()) <= tol * float(Q[k].grad.abs().max()), k
+    finally:
+        ops.register_grad_sinks([])
+        ops.set_mixed_precision(False)
+
+
+def test_conv_block_equals_the_unfused_composition(ops):
+    from some_amd.engine import ClipBatch
+    lens = [300, 257, 64]
+    batch, M = ClipBatch(lens, 'cuda'), sum(lens)
+    ops.set_mixed_precision(True, 'bf16')
+    try:
+        P, grad = _flat_params(ops, [('gamma', (512,), 0.1), ('beta', (512,), 0.1), ('pw1_w', (1024, 512, 1), 512 ** -0.5), ('pw1_b', (1024,), 0.3),
+                                     ('dw_w', (512, 1, 31), 0.2), ('dw_b', (512,), 0.1), ('bn_gamma', (512,), 0.1), ('bn_b', (512,), 0.1),
+                                     ('pw2_w', (512, 512, 1), 512 ** -0.5), ('pw2_b', (512,), 0.3)], seed=80)
+        x, d = _rand(M, 512, seed=90), _rand(M, 512, seed=91)
+        order = ('gamma', 'beta', 'pw1_w', 'pw1_b', 'dw_w', 'dw_b', 'bn_gamma', 'bn_b')
+        outs = []
+        for fused in (True, False):
+            if not fused:
+                ops.register_grad_sinks([])
+            R = P if fused else _clone_leaves(P)
+            rm, rv = torch.zeros(512, device='cuda'), torch.ones(512, device='cuda')
+            ops.weights_version += 1
+            xx = x.clone().requires_grad_()
+            y = ops.conv_block(xx, *[R[k] for k in order], rm, rv, R['pw2_w'], R['pw2_b'], batch, 0.0, 0)
+            assert type(y.grad_fn).__name__.startswith('_ConvBlock16') == fused
+            y.backward(d)
+            outs.append((y.detach(), xx.grad, {k: R[k].grad.clone() for k in R}, rm, rv))
+        (y0, dx0, g0, rm0, rv0), (y1, dx1, g1, rm1, rv1) = outs
+        assert float((y0 - y1).abs().max()) <= 1e-5 * float(y1.abs().max())
+        assert float((dx0 - dx1).abs().max()) <= 1e-5 * float(dx1.abs().max())
+        assert torch.equal(rm0, rm1) and torch.equal(rv0, rv1)
+        for k in g0:
+            tol = 5e-3 if k in ('pw1_b', 'pw2_b') else 2e-5         # bias gradients: sums of the stored 16-bit gradient vs of the fp32 one
+            assert float((g0[k] - g1[k]).abs().max()) <= tol * float(g1[k].abs().max()) + 1e-7, k
+    finally:
+        ops.register_grad_sinks([])
+        ops.set_mixed_precision(False)
