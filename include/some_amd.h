@@ -256,6 +256,9 @@ int some_train_cast16(SomeHandle* h, const float* x_dev, void* y16_dev, int64_t 
 /* y16[i] = rn16(silu(x[i])): conform_conv's activation (modules/conv/base_conv.py:68) as the 16-bit operand of pointwise_conv2; n % 8 == 0. */
 int some_train_silu16(SomeHandle* h, const float* x_dev, void* y16_dev, int64_t n, int32_t operand, void* stream);
 int some_train_transpose16(SomeHandle* h, const float* w_dev, void* w16_dev, void* w16t_dev, int32_t N, int32_t K, int32_t operand, void* stream);
+/* The same for n weights in ONE launch: table_dev holds five int64 per weight - the device addresses of W, W16, W16T (either image may be
+ * 0) and N, K; max_n / max_k bound the table's N / K.  What the trainer runs once per optimiser step for all 16-bit weight images. */
+int some_train_transpose16_table(SomeHandle* h, const int64_t* table_dev, int32_t n, int32_t max_n, int32_t max_k, int32_t operand, void* stream);
 /* C[M, N] = A16[M, K] B16[N, K]^T, fp32 accumulation, both operands contraction-contiguous 16-bit arrays (K % 32 == 0, lda % 8 ==
  * ldb % 8 == 0, 16-byte aligned) moved global -> LDS by DMA.  epilogue:
  *   0  C fp32 [M, ldc] = acc (+ bias_dev[N] if not NULL)                                 nn.Linear forward / data gradient (B16 = W16T)

@@ -79,6 +79,7 @@ SYMBOLS = {
     'some_train_cast16': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
     'some_train_silu16': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
     'some_train_transpose16': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    'some_train_transpose16_table': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     'some_train_gemm16s': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_float, _P]),
     'some_train_dropcast16': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_uint64, C.c_int32, _P]),

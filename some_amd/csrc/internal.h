@@ -74,6 +74,7 @@ hipError_t launch_dropcast16(const float* d, void* y16, int M, int N, float alph
 hipError_t launch_cast16(const float* x, void* y16, int64_t n, int bf16, hipStream_t s);
 hipError_t launch_silu16(const float* x, void* y16, int64_t n, int bf16, hipStream_t s);
 hipError_t launch_transpose16(const float* w, void* w16, void* w16t, int N, int K, int bf16, hipStream_t s);
+hipError_t launch_transpose16_table(const int64_t* table_dev, int n, int max_n, int max_k, int bf16, hipStream_t s);
 
 // ---- row ops --------------------------------------------------------------------------------------
 // y[g][m][:] = LayerNorm(x[g][m][:]) * gamma[g] + beta[g], eps 1e-5, rows of 512.

@@ -159,6 +159,15 @@ int some_train_transpose16(SomeHandle* h, const float* w_dev, void* w16_dev, voi
     return SOME_OK;
 }
 
+int some_train_transpose16_table(SomeHandle* h, const int64_t* table_dev, int32_t n, int32_t max_n, int32_t max_k, int32_t operand, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, n >= 0 && (n == 0 || (table_dev && max_n > 0 && max_k > 0)), "some_train_transpose16_table: bad argument");
+    T_CHECK(h, n <= 65535, "some_train_transpose16_table: at most 65535 weights per call");
+    T_CHECK(h, operand == 1 || operand == 2, "some_train_transpose16_table: operand must be 1 (f16) or 2 (bf16)");
+    T_TRY(h, launch_transpose16_table(table_dev, n, max_n, max_k, operand == 2, st(stream)));
+    return SOME_OK;
+}
+
 int some_train_gemm16s(SomeHandle* h, int32_t epilogue, const void* A16_dev, int32_t lda, const void* B16_dev, int32_t ldb, const float* bias_dev,
                        void* C_dev, int32_t ldc, const void* H16_dev, int32_t ldh, int64_t plane_elems, int32_t M, int32_t N, int32_t K,
                        int32_t operand, float p, uint64_t seed, float alpha, void* stream) {

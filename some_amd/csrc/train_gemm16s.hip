@@ -391,11 +391,22 @@ __global__ __launch_bounds__(256) void dropcast16_kernel(const float* __restrict
     }
 }
 
-// W [N, K] fp32 -> W16 [N, K] and W16T [K, N]: 64 x 64 tiles through LDS (both outputs leave as 128-byte row segments)
+// W [N, K] fp32 -> W16 [N, K] and W16T [K, N]: 64 x 64 tiles through LDS (both outputs leave as 128-byte row segments).
+// `table` != null: blockIdx.z picks one of many weights from a descriptor table (five int64 per weight: source, W16, W16T addresses, N, K) -
+// all the model's 16-bit weight images in ONE launch per optimiser step instead of one launch per weight.
 template <bool BF16>
 __global__ __launch_bounds__(256) void transpose16_kernel(const float* __restrict__ w, uint16_t* __restrict__ w16, uint16_t* __restrict__ w16t,
-                                                           int N, int K) {
+                                                           int N, int K, const int64_t* __restrict__ table) {
     __shared__ uint16_t tile[64][66];
+    if (table != nullptr) {
+        const int64_t* e = table + (size_t)blockIdx.z * 5;
+        w = reinterpret_cast<const float*>(e[0]);
+        w16 = reinterpret_cast<uint16_t*>(e[1]);
+        w16t = reinterpret_cast<uint16_t*>(e[2]);
+        N = (int)e[3];
+        K = (int)e[4];
+        if ((int)blockIdx.y * 64 >= N || (int)blockIdx.x * 64 >= K) return;     // the grid covers the largest weight of the table
+    }
     const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
@@ -487,7 +498,15 @@ hipError_t launch_cast16(const float* x, void* y16, int64_t n, int bf16, hipStre
 hipError_t launch_transpose16(const float* w, void* w16, void* w16t, int N, int K, int bf16, hipStream_t s) {
     if (N <= 0 || K <= 0) return hipSuccess;
     const dim3 grid((unsigned)((K + 63) / 64), (unsigned)((N + 63) / 64));
-    if (bf16) hipLaunchKernelGGL(transpose16_kernel<true>, grid, dim3(256), 0, s, w, static_cast<uint16_t*>(w16), static_cast<uint16_t*>(w16t), N, K);
-    else hipLaunchKernelGGL(transpose16_kernel<false>, grid, dim3(256), 0, s, w, static_cast<uint16_t*>(w16), static_cast<uint16_t*>(w16t), N, K);
+    if (bf16) hipLaunchKernelGGL(transpose16_kernel<true>, grid, dim3(256), 0, s, w, static_cast<uint16_t*>(w16), static_cast<uint16_t*>(w16t), N, K, nullptr);
+    else hipLaunchKernelGGL(transpose16_kernel<false>, grid, dim3(256), 0, s, w, static_cast<uint16_t*>(w16), static_cast<uint16_t*>(w16t), N, K, nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose16_table(const int64_t* table_dev, int n, int max_n, int max_k, int bf16, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((max_k + 63) / 64), (unsigned)((max_n + 63) / 64), (unsigned)n);
+    if (bf16) hipLaunchKernelGGL(transpose16_kernel<true>, grid, dim3(256), 0, s, nullptr, nullptr, nullptr, 0, 0, table_dev);
+    else hipLaunchKernelGGL(transpose16_kernel<false>, grid, dim3(256), 0, s, nullptr, nullptr, nullptr, 0, 0, table_dev);
     return hipGetLastError();
 }

@@ -103,6 +103,7 @@ class TrainableMidiConforms:
         self.training = True
         self._seed = seed
         self._calls = 0
+        self._shadow_list = None
 
     # ---- dropout: one independent (seed, counter) stream per call site and step; fused into the neighbouring pass --------
     def _drop(self, kind: str):
@@ -113,6 +114,22 @@ class TrainableMidiConforms:
         return p, (self._seed * 1000003 + self._calls) * 4294967311 % (1 << 62)
 
     # ---- blocks (Gconform.py) ------------------------------------------------------------------------------------------
+    def _shadow_weights(self):
+        """The matrices the fused sub-blocks read as 16-bit images (ops.shadow16), in a fixed order - refreshed together once per pass."""
+        o, P = self.ops, self.params
+        if not (o.ffn16 and o._hi_mode in (1, 2)):
+            return []
+        if self._shadow_list is None:
+            ws = []
+            for pre in [f'model.cf_lay.{i}.{b}' for i in range(self.lay) for b in ('att1', 'att2')] + ['model.att1', 'model.att2']:
+                ws += [P[pre + '.ffn1.ln1.weight'], P[pre + '.ffn1.ln2.weight'], P[pre + '.ffn2.ln1.weight'], P[pre + '.ffn2.ln2.weight'],
+                       P[pre + '.att.to_out.0.weight'], P[pre + '.conv.pointwise_conv1.weight'], P[pre + '.conv.pointwise_conv2.weight']]
+                wqkv = o.joined(P[pre + '.att.to_q.weight'], P[pre + '.att.to_kv.weight'])[0]
+                if wqkv is not None:
+                    ws.append(wqkv)
+            self._shadow_list = ws
+        return self._shadow_list
+
     def _ffn_block(self, x, pre: str, i: int, name: str):
         """x = ffn(norm_i(x)) * 0.5 + x (Gconform.py:57,60), the FFN's output dropout included - one fused operator in mixed precision."""
         P, o = self.params, self.ops
@@ -142,6 +159,7 @@ class TrainableMidiConforms:
         """Gmidi_conform.forward (Gconform.py:119-140) + midi_conforms.forward(sig=False)."""
         P, o = self.params, self.ops
         o.weights_version += 1                     # the parameters may have moved since the last pass: 16-bit weight images are re-derived
+        o.prepare_shadows(self._shadow_weights())  # ... all of them in one launch (mixed precision only)
         units = units.reshape(-1, units.shape[-1]).contiguous()
         mask_u8 = None if mask is None else mask.reshape(-1).to(torch.uint8).contiguous()
         x = o.linear(units, P['model.inln.weight'], P['model.inln.bias'])

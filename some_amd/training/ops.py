@@ -53,6 +53,7 @@ class TrainOps:
         self.weights_version = 0
         self._shadows: Dict[int, tuple] = {}
         self._joined: Dict[tuple, tuple] = {}
+        self._shadow_tables: Dict[tuple, tuple] = {}
 
     def set_mixed_precision(self, on: bool, operand: str = 'f16'):
         """Mixed-precision training (the reference's pl_trainer_precision '16-mixed' / 'bf16'): the matrix products read one
@@ -125,6 +126,30 @@ class TrainOps:
         self.check(self.lib.some_train_transpose16(self.h, _p(w), _p(w16), _p(w16t), N, K, self._hi_mode, self.stream()))
         self._shadows[key] = ((self.weights_version, self._hi_mode, w.data_ptr()), w16, w16t, w)   # keeps ``w`` alive: id() stays unique
         return w16, w16t
+
+    def prepare_shadows(self, weights):
+        """Refresh the 16-bit images of ``weights`` (fp32 [N, K] or [N, K, 1] tensors whose storage does not move) in ONE launch
+        (some_train_transpose16_table) and mark them current for ``weights_version``."""
+        if not weights or self._hi_mode not in (1, 2):
+            return
+        key = (tuple(id(w) for w in weights), self._hi_mode)
+        hit = self._shadow_tables.get(key)
+        if hit is None or any(w.data_ptr() != q for w, q in zip(weights, hit[3])):
+            rows, max_n, max_k = [], 0, 0
+            for w in weights:
+                N, K = w.shape[0], w[0].numel()
+                w16 = torch.empty((N, K), dtype=self.dtype16, device=self.device)
+                w16t = torch.empty((K, N), dtype=self.dtype16, device=self.device)
+                self._shadows[id(w)] = [None, w16, w16t, w]
+                rows.append([w.data_ptr(), w16.data_ptr(), w16t.data_ptr(), N, K])
+                max_n, max_k = max(max_n, N), max(max_k, K)
+            hit = (torch.tensor(rows, dtype=torch.int64, device=self.device), max_n, max_k, [w.data_ptr() for w in weights])
+            self._shadow_tables = {key: hit}                                          # one model, one table
+        self.check(self.lib.some_train_transpose16_table(self.h, _p(hit[0]), len(weights), hit[1], hit[2], self._hi_mode, self.stream()))
+        stamp = (self.weights_version, self._hi_mode)
+        for w in weights:
+            e = self._shadows[id(w)]
+            self._shadows[id(w)] = ((stamp[0], stamp[1], w.data_ptr()), e[1], e[2], w)
 
     def gemm16s(self, epi: int, a16: torch.Tensor, b16: torch.Tensor, bias, out: torch.Tensor, ldc: int, M: int, N: int, K: int,
                 h16: Optional[torch.Tensor] = None, plane: int = 0, p: float = 0.0, seed: int = 0, alpha: float = 1.0):

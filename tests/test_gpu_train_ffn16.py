@@ -307,3 +307,27 @@ def test_conv_block_equals_the_unfused_composition(ops):
     finally:
         ops.register_grad_sinks([])
         ops.set_mixed_precision(False)
+
+
+@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+def test_weight_images_of_many_weights_in_one_launch(ops, operand):
+    """some_train_transpose16_table: W16 / W16T of weights of different shapes (a k = 1 Conv1d weight among them) from one launch equal
+    the fp32 -> 16-bit cast and its transpose; ops.shadow16 then serves them without another launch until weights_version moves."""
+    ops.set_mixed_precision(True, operand)
+    try:
+        ws = [_rand(2048, 512, seed=101), _rand(512, 2048, seed=102), _rand(1024, 512, 1, seed=103), _rand(96, 64, seed=104), _rand(1536, 512, seed=105)]
+        ops.weights_version += 1
+        ops.prepare_shadows(ws)
+        for w in ws:
+            w2 = w.reshape(w.shape[0], -1)
+            hit = ops._shadows[id(w)]
+            assert hit[0][0] == ops.weights_version
+            a, t = ops.shadow16(w)
+            assert a is hit[1] and t is hit[2]
+            assert torch.equal(a, w2.to(ops.dtype16)) and torch.equal(t, w2.to(ops.dtype16).t().contiguous())
+        ws[3].mul_(2.0)
+        ops.weights_version += 1
+        ops.prepare_shadows(ws)                                        # same table, refreshed contents
+        assert torch.equal(ops.shadow16(ws[3])[0], ws[3].to(ops.dtype16))
+    finally:
+        ops.set_mixed_precision(False)
