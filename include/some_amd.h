@@ -390,6 +390,14 @@ int some_train_attention_bwd_f16x3(SomeHandle* h, const float* qkv_split_dev, co
                                    const float* dout_dev, const float* lse_dev, const int32_t* frame_offsets_dev,
                                    int32_t B, int32_t max_frames, int32_t M, int32_t Mp, int32_t hi_only,
                                    float* dqkv_dev, float* dsum_scratch_dev, void* stream);
+/* The same with dq | dk | dv written as 16-bit values (the format of hi_only: 1 = f16, 2 = bf16) and multiplied by *out_scale_dev on the
+ * way out (a device scalar - the inverse of the power of two the caller multiplied dO with): the operand of the projection's data- and
+ * weight-gradient GEMMs (some_train_gemm16s / some_train_gemm16_wgrad16) without an fp32 array, a rescaling pass and a cast pass. */
+int some_train_attention_bwd_f16x3_out16(SomeHandle* h, const float* qkv_split_dev, const float* qkv_t_split_dev,
+                                         const float* dout_split_dev, const float* dout_t_split_dev, const float* out_dev,
+                                         const float* dout_dev, const float* lse_dev, const int32_t* frame_offsets_dev,
+                                         int32_t B, int32_t max_frames, int32_t M, int32_t Mp, int32_t hi_only,
+                                         void* dqkv16_dev, const float* out_scale_dev, float* dsum_scratch_dev, void* stream);
 
 /* ---- single-operator entry points (kernel-level parity tests and micro-benchmarks) ------------------ */
 

@@ -116,7 +116,8 @@ hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s);
 hipError_t launch_attention_dsum(const float* out, const float* dout, float* dsum, int M, hipStream_t s);
 // split-f16 backward (train_attention_f16x3.hip): R / D row-major SPLIT32, Rt / Dt SPLIT32 over frames ([C, Mp])
 hipError_t launch_attention_bwd_f16x3(const float* R, const float* Rt, const float* D, const float* Dt, const float* lse, const float* dsum,
-                                      const int32_t* frame_offsets, int B, int max_frames, int M, int Mp, float* dqkv, int hi_only, hipStream_t s);
+                                      const int32_t* frame_offsets, int B, int max_frames, int M, int Mp, float* dqkv, int hi_only, hipStream_t s,
+                                      void* dqkv16 = nullptr, const float* out_scale = nullptr, int out16 = 0);
 
 // split-f16 attention (attention_f16x3.hip): operands as written by the EPI_QKV GEMM epilogue; out is SPLIT32.
 struct Attn3Args {

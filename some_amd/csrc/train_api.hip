@@ -483,4 +483,23 @@ int some_train_attention_bwd_f16x3(SomeHandle* h, const float* qkv_split_dev, co
     return SOME_OK;
 }
 
+int some_train_attention_bwd_f16x3_out16(SomeHandle* h, const float* qkv_split_dev, const float* qkv_t_split_dev,
+                                         const float* dout_split_dev, const float* dout_t_split_dev, const float* out_dev,
+                                         const float* dout_dev, const float* lse_dev, const int32_t* frame_offsets_dev,
+                                         int32_t B, int32_t max_frames, int32_t M, int32_t Mp, int32_t hi_only,
+                                         void* dqkv16_dev, const float* out_scale_dev, float* dsum_scratch_dev, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, B >= 0 && max_frames >= 0 && M >= 0, "some_train_attention_bwd_f16x3_out16: negative size");
+    if (B == 0 || M == 0) return SOME_OK;
+    T_CHECK(h, hi_only == 1 || hi_only == 2, "some_train_attention_bwd_f16x3_out16: mixed precision only (hi_only 1 = f16, 2 = bf16: also the output format)");
+    T_CHECK(h, Mp >= M && (Mp % 32) == 0, "some_train_attention_bwd_f16x3_out16: Mp must be M rounded up to a multiple of 32");
+    T_CHECK(h, qkv_split_dev && qkv_t_split_dev && dout_split_dev && dout_t_split_dev && out_dev && dout_dev && lse_dev && frame_offsets_dev &&
+                   dqkv16_dev && out_scale_dev && dsum_scratch_dev, "some_train_attention_bwd_f16x3_out16: null pointer");
+    T_CHECK(h, (reinterpret_cast<uintptr_t>(dqkv16_dev) & 7) == 0, "some_train_attention_bwd_f16x3_out16: dqkv16 must be 8-byte aligned");
+    T_TRY(h, launch_attention_dsum(out_dev, dout_dev, dsum_scratch_dev, M, st(stream)));
+    T_TRY(h, launch_attention_bwd_f16x3(qkv_split_dev, qkv_t_split_dev, dout_split_dev, dout_t_split_dev, lse_dev, dsum_scratch_dev,
+                                        frame_offsets_dev, B, max_frames, M, Mp, nullptr, hi_only, st(stream), dqkv16_dev, out_scale_dev, hi_only));
+    return SOME_OK;
+}
+
 }  // extern "C"

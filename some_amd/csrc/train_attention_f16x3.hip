@@ -90,7 +90,28 @@ struct Bwd3Args {
     float* dqkv;           // [M, 1536] fp32
     const int32_t* frame_offsets;
     int B, max_frames, M, Mp;
+    // optional: dqkv leaves as 16-bit values (out16 = 1 f16, 2 bf16) scaled by *out_scale (a device scalar: the power of two the caller took
+    // into dO) - the operand of the projection's data / weight gradient GEMMs without an fp32 round trip (csrc/train_gemm16s.hip)
+    uint16_t* dqkv16;
+    const float* out_scale;
+    int out16;
 };
+
+typedef float bwd_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bwd_b2 __attribute__((ext_vector_type(2)));
+typedef uint32_t bwd_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bwd_pack16(float a, float b, int out16) {
+    const bwd_f2 v = {a, b};
+    return out16 == 2 ? __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bwd_b2)) : __builtin_bit_cast(uint32_t, __builtin_convertvector(v, half2_t));
+}
+__device__ __forceinline__ void bwd_store4(float* p32, uint16_t* p16, const f32x4& v, float os, int out16) {
+    if (out16) {
+        const bwd_u2 w = {bwd_pack16(v[0] * os, v[1] * os, out16), bwd_pack16(v[2] * os, v[3] * os, out16)};
+        *reinterpret_cast<bwd_u2*>(p16) = w;
+    } else {
+        *reinterpret_cast<f32x4*>(p32) = v;
+    }
+}
 
 // ---- dK, dV: a lane owns a key -----------------------------------------------------------------------------------------------
 constexpr int DKV_STAGE = 2 * FT * LDR + 2 * kHeadDim * LDT + 2 * FT;          // Qr, dOr, Qt, dOt, lse2[32], D[32]
@@ -234,8 +255,12 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dkv_kernel(Bwd3Args a, int n
     }
 
     if (kv) {
-        float* dKg = a.dqkv + (size_t)(f0 + key) * QKV_LD + kDim + head * kHeadDim;
+        const size_t koff = (size_t)(f0 + key) * QKV_LD + kDim + head * kHeadDim;
+        float* dKg = a.dqkv + koff;
         float* dVg = dKg + kDim;
+        uint16_t* dKh = a.dqkv16 + koff;
+        uint16_t* dVh = dKh + kDim;
+        const float os = a.out16 ? *a.out_scale : 1.f;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             const int d = 8 * r4 + 4 * kg;
@@ -245,10 +270,10 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dkv_kernel(Bwd3Args a, int n
                 k_lo[j] = dk0[r4 * 4 + j] * kScale; k_hi[j] = dk1[r4 * 4 + j] * kScale;
                 v_lo[j] = dv0[r4 * 4 + j] * kPUnshift; v_hi[j] = dv1[r4 * 4 + j] * kPUnshift;
             }
-            *reinterpret_cast<f32x4*>(dKg + d) = k_lo;
-            *reinterpret_cast<f32x4*>(dKg + 32 + d) = k_hi;
-            *reinterpret_cast<f32x4*>(dVg + d) = v_lo;
-            *reinterpret_cast<f32x4*>(dVg + 32 + d) = v_hi;
+            bwd_store4(dKg + d, dKh + d, k_lo, os, a.out16);
+            bwd_store4(dKg + 32 + d, dKh + 32 + d, k_hi, os, a.out16);
+            bwd_store4(dVg + d, dVh + d, v_lo, os, a.out16);
+            bwd_store4(dVg + 32 + d, dVh + 32 + d, v_hi, os, a.out16);
         }
     }
 }
@@ -374,13 +399,16 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dq_kernel(Bwd3Args a, int nq
         patch[l31 * LDR + 32 + d] = o1[r] * kScale;
     }
     __syncthreads();
-    float* __restrict__ og = a.dqkv + (size_t)f0 * QKV_LD + head * kHeadDim;
+    const size_t ooff = (size_t)f0 * QKV_LD + head * kHeadDim;
+    const float os = a.out16 ? *a.out_scale : 1.f;
     const int orow = lane >> 4, ocol = (lane & 15) * 4;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int qlr = orow + 4 * p;
         const int qq = q0 + wave * 32 + qlr;
-        if (qq < T) *reinterpret_cast<f32x4*>(og + (size_t)qq * QKV_LD + ocol) = *reinterpret_cast<const f32x4*>(patch + qlr * LDR + ocol);
+        if (qq < T)
+            bwd_store4(a.dqkv + ooff + (size_t)qq * QKV_LD + ocol, a.dqkv16 + ooff + (size_t)qq * QKV_LD + ocol,
+                       *reinterpret_cast<const f32x4*>(patch + qlr * LDR + ocol), os, a.out16);
     }
 }
 
@@ -404,8 +432,9 @@ static hipError_t launch_bwd(const Bwd3Args& a, hipStream_t s) {
 }
 
 hipError_t launch_attention_bwd_f16x3(const float* R, const float* Rt, const float* D, const float* Dt, const float* lse, const float* dsum,
-                                      const int32_t* frame_offsets, int B, int max_frames, int M, int Mp, float* dqkv, int hi_only, hipStream_t s) {
+                                      const int32_t* frame_offsets, int B, int max_frames, int M, int Mp, float* dqkv, int hi_only, hipStream_t s,
+                                      void* dqkv16, const float* out_scale, int out16) {
     if (B <= 0 || max_frames <= 0 || M <= 0) return hipSuccess;
-    Bwd3Args a{R, Rt, D, Dt, lse, dsum, dqkv, frame_offsets, B, max_frames, M, Mp};
+    Bwd3Args a{R, Rt, D, Dt, lse, dsum, dqkv, frame_offsets, B, max_frames, M, Mp, static_cast<uint16_t*>(dqkv16), out_scale, out16};
     return hi_only == 2 ? launch_bwd<2>(a, s) : hi_only ? launch_bwd<1>(a, s) : launch_bwd<3>(a, s);
 }

@@ -796,7 +796,7 @@ class _AttnBlock16(torch.autograd.Function):
         datt = ops.new(M, 512)
         ops.gemm16s(0, dy16, ops.shadow16(wo)[1], None, datt, 512, M, 512, 512)
         _wgrad16_into_sinks(ops, dy16, att16, wo, bo)
-        dqkv16 = ops.cast16(_Attention.backward(ctx.actx, datt)[1])
+        dqkv16 = _attention_bwd16(ctx.actx, datt) if ctx.actx.prec == 'f16x3' else ops.cast16(_Attention.backward(ctx.actx, datt)[1])
         wqkv, gqkv = ops.joined(wq, wkv)
         dn = ops.new(M, 512)
         ops.gemm16s(0, dqkv16, ops.shadow16(wqkv)[1], None, dn, 512, M, 512, 1536)
@@ -1112,6 +1112,24 @@ class _Attention(torch.autograd.Function):
             ops.check(ops.lib.some_train_attention_bwd(ops.h, _p(qkv), _p(out), _p(dout), _p(lse), _p(batch.frame_offsets_dev), batch.B,
                                                        batch.max_frames, M, _p(dqkv), _p(dsum), ops.stream()))
         return None, dqkv, None
+
+
+def _attention_bwd16(ctx, dout):
+    """_Attention.backward in mixed precision with dq | dk | dv written as the 16-bit GEMM operand by the kernels themselves (no fp32 array,
+    no rescaling pass, no cast pass): [M, 1536] 16-bit."""
+    ops, batch = ctx.ops, ctx.batch
+    dout = dout.contiguous()
+    M = dout.shape[0]
+    R, Rt, out, lse = ctx.saved_tensors
+    dqkv16, dsum = torch.empty((M, 1536), dtype=ops.dtype16, device=ops.device), ops.new(8, M)
+    scale = torch.exp2(torch.floor(10.0 - torch.log2(dout.abs().amax().clamp_min(1e-30))))     # as in _Attention.backward
+    dout = dout * scale
+    inv = torch.reciprocal(scale).reshape(1)
+    D, Dt = ops.split_rows(dout), ops.transpose(dout, pad_to=64, split=True)
+    ops.check(ops.lib.some_train_attention_bwd_f16x3_out16(ops.h, _p(R), _p(Rt), _p(D), _p(Dt), _p(out), _p(dout), _p(lse), _p(batch.frame_offsets_dev),
+                                                           batch.B, batch.max_frames, M, Rt.shape[1], ops._hi_mode, _p(dqkv16), _p(inv), _p(dsum),
+                                                           ops.stream()))
+    return dqkv16
 
 
 class _Bce(torch.autograd.Function):
