@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call 20: end state of the training path - kernel stats at 8 x 2584 (bf16), the epoch of BASELINE configs[4] at its own size
-O=gpurun_out/r03v; mkdir -p $O
+O=gpurun_out/r03y; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python tools/train_bench.py --mixed --operand bf16 --steps 5 --warmup 2 > $O/train_bench_under_rocprof.txt 2> $O/stats.log
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/train_bf16_kernel_stats.csv
