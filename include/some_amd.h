@@ -432,7 +432,10 @@ int some_op_attention(SomeHandle* h, const float* qkv_dev, const int32_t* frame_
                       int32_t max_frames, float* out_dev, int32_t out_split, void* stream);
 /* Split-f16 pair: QKV projection (h [M,512] SPLIT32 x Wqkv [1536,512] SPLIT32) writing Q | K SPLIT32 planes and V
  * transposed, followed by the split-f16 flash attention (attention_f16x3.hip); out [M,512] SPLIT32.
- * workspace: >= M*4096 + 2048 * roundup(M, 256) bytes. */
+ * Operands are laid out in clip-aligned rows (every clip's keys start a 64-key tile: a clip's result is bit-identical
+ * whatever else is in the batch - inference/base_infer.py:46-53 runs every chunk alone).
+ * workspace: >= some_op_qkv_attention_f16x3_bytes(M, B) bytes, 256-byte aligned. */
+size_t some_op_qkv_attention_f16x3_bytes(int32_t M, int32_t B);
 int some_op_qkv_attention_f16x3(SomeHandle* h, const float* h_split_dev, const float* wqkv_split_dev,
                                 const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, int32_t M,
                                 float* out_split_dev, void* workspace_dev, size_t workspace_bytes, void* stream);

@@ -114,6 +114,7 @@ SYMBOLS = {
     'some_op_split_rows_fmt': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     'some_op_layernorm': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     'some_op_attention': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
+    'some_op_qkv_attention_f16x3_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
     'some_op_qkv_attention_f16x3': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_size_t, _P]),
     'some_op_dwconv_silu': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     'some_profile_enable': (C.c_int, [_P, C.c_int32]),

@@ -57,7 +57,32 @@ bool split_blocks_f16c(float* blk, size_t n_blocks) {
 #else
 bool split_blocks_f16c(float*, size_t) { return false; }
 #endif
-constexpr size_t kWsSlack = 1 << 20;   // per stream: room for the V^T row padding (ldv - M < 256 frames x 2 KiB)
+constexpr size_t kWsSlack = 1 << 20;   // per stream: slack behind the last array
+
+// Workspace of some_forward: per model stream X [M,512] | H [M,512] | G [M,512] | U, then the attention plan (f16x3 mode).
+// U holds the FFN hidden rows [M,2048] and, in f16x3 mode, the attention operands in clip-aligned rows (Mc = attn_rows_cover):
+// Q | K SPLIT32 planes [Mc,512] and the V^T f16 planes 2 x [512, vt_ld(Mc)] - larger than the FFN rows only for batches of
+// very short clips.
+struct WsLayout {
+    size_t per_stream;     // floats
+    size_t plan_off;       // bytes: pad_offsets int32 [B + 1], then row_map int32 [Mc]
+    size_t map_off;        // bytes
+    size_t total;          // bytes
+    int64_t Mc;
+};
+WsLayout ws_layout(int precision, int64_t total_frames, int32_t B) {
+    WsLayout w{};
+    const size_t m = (size_t)total_frames;
+    w.Mc = attn_rows_cover(total_frames, B);
+    size_t u_bytes = m * (size_t)kFfn * sizeof(float);
+    if (precision == SOME_PRECISION_F16X3)
+        u_bytes = std::max(u_bytes, (size_t)w.Mc * 2 * kDim * sizeof(float) + (size_t)2 * kDim * vt_ld(w.Mc) * 2);
+    w.per_stream = (align_up(m * (size_t)(kDim * 3) * sizeof(float) + u_bytes, 256) + kWsSlack) / sizeof(float);
+    w.plan_off = kStreams * w.per_stream * sizeof(float);
+    w.map_off = w.plan_off + align_up(((size_t)B + 1) * 4, 256);
+    w.total = w.map_off + align_up((size_t)w.Mc * 4, 256) + 1024;
+    return w;
+}
 
 // ---- arena layout ------------------------------------------------------------------------------------
 struct Cursor {
@@ -500,11 +525,8 @@ int some_pcm_gather(SomeHandle* h, const void* src_dev, int32_t sample_format, c
 }
 
 size_t some_workspace_bytes(const SomeHandle* h, int64_t total_frames, int32_t B) {
-    (void)B;
     if (!h || total_frames <= 0) return 0;
-    const size_t m = (size_t)total_frames;
-    // per stream: X 512 | H 512 | U 2048 | G 512 floats per frame
-    return kStreams * (align_up(m * (size_t)(kDim * 3 + kFfn) * sizeof(float), 256) + kWsSlack) + 1024;
+    return ws_layout(h->precision, total_frames, B < 0 ? 0 : B).total;
 }
 
 int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_offsets_dev, int32_t B,
@@ -528,8 +550,12 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = (int)total_frames;
     const size_t m = (size_t)M;
-    const size_t per_stream = (align_up(m * (size_t)(kDim * 3 + kFfn) * sizeof(float), 256) + kWsSlack) / sizeof(float);
+    const WsLayout wl = ws_layout(h->precision, total_frames, B);
+    const size_t per_stream = wl.per_stream;
     float* ws = static_cast<float*>(workspace_dev);
+    int32_t* pad_off = reinterpret_cast<int32_t*>(static_cast<char*>(workspace_dev) + wl.plan_off);
+    int32_t* row_map = reinterpret_cast<int32_t*>(static_cast<char*>(workspace_dev) + wl.map_off);
+    const int Mc = (int)wl.Mc;
     float *X[2], *H[2], *U[2], *G[2];
     for (int g = 0; g < kStreams; ++g) {
         float* base = ws + g * per_stream;
@@ -554,8 +580,8 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
     };
     // Every launch covers the model streams [g0, g0 + ng) as blockIdx.y groups: both (grouped, one HIP stream), or one
     // model stream per HIP stream (dual-stream mode below).
-    auto gemm = [&](const char* name, GemmEpi epi, GemmArgs& a, int ng, int n_out, hipStream_t st, bool out_split = false) -> int {
-        a.groups = ng; a.M = M; a.flags = h->gemm_flags;
+    auto gemm = [&](const char* name, GemmEpi epi, GemmArgs& a, int ng, int n_out, hipStream_t st, bool out_split = false, int rows = -1) -> int {
+        a.groups = ng; a.M = rows < 0 ? M : rows; a.flags = h->gemm_flags;
         const double flops = 2.0 * Md * a.K * n_out * ng;
         Scope sc(h, st, name, flops, 0.0);
         hipError_t e = f16x3 ? launch_gemm_f16x3(epi, a, out_split, pick_tile(n_out, ng), st) : launch_gemm(epi, a, st);
@@ -604,21 +630,22 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
         if ((rc = ffn(layer, 0, g0, ng, st))) return rc;
         if ((rc = ln(layer, 1, g0, ng, st, X, H))) return rc;
         if (f16x3) {
-            // QKV projection writes Q | K as SPLIT32 planes and V transposed; split-f16 attention consumes them
-            const int ldv = vt_ld(M);
+            // QKV projection writes Q | K as SPLIT32 planes and V transposed, all in clip-aligned rows (row gather through the
+            // attention plan: a clip's key tiles start at its own first frame); split-f16 attention consumes them
+            const int ldv = vt_ld(Mc);
             GemmArgs a{};
             Attn3Args t{};
             for (int gi = 0; gi < ng; ++gi) {
                 const int g = g0 + gi;
                 float* qp = U[g];
-                float* kp = U[g] + m * kDim;
-                void* vt = U[g] + 2 * m * kDim;
+                float* kp = U[g] + (size_t)Mc * kDim;
+                void* vt = U[g] + 2 * (size_t)Mc * kDim;
                 a.g[gi] = GemmGroup{H[g], W + L.blocks[(size_t)layer * 2 + g].wqkv, nullptr, nullptr, qp, nullptr, 3 * kDim, 0, kp, vt, ldv};
                 t.q[gi] = qp; t.k[gi] = kp; t.vt[gi] = vt; t.out[gi] = H[g];
             }
-            a.K = kDim; a.lda = kDim; a.ldc = kDim;
-            if ((rc = gemm("gemm[512->1536 qkv]", EPI_QKV, a, ng, 3 * kDim, st))) return rc;
-            t.frame_offsets = frame_offsets_dev; t.groups = ng; t.B = B; t.max_frames = max_frames; t.M = M; t.ldv = ldv;
+            a.K = kDim; a.lda = kDim; a.ldc = kDim; a.row_map = row_map; a.a_rows = M;
+            if ((rc = gemm("gemm[512->1536 qkv]", EPI_QKV, a, ng, 3 * kDim, st, false, Mc))) return rc;
+            t.frame_offsets = frame_offsets_dev; t.pad_offsets = pad_off; t.groups = ng; t.B = B; t.max_frames = max_frames; t.M = Mc; t.ldv = ldv;
             Scope sc(h, st, "attention", 4.0 * kHeadDim * kHeads * ng * sumT2, 0.0);
             HIP_TRY(h, launch_attention_f16x3(t, st));
         } else {
@@ -714,6 +741,10 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
     hipStream_t s2 = dual ? aux->aux : s;
 
     int rc;
+    if (f16x3) {    // clip-aligned attention coordinates, once per call (18 attention launches read them)
+        Scope sc(h, s, "attn_plan", 0.0, 0.0);
+        HIP_TRY(h, launch_attn_plan(frame_offsets_dev, B, Mc, pad_off, row_map, s));
+    }
     {   // Gconform.py:124-127: the two input projections (+ masked_fill on the midi stream)
         GemmArgs a{};
         for (int g = 0; g < kStreams; ++g)
@@ -873,26 +904,40 @@ int some_op_attention(SomeHandle* h, const float* qkv_dev, const int32_t* frame_
     return SOME_OK;
 }
 
+size_t some_op_qkv_attention_f16x3_bytes(int32_t M, int32_t B) {
+    if (M <= 0 || B < 0) return 0;
+    const int64_t Mc = attn_rows_cover(M, B);
+    return align_up((size_t)Mc * kDim * 4 * 2 + (size_t)2 * kDim * vt_ld(Mc) * 2, 256) + align_up(((size_t)B + 1) * 4, 256) +
+           align_up((size_t)Mc * 4, 256);
+}
+
 int some_op_qkv_attention_f16x3(SomeHandle* h, const float* h_split_dev, const float* wqkv_split_dev,
                                 const int32_t* frame_offsets_dev, int32_t B, int32_t max_frames, int32_t M,
                                 float* out_split_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
     if (!h) return SOME_EINVAL;
     if (B < 0 || M < 0 || !h_split_dev || !wqkv_split_dev || !frame_offsets_dev || !out_split_dev || !workspace_dev)
         return fail(h, SOME_EINVAL, "some_op_qkv_attention_f16x3: bad argument");
-    const int ldv = vt_ld(M);
-    const size_t need = (size_t)M * kDim * 4 * 2 + (size_t)2 * kDim * ldv * 2;
-    if (workspace_bytes < need) return fail(h, SOME_ENOMEM, "some_op_qkv_attention_f16x3: workspace too small");
+    if (B == 0 || M == 0) return SOME_OK;
+    const int Mc = (int)attn_rows_cover(M, B);
+    const int ldv = vt_ld(Mc);
+    const size_t plan_off = align_up((size_t)Mc * kDim * 4 * 2 + (size_t)2 * kDim * ldv * 2, 256);
+    const size_t map_off = plan_off + align_up(((size_t)B + 1) * 4, 256);
+    if (workspace_bytes < some_op_qkv_attention_f16x3_bytes(M, B)) return fail(h, SOME_ENOMEM, "some_op_qkv_attention_f16x3: workspace too small");
+    if (reinterpret_cast<uintptr_t>(workspace_dev) & 255) return fail(h, SOME_EINVAL, "some_op_qkv_attention_f16x3: workspace must be 256-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* qp = static_cast<float*>(workspace_dev);
-    float* kp = qp + (size_t)M * kDim;
-    void* vt = kp + (size_t)M * kDim;
+    float* kp = qp + (size_t)Mc * kDim;
+    void* vt = kp + (size_t)Mc * kDim;
+    int32_t* pad_off = reinterpret_cast<int32_t*>(static_cast<char*>(workspace_dev) + plan_off);
+    int32_t* row_map = reinterpret_cast<int32_t*>(static_cast<char*>(workspace_dev) + map_off);
+    HIP_TRY(h, launch_attn_plan(frame_offsets_dev, B, Mc, pad_off, row_map, s));
     GemmArgs a{};
     a.g[0] = GemmGroup{h_split_dev, wqkv_split_dev, nullptr, nullptr, qp, nullptr, 3 * kDim, 0, kp, vt, ldv};
-    a.groups = 1; a.M = M; a.K = kDim; a.lda = kDim; a.ldc = kDim;
+    a.groups = 1; a.M = Mc; a.K = kDim; a.lda = kDim; a.ldc = kDim; a.row_map = row_map; a.a_rows = M;
     HIP_TRY(h, launch_gemm_f16x3(EPI_QKV, a, false, h->tile >= 0 ? h->tile : 0, s));
     Attn3Args t{};
     t.q[0] = qp; t.k[0] = kp; t.vt[0] = vt; t.out[0] = out_split_dev;
-    t.frame_offsets = frame_offsets_dev; t.groups = 1; t.B = B; t.max_frames = max_frames; t.M = M; t.ldv = ldv;
+    t.frame_offsets = frame_offsets_dev; t.pad_offsets = pad_off; t.groups = 1; t.B = B; t.max_frames = max_frames; t.M = Mc; t.ldv = ldv;
     HIP_TRY(h, launch_attention_f16x3(t, s));
     return SOME_OK;
 }

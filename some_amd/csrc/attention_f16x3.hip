@@ -11,9 +11,14 @@
 //   Q, K : [M, 512] SPLIT32 rows (split.h) - a head's 64 dims are 256 contiguous bytes (2 k-blocks of hi|lo);
 //   V^T  : hi and lo f16 planes [512, ldv] with the FRAME index contiguous (every aligned group of 16 frames stored as
 //          its quarters 0, 2, 1, 3), so a (d, 8-key) operand fragment is ONE ds_read_b128 and no transposition happens here.
-// Key tiles are aligned in GLOBAL frame coordinates (64 gt .. 64 gt + 63), which keeps every 16-byte V^T chunk
-// aligned however the clips are packed; keys outside the clip get score -inf (their data is another clip's
-// finite values or the zero padding the GEMM wrote, so 0 * v stays 0).
+// Inference: Q / K rows and V^T columns lie in CLIP-ALIGNED coordinates - clip b starts at pad_offsets[b], a multiple of 16
+// (internal.h: launch_attn_plan; the QKV projection gathers its input rows accordingly) - and key tile i of a clip covers its
+// frames 64 i .. 64 i + 63: every 16-byte V^T chunk and every permuted group of 16 stays aligned however the clips are packed,
+// and the sequence of online-softmax steps a query sees depends on its clip alone, so a clip's result is bit-identical whatever
+// it is batched with (the reference runs every chunk by itself, inference/base_infer.py:46-53).  Training forward
+// (pad_offsets = nullptr): operands in packed coordinates, key tiles aligned in GLOBAL 64-frame blocks.
+// Keys outside the clip get score -inf (their data is another clip's finite values or the zero rows the GEMM wrote, so
+// 0 * v stays 0).
 // The softmax scale 64^-0.5 * log2(e) is folded into the exp2 argument: p = exp2(fma(s, c, -m)).
 #include <cstdlib>
 
@@ -85,8 +90,9 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
     const int hg = unit % (kHeads * a.groups), b = unit / (kHeads * a.groups);
     if (b >= a.B) return;
     const int head = hg % kHeads, g = hg / kHeads;
-    const int f0 = a.frame_offsets[b];
-    const int T = a.frame_offsets[b + 1] - f0;
+    const int fo = a.frame_offsets[b];                               // output rows (packed coordinates)
+    const int T = a.frame_offsets[b + 1] - fo;
+    const int f0 = TRAIN ? fo : a.pad_offsets[b];                    // operand rows / V^T columns
     const int q0 = qb * QB;
     if (q0 >= T) return;
 
@@ -118,15 +124,16 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
 
     // ---- staging roles: a K tile is 64 rows x 16 chunks, a V^T tile 64 rows x (8 hi + 8 lo) chunks; 4 + 4 per thread
     const int srow = tid >> 4, sc = tid & 15;       // rows srow + 16 p, chunk sc
-    const int gt0 = f0 / KT, gt1 = (f0 + T - 1) / KT;
-    const int n = gt1 - gt0 + 1;                    // key tiles of this clip
+    // first key of tile 0: the clip's own first frame (clip-aligned operands) or the global 64-frame block it lies in
+    const int kt0 = TRAIN ? f0 / KT * KT : f0;
+    const int n = (f0 + T - kt0 + KT - 1) / KT;     // key tiles of this clip
     f32x4 rk[4], rv[4];
     // K rows through a buffer descriptor: keys >= M (the tail of the last global tile) lie past num_records and read as
     // zeros - no exec-masked branch in the loop
     const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(Kp), 0, (int)((size_t)a.M * ROW_B - head * 256 > 0x7fffffffull ? 0x7fffffffull : (size_t)a.M * ROW_B - head * 256), 0x00020000);
     auto gload_k = [&](int i) {
-        const int g0 = (gt0 + i) * KT;
+        const int g0 = kt0 + i * KT;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             rk[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsk, (uint32_t)(g0 + srow + 16 * p) * (uint32_t)ROW_B + sc * 16u, 0, 0));
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
     for (int p = 0; p < 4; ++p)
         voff_v[p] = (uint32_t)(srow + 16 * p) * (uint32_t)a.ldv * 2u + (uint32_t)(sc & 7) * 16u + (sc < 8 ? 0u : (uint32_t)kDim * (uint32_t)a.ldv * 2u);
     auto gload_v = [&](int i) {
-        const int g0 = (gt0 + i) * KT;
+        const int g0 = kt0 + i * KT;
         if constexpr (!TRAIN) {
 #pragma unroll
             for (int p = 0; p < 4; ++p)
@@ -191,8 +198,8 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
         }
     };
     auto mask_tile = [&](int i, f32x16& s0, f32x16& s1) {
-        const int gbase = (gt0 + i) * KT;
-        if (gbase < f0 || gbase + KT > f0 + T) {          // first and last global tile only
+        const int gbase = kt0 + i * KT;
+        if (gbase < f0 || gbase + KT > f0 + T) {          // last tile (and the first one of a clip inside a global block)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k0 = gbase + (r & 3) + 8 * (r >> 2) + 4 * kg;
@@ -370,12 +377,12 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
             if (q < T) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(patch + ql_ * LDR + ocol);
                 if (TRAIN) {
-                    *reinterpret_cast<f32x4*>(a.out32[g] + (size_t)(f0 + q) * kDim + head * kHeadDim + ocol) = v;
+                    *reinterpret_cast<f32x4*>(a.out32[g] + (size_t)(fo + q) * kDim + head * kHeadDim + ocol) = v;
                 } else {
                     half4 hh, ll;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { half_t h, l; split_f16(v[i], h, l); hh[i] = h; ll[i] = l; }
-                    char* row = reinterpret_cast<char*>(a.out[g]) + ((size_t)(f0 + q) * kDim + head * kHeadDim) * 4 +
+                    char* row = reinterpret_cast<char*>(a.out[g]) + ((size_t)(fo + q) * kDim + head * kHeadDim) * 4 +
                                 (ocol >> 5) * 128 + (ocol & 31) * 2;
                     *reinterpret_cast<half4*>(row) = hh;
                     *reinterpret_cast<half4*>(row + 64) = ll;
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
         }
         if (TRAIN && kg == 0) {       // P was carried as 2^kPShift p: lse2 = max + log2(sum p)
             const int q = q0 + wave * 32 + l31;
-            if (q < T) a.lse[g][(size_t)head * a.M + f0 + q] = m_run + __log2f(l_tot) - kPShift;
+            if (q < T) a.lse[g][(size_t)head * a.M + fo + q] = m_run + __log2f(l_tot) - kPShift;
         }
     }
 }
@@ -407,6 +414,7 @@ hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
         attr_set = true;
     }
     const bool inference = a.out32[0] == nullptr;
+    if (inference && a.pad_offsets == nullptr) return hipErrorInvalidValue;
     constexpr int QB = 128;
     const int nqb = (a.max_frames + QB - 1) / QB;
     const int units = a.B * kHeads * a.groups;

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     // k-iteration is ONE basic block and the scheduler interleaves the staging traffic with the MFMAs.
     constexpr int RPP = NT / 8;                          // rows per pass
     static_assert(BM % RPP == 0, "a pass must not straddle A and W");
-    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(g.A, (size_t)a.M * a.lda * 4);
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(g.A, (size_t)a.a_rows * a.lda * 4);
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(g.W, (size_t)g.N * a.K * 4);
     const int srow = tid >> 3, scol = tid & 7;
     uint32_t voff[NLD];
@@ -363,6 +363,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
         const int row = srow + p * RPP;
         voff[p] = row < BM ? (uint32_t)(m0 + row) * (uint32_t)a.lda * 4u + scol * 16u
                            : (uint32_t)(n0 + row - BM) * (uint32_t)a.K * 4u + scol * 16u;
+    }
+    if (a.row_map != nullptr) {      // row gather (QKV projection into clip-aligned rows): the offsets are fixed for the whole k-loop
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            const int row = srow + p * RPP;
+            if (row < BM) {
+                const int src = m0 + row < a.M ? a.row_map[m0 + row] : -1;
+                voff[p] = src >= 0 ? (uint32_t)src * (uint32_t)a.lda * 4u + scol * 16u : kOob;
+            }
+        }
     }
     const int dst0 = srow * LDT + scol * 4;
     f32x4 stage[NLD];
@@ -1149,6 +1159,7 @@ hipError_t launch_gemm_f16x1(GemmEpi epi, const GemmArgs& a_in, int tile, hipStr
     if ((a_in.K & 31) || (a_in.lda & 31)) return hipErrorInvalidValue;
     GemmArgs a = a_in;
     a.m_begin = 0;
+    if (a.a_rows <= 0) a.a_rows = a.M;
     const bool small = tile == 0;                     // 128 x 128 (two workgroups per CU) for small grids, else 256 x 256
     return bf16 ? launch_x1<true>(epi, a, small, s) : launch_x1<false>(epi, a, small, s);
 }
@@ -1191,6 +1202,8 @@ hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a_in, bool out_split, 
             if (a_in.g[g].N != 3 * kDim || !a_in.g[g].C2 || !a_in.g[g].C3 || (a_in.g[g].ldv & 255) || a_in.g[g].ldv < a_in.M) return hipErrorInvalidValue;
     GemmArgs a = a_in;
     a.m_begin = 0;
+    if (a.a_rows <= 0) a.a_rows = a.M;
+    if (a.row_map != nullptr && tile == 3) return hipErrorInvalidValue;      // the DMA-ring kernel has no row gather
     if (a.k_slices > 1) {
         if (epi != EPI_NONE || out_split || tile == 3) return hipErrorInvalidValue;
         return launch_one(epi, a, false, tile, s);

@@ -52,6 +52,10 @@ struct GemmArgs {
     int k_slices;          // split-K (f16x3, EPI_NONE): blockIdx.z = slice of the contraction; 0 / 1 = off
     size_t slice_stride;   // floats between the partial C planes of consecutive slices
     int flags;             // GEMM_FLAG_* (f16x3 path)
+    // f16x3 path, optional row gather: output row p reads A row row_map[p] (< 0: a row of zeros); M then counts OUTPUT rows and
+    // a_rows the rows of A.  The QKV projection uses it to write Q | K | V^T in clip-aligned coordinates (launch_attn_plan).
+    const int32_t* row_map;
+    int a_rows;            // rows of A (0: M)
 };
 constexpr int GEMM_FLAG_TR = 1;   // row-per-lane (transposed accumulator) epilogues where the epilogue has one (gemm_f16x3.hip)
 
@@ -127,6 +131,10 @@ struct Attn3Args {
     float* out[kStreams];          // [M, 512] SPLIT32
     const int32_t* frame_offsets;
     int groups, B, max_frames, M, ldv;
+    // inference: clip b's Q / K rows and V^T columns start at pad_offsets[b] (multiples of 16, launch_attn_plan) and its key tiles
+    // are counted from there - a clip's result does not depend on where it lies in the batch; M = rows of the Q / K planes.
+    // nullptr (training forward): operands in frame_offsets coordinates, key tiles aligned in global 64-frame blocks.
+    const int32_t* pad_offsets;
     // training forward (out32 != nullptr): q / k point into split_rows(qkv) (row stride 1536 floats), vt into the V rows of
     // transpose(qkv, split) ([.., ldv] SPLIT32 over frames, ldv % 64 == 0); fp32 output + base-2 log-sum-exp [8, M]
     float* out32[kStreams];
@@ -135,6 +143,16 @@ struct Attn3Args {
 };
 hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s);
 inline int vt_ld(int64_t M) { return (int)((M + 255) / 256 * 256); }
+// Clip-aligned attention coordinates (inference): clip b owns rows [pad_offsets[b], pad_offsets[b] + T_b) with
+// pad_offsets[b] = sum over earlier clips of roundup(T, 16).  attn_rows_cover bounds the row count from the host's side (the
+// offsets live on the device): M + 15 B rows of clips, + 63 so that the last key tile of the last clip stays inside, as a
+// multiple of 64.  launch_attn_plan fills pad_offsets [B + 1] and row_map [rows_cover] (source row or -1).
+#ifndef SOME_CLIP_ALIGN
+#define SOME_CLIP_ALIGN 16      // 16 = the permuted V^T group (gemm_f16x3.hip EPI_QKV); build variants: 32 / 64
+#endif
+constexpr int kClipAlign = SOME_CLIP_ALIGN;
+inline int64_t attn_rows_cover(int64_t M, int64_t B) { return (M + (kClipAlign - 1) * B + 63 + 63) / 64 * 64; }
+hipError_t launch_attn_plan(const int32_t* frame_offsets, int B, int rows_cover, int32_t* pad_offsets, int32_t* row_map, hipStream_t s);
 
 // ---- depthwise conv + folded BN + SiLU ------------------------------------------------------------
 struct DwArgs {

@@ -146,7 +146,56 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
 }
 
+// ---- clip-aligned attention coordinates (internal.h: launch_attn_plan) -------------------------------------------------
+// pad_offsets[b] = sum_{c < b} roundup(T_c, 16): one workgroup, each thread sums a run of clips, block scan over the run totals.
+__global__ __launch_bounds__(256) void attn_plan_scan_kernel(const int32_t* __restrict__ fo, int B, int32_t* __restrict__ pad) {
+    __shared__ int32_t part[256];
+    const int tid = threadIdx.x;
+    const int per = (B + 255) / 256;
+    const int b0 = min(B, tid * per), b1 = min(B, b0 + per);
+    int32_t sum = 0;
+    for (int b = b0; b < b1; ++b) sum += (fo[b + 1] - fo[b] + kClipAlign - 1) / kClipAlign * kClipAlign;
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {           // Hillis-Steele inclusive scan
+        const int32_t v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int32_t run = part[tid] - sum;                 // exclusive prefix of this thread's run
+    for (int b = b0; b < b1; ++b) {
+        pad[b] = run;
+        run += (fo[b + 1] - fo[b] + kClipAlign - 1) / kClipAlign * kClipAlign;
+    }
+    if (tid == 255) pad[B] = part[255];
+}
+// row_map[p] = the packed frame that padded row p holds, -1 for the alignment rows behind a clip and the tail
+__global__ __launch_bounds__(256) void attn_plan_map_kernel(const int32_t* __restrict__ fo, const int32_t* __restrict__ pad, int B, int rows,
+                                                            int32_t* __restrict__ row_map) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= rows) return;
+    int lo = 0, hi = B;                            // last b in [0, B] with pad[b] <= p (pad[0] = 0)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pad[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    int32_t src = -1;
+    if (lo < B) {
+        const int t = p - pad[lo];
+        if (t < fo[lo + 1] - fo[lo]) src = fo[lo] + t;
+    }
+    row_map[p] = src;
+}
+
 }  // namespace
+
+hipError_t launch_attn_plan(const int32_t* frame_offsets, int B, int rows_cover, int32_t* pad_offsets, int32_t* row_map, hipStream_t s) {
+    if (B <= 0 || rows_cover <= 0) return hipSuccess;
+    hipLaunchKernelGGL(attn_plan_scan_kernel, dim3(1), dim3(256), 0, s, frame_offsets, B, pad_offsets);
+    hipLaunchKernelGGL(attn_plan_map_kernel, dim3((unsigned)((rows_cover + 255) / 256)), dim3(256), 0, s, frame_offsets, pad_offsets, B, rows_cover, row_map);
+    return hipGetLastError();
+}
 
 hipError_t launch_split_rows(const float* x, float* out, int64_t rows, int K, hipStream_t s, int bf16) {
     if (rows <= 0) return hipSuccess;

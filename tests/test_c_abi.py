@@ -93,6 +93,10 @@ def test_forward_requires_weights_and_gpu_pointers():
     rc = lib.some_forward(eng.handle, None, None, 1, 10, 10, None, 0, None, None, None, 0, None)
     assert rc == _lib.SOME_ESTATE and b'attach' in lib.some_last_error(eng.handle)
     assert lib.some_workspace_bytes(eng.handle, 1000, 1) >= 2 * 1000 * (512 * 3 + 2048) * 4
+    # a batch of very short clips: the clip-aligned attention operands (every clip padded to a multiple of 16 rows) outgrow the FFN rows
+    mc = (1000 + 15 * 1000 + 126) // 64 * 64
+    assert lib.some_workspace_bytes(eng.handle, 1000, 1000) >= 2 * (1000 * 512 * 3 * 4 + mc * 4096 + 2048 * mc) + 4 * mc
+    assert lib.some_op_qkv_attention_f16x3_bytes(2584, 1) >= 2688 * 4096 + 2048 * 2688 + 4 * 2688
     assert lib.some_decode_scratch_bytes(eng.handle, 1000) >= 1000 * 13
 
 

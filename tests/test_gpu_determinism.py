@@ -167,8 +167,7 @@ def test_full_size_qkv_attention_f16x3_bit_stable(eng, operands):
     W = torch.randn(1536, 512, device='cuda', generator=g) / 512 ** 0.5
     W[:512] *= 3.0
     hs, Ws = _split(eng, operands['x512']), _split(eng, W)
-    ldv = (M + 255) // 256 * 256
-    ws = torch.empty(M * 4096 + 2048 * ldv, dtype=torch.uint8, device='cuda')
+    ws = torch.empty(eng.lib.some_op_qkv_attention_f16x3_bytes(M, batch.B), dtype=torch.uint8, device='cuda')
     out = torch.empty(M, 512, device='cuda')
 
     def run():

@@ -288,8 +288,7 @@ def test_qkv_attention_f16x3(eng, lens):
     W = torch.randn(1536, 512, device='cuda', generator=g) / 512 ** 0.5
     W[:512] *= 3.0                                           # sharper softmax
     out = torch.full((M, 512), float('nan'), device='cuda')
-    ldv = (M + 255) // 256 * 256
-    ws = torch.empty(M * 4096 + 2048 * ldv, dtype=torch.uint8, device='cuda')
+    ws = torch.empty(eng.lib.some_op_qkv_attention_f16x3_bytes(M, batch.B), dtype=torch.uint8, device='cuda')
     hs, Ws = _split(eng, h), _split(eng, W)          # keep alive: the library only borrows the pointers
     _lib.check(eng.handle, eng.lib.some_op_qkv_attention_f16x3(
         eng.handle, _p(hs), _p(Ws), _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M,
@@ -313,6 +312,41 @@ def test_qkv_attention_f16x3(eng, lens):
         ref = (torch.softmax(q @ k.transpose(1, 2) * 0.125, dim=-1) @ v).transpose(0, 1).reshape(t, 512).float()
         err = (got[s:s + t] - ref).abs().max().item()
         assert err < 1.2e-5, (b, t, err)            # measured 6e-6 .. 1.0e-5 over 2584 keys with the x3 sharpened scores
+
+
+def test_qkv_attention_f16x3_is_packing_independent(eng):
+    """A clip's attention output is the same BITS alone, at any position of a packed batch and beside any neighbours: operand rows
+    are clip-aligned (row gather in the QKV projection) and key tiles are counted from the clip's first frame.  Round 3 aligned the
+    tiles in global packed coordinates: last-bit differences that moved note boundaries between 1-rank and N-rank jobs."""
+    from some_amd import _lib
+    from some_amd.engine import ClipBatch
+    g = torch.Generator(device='cuda').manual_seed(4242)
+    lens = [130, 257, 64, 1, 33, 862, 16, 2584]
+    W = torch.randn(1536, 512, device='cuda', generator=g) / 512 ** 0.5
+    W[:512] *= 3.0
+    Ws = _split(eng, W)
+    hs = [torch.randn(t, 512, device='cuda', generator=g) for t in lens]
+
+    def run(order):
+        batch = ClipBatch([lens[i] for i in order], 'cuda')
+        M = batch.total_frames
+        h_split = _split(eng, torch.cat([hs[i] for i in order]))
+        out = torch.full((M, 512), float('nan'), device='cuda')
+        ws = torch.empty(eng.lib.some_op_qkv_attention_f16x3_bytes(M, batch.B), dtype=torch.uint8, device='cuda')
+        ws.fill_(0xFF)                                  # NaN bit patterns in every unwritten operand slot
+        _lib.check(eng.handle, eng.lib.some_op_qkv_attention_f16x3(
+            eng.handle, _p(h_split), _p(Ws), _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M,
+            _p(out), _p(ws), ws.numel(), _stream()))
+        torch.cuda.synchronize()
+        assert torch.isfinite(_unsplit(out)).all()
+        return batch, out
+
+    alone = [run([i])[1] for i in range(len(lens))]
+    for order in (list(range(len(lens))), [7, 3, 5, 0, 6, 2, 4, 1], [2, 2, 5, 3, 3, 7, 7]):
+        batch, out = run(order)
+        for pos, i in enumerate(order):
+            s = int(batch.frame_offsets[pos])
+            assert torch.equal(out[s:s + lens[i]], alone[i]), (order, pos)
 
 
 @pytest.mark.parametrize('tile', [0, 1, 2, 4])

@@ -73,19 +73,7 @@ def test_batch_infer_one_nccl_rank_and_two_gloo_ranks_equal_the_plain_run(tmp_pa
     assert (tmp_path / 'nccl1.csv').read_bytes() == plain
     r = _torchrun(2, base + ['--csv', str(tmp_path / 'gloo2.csv')], env={'SOME_AMD_DIST_BACKEND': 'gloo'})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    # rows are dealt to the ranks by size; a rank packs ITS rows into device batches, so a row meets other neighbours than in the plain
-    # run and its attention key tiles (aligned in global frame coordinates) fall differently - last-bit differences, as the reference
-    # itself has between B = 2 and B = 1 (6e-8).  With random weights (~100 notes per clip, many boundaries on a
-    # rounding edge) a few notes move by one frame: compared note by note, not row string by row string
-    rows = list(csv.DictReader(open(tmp_path / 'gloo2.csv', encoding='utf8')))
-    ref = list(csv.DictReader(open(tmp_path / 'plain.csv', encoding='utf8')))
-    assert [r_['name'] for r_ in rows] == [r_['name'] for r_ in ref] and all(r_['note_seq'] for r_ in rows)
-    same_rows = sum(a['note_seq'] == b['note_seq'] and a['note_dur'] == b['note_dur'] for a, b in zip(rows, ref))
-    n_notes = n_moved = 0
-    for a, b in zip(rows, ref):
-        ta = np.round(np.cumsum([float(x) for x in a['note_dur'].split()]) * 44100 / 512).astype(int)
-        tb = np.round(np.cumsum([float(x) for x in b['note_dur'].split()]) * 44100 / 512).astype(int)
-        n_notes += len(tb)
-        n_moved += len(set(ta.tolist()) ^ set(tb.tolist()))
-    print(f'two gloo ranks vs one process: {same_rows} of {len(rows)} rows identical as strings; {n_moved} of {n_notes} note boundaries differ')
-    assert n_moved <= max(2, 0.01 * n_notes)
+    # rows are dealt to the ranks by size and a rank packs ITS rows into device batches, so a row meets other neighbours than in the
+    # plain run - and its result must not care (clip-aligned attention key tiles; tests/test_gpu_parity.py pins the forward bit for
+    # bit): the sharded job's CSV is the single-process CSV, byte for byte, as the reference's per-chunk loop guarantees by construction
+    assert (tmp_path / 'gloo2.csv').read_bytes() == plain

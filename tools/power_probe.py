@@ -54,8 +54,7 @@ def main():
             M = batch.total_frames
             hs, Ws = split(gen(M, 512)), split(gen(1536, 512) / 512 ** 0.5)
             out = torch.empty(M, 512, device='cuda')
-            ldv = (M + 255) // 256 * 256
-            ws = torch.empty(M * 4096 + 2048 * ldv, dtype=torch.uint8, device='cuda')
+            ws = torch.empty(eng.lib.some_op_qkv_attention_f16x3_bytes(M, batch.B), dtype=torch.uint8, device='cuda')
 
             def run():
                 _lib.check(eng.handle, eng.lib.some_op_qkv_attention_f16x3(
