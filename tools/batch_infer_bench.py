@@ -143,8 +143,9 @@ def main():
             res['rows_rechecked_differing_as_strings'] = int(bad)
             res['rechecked_note_boundaries'] = int(notes)
             res['rechecked_note_boundaries_differing'] = int(moved)
-            res['recheck_note'] = ('rows recomputed alone through host Slicer + infer(): a row packed with other neighbours sees other attention key-tile '
-                                   'alignments - last-bit differences, as the reference has between B = 2 and B = 1 (SURVEY 8c)')
+            res['recheck_note'] = ('rows recomputed alone through host Slicer + infer(), the reference\'s own granularity (batch_infer.py:49-81): a '
+                                   'clip\'s result does not depend on its batch (clip-local attention key tiles), so the CSV cells are expected to be '
+                                   'identical STRINGS')
         if args.json:
             import json
             print(json.dumps(res))

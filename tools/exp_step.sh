@@ -2,7 +2,7 @@
 # step-time-only A/B legs (dual-stream forward, no per-kernel leg): tools/exp_step.sh <tag> <repeats> "name|ENV=.." ...
 TAG=$1; REP=$2; shift 2
 O=gpurun_out; mkdir -p $O
-B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-latency --no-f32-leg --no-secondary --no-kernel-profile"
+B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-latency --no-f32-leg --no-secondary --no-kernel-profile --no-e2e --no-train"
 for r in $(seq $REP); do
   for spec in "$@"; do
     name=${spec%%|*}; envs=${spec#*|}
