@@ -95,8 +95,9 @@ __device__ __forceinline__ void epilogue16s(const G16sArgs& a, f32x16 (&acc)[TM]
                 const uint32_t row0 = (uint32_t)(m0 + (wm * TM + i) * 32 + 4 * hi);
                 const uint32_t vc = nv ? row0 * row_c + (uint32_t)n * 4u : kOob;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][jn][r] + bias), rc, vc, rk(r) * row_c, 0);
+                for (int r = 0; r < 16; ++r)      // rows >= M of a partial row tile are masked explicitly (not left to the descriptor's range check)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][jn][r] + bias), rc,
+                                                          (FULL || row0 + rk(r) < (uint32_t)a.M) ? vc : kOob, rk(r) * row_c, 0);
             }
         }
     } else if constexpr (EPI == G16S_RESDROP) {
@@ -117,7 +118,8 @@ __device__ __forceinline__ void epilogue16s(const G16sArgs& a, f32x16 (&acc)[TM]
                 const uint32_t cell0 = ((uint32_t)row0 >> 1) * (uint32_t)a.N + (uint32_t)n;
                 float res[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, vr, rk(r) * row_h, 0));
+                for (int r = 0; r < 16; ++r)
+                    res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (FULL || row0 + (int)rk(r) < a.M) ? vr : kOob, rk(r) * row_h, 0));
 #pragma unroll
                 for (int rp = 0; rp < 8; ++rp) {
                     const uint32_t bits = drop_bits(cell0 + (rk(2 * rp) >> 1) * (uint32_t)a.N, a.k0, a.k1);   // rows (m, m + 1), m even
@@ -126,7 +128,7 @@ __device__ __forceinline__ void epilogue16s(const G16sArgs& a, f32x16 (&acc)[TM]
                         const int r = 2 * rp + e;
                         const float k = (e ? bits >> 16 : bits & 0xffffu) >= a.thr ? ak : 0.f;
                         const float v = __fadd_rn(res[r], __fmul_rn(k, acc[i][jn][r] + bias));       // alpha * dropout(y) + x, no contraction
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rc, vc, rk(r) * row_c, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rc, (FULL || row0 + (int)rk(r) < a.M) ? vc : kOob, rk(r) * row_c, 0);
                     }
                 }
             }

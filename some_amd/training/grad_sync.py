@@ -14,11 +14,14 @@ ring's summation order beyond.
 Launch ORDER is fixed: bucket k goes out only after every bucket above it (torch DDP's rule).  Collectives pair up across ranks by
 issue order, so an order that depended on which bucket happened to complete first on a rank (a parameter without a gradient on
 one rank only, a different autograd schedule) would pair mismatched slices - a hang or silent corruption.  A bucket that
-completes early waits in ``ready`` until its turn; ``finish()`` flushes the rest in the same descending order.  Parameters that
-received no gradient in the previous armed pass (``absent``: unused heads, frozen layers) are counted as reported when the next
-pass is armed - DDP's static-graph rule - so that one unused parameter in the top bucket does not hold every bucket back until
-``finish()``; if such a parameter does report after all, its gradient is simply in the buffer before the bucket goes out (and it
-leaves the set), unless the bucket has already gone: then the pass raises.
+completes early waits in ``ready`` until its turn; ``finish()`` flushes the rest in the same descending order.  A parameter that
+receives no gradient in a pass (an unused head, a frozen layer, a data-dependent path) therefore holds its bucket and every bucket
+below it back until ``finish()``: that pass is not overlapped, and nothing else happens - a gradient path may switch on and off from
+step to step and differ between ranks.  ``static_graph=True`` (config ``some_amd_ddp_static_graph``) is DDP's static-graph rule
+instead: parameters without a gradient in the previous armed pass (``absent``) are counted as reported when the next pass is armed,
+so one unused parameter does not cost the overlap; it is only sound when the set of used parameters never changes and is the same
+on every rank - if an ``absent`` parameter does report after its bucket has gone the slice has been reduced without it, and the
+pass raises.
 
 Every parameter reports exactly once per armed backward pass: a second report (a weight used by two layers) would launch the
 bucket before the later gradient is in the buffer, so it raises instead of counting (``fired``), and ``pending`` can never go
@@ -36,9 +39,10 @@ import torch
 
 class BucketedGradSync:
     def __init__(self, flat_grad: torch.Tensor, params: Sequence[Tuple[torch.Tensor, int, int]], process_group=None,
-                 bucket_bytes: int = 32 << 20, names: Optional[Sequence[str]] = None):
+                 bucket_bytes: int = 32 << 20, names: Optional[Sequence[str]] = None, static_graph: bool = False):
         """params: (leaf tensor whose .grad is a view of ``flat_grad``, offset, padded numel) in buffer order."""
         self.flat_grad, self.pg = flat_grad, process_group
+        self.static_graph = bool(static_graph)
         self.bounds: List[Tuple[int, int]] = []           # [start, end) of every bucket in the flat buffer
         self.bucket_of: List[int] = []                    # parameter index -> bucket
         self.size: List[int] = []                         # parameters per bucket
@@ -153,7 +157,7 @@ class BucketedGradSync:
             self.next_bucket -= 1
         for w in self.work:
             w.wait()
-        self.absent = {i for i, f in enumerate(self.fired) if not f}
+        self.absent = {i for i, f in enumerate(self.fired) if not f} if self.static_graph else set()
 
     def unreported(self) -> List[str]:
         """Names of the parameters that did not report in the last armed pass (no gradient this step)."""

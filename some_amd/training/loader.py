@@ -69,7 +69,12 @@ class PrefetchLoader:
         self.depth = max(1, self.workers) * max(1, int(prefetch_factor))
         self.on_device = isinstance(dataset, data.SyntheticNoteDataset) or self.device is None       # items are device tensors already
         self.cuda = not self.on_device and self.device.type == 'cuda'        # (a CPU device runs the same pipeline without pinning / streams: tests)
-        self.pool = None if self.on_device or self.workers == 0 else concurrent.futures.ThreadPoolExecutor(self.workers, thread_name_prefix='some-loader')
+        # worker threads pin memory (torch.full(..., pin_memory=True)): a new host thread defaults to device 0, so under one process per GPU
+        # every rank's workers would create a context on GPU 0 and pin there - bind them to this rank's device first (what torch's
+        # DataLoader pin thread does)
+        init = (lambda: torch.cuda.set_device(self.device)) if self.cuda else None
+        self.pool = None if self.on_device or self.workers == 0 else concurrent.futures.ThreadPoolExecutor(self.workers, thread_name_prefix='some-loader',
+                                                                                                             initializer=init)
         self.copy_stream = torch.cuda.Stream(self.device) if self.cuda else None
         self.stats = {'batches': 0, 'wait_s': 0.0, 'host_collate_s': 0.0}
 

@@ -74,7 +74,7 @@ class MIDIExtractionTrainer:
             P = self.model.params
             order = [(P.views[k], P.offsets[k], (P.views[k].numel() + 63) // 64 * 64) for k in P.param_names]
             self.grad_sync = BucketedGradSync(P.grad, order, process_group, int(config.get('some_amd_ddp_bucket_mb', 32)) << 20,
-                                              names=list(P.param_names))
+                                              names=list(P.param_names), static_graph=bool(config.get('some_amd_ddp_static_graph', False)))
         # Gradient sinks: nn.Linear / LayerNorm parameter gradients are written into the flat buffer by the backward kernels themselves
         # (ops.py: no per-parameter copy / accumulation launches).  Under data parallelism each deposit is reported to the bucketed
         # sync through mark().  (Round 2 kept sinks off for world > 1 because the replicas diverged: autograd fires a parameter's
@@ -173,6 +173,7 @@ class MIDIExtractionTrainer:
             self.ops.check(self.ops.lib.some_train_adamw(self.ops.h, p(P.flat), p(P.grad), p(self.exp_avg), p(self.exp_avg_sq), P.numel, lr,
                                                          self.betas[0], self.betas[1], self.eps, self.weight_decay, self.global_step,
                                                          clip_coef / (self.world * scale), self.ops.stream()))
+            self.ops.weights_version += 1          # the parameters moved: cached 16-bit weight images (ops.shadow16) are stale for ANY caller
         out = dict(losses)
         out['total_loss'] = total
         out['lr'] = lr
@@ -199,6 +200,7 @@ class MIDIExtractionTrainer:
     def load_checkpoint(self, ckpt: Dict[str, object]):
         P = self.model.params
         P.load_state_dict({(k[6:] if k.startswith('model.') else k): v for k, v in ckpt['state_dict'].items()})
+        self.ops.weights_version += 1              # (see _training_step)
         self.global_step = int(ckpt.get('global_step', 0))
         st = ckpt.get('some_amd_trainer')
         if st is not None:                      # a reference / inference-only checkpoint has no optimiser state: fresh moments

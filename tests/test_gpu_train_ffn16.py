@@ -63,6 +63,31 @@ def test_gemm16s_plain_matches_products_of_the_stored_operands(ops, operand, M, 
         ops.set_mixed_precision(False)
 
 
+@pytest.mark.parametrize('M', [129, 700, 777])
+@pytest.mark.parametrize('epi', [0, 3])
+def test_gemm16s_partial_row_tiles_stay_inside_the_output(ops, epi, M):
+    """Canary rows behind the M valid ones: the fp32 (epilogue 0) and residual + dropout (epilogue 3) epilogues of a partial
+    128-row tile must neither write rows >= M nor read the residual there - M % 128 != 0 is nearly every training batch."""
+    ops.set_mixed_precision(True, 'bf16')
+    try:
+        N, K, guard = 512, 512, 160
+        x16 = ops.cast16(_rand(M, K, seed=11))
+        w16, _ = ops.shadow16(_rand(N, K, seed=12, scale=K ** -0.5))
+        b = _rand(N, seed=13)
+        big = torch.full((M + guard, N), 12345.0, device='cuda')
+        res_big = torch.full((M + guard, N), float('nan'), device='cuda')        # a read past row M would poison nothing visible, but must not fault
+        res_big[:M] = _rand(M, N, seed=14)
+        if epi == 0:
+            ops.gemm16s(0, x16, w16, b, big[:M], N, M, N, K)
+        else:
+            ops.gemm16s(3, x16, w16, b, big[:M], N, M, N, K, h16=res_big[:M], p=0.1, seed=77, alpha=0.5)
+        torch.cuda.synchronize()
+        assert torch.isfinite(big[:M]).all()
+        assert (big[M:] == 12345.0).all()
+    finally:
+        ops.set_mixed_precision(False)
+
+
 @pytest.mark.parametrize('operand', ['bf16', 'f16'])
 @pytest.mark.parametrize('M,p', [(700, 0.0), (700, 0.1), (131, 0.5)])
 def test_ffn16_forward_and_backward_match_the_restated_arithmetic(ops, operand, M, p):

@@ -337,7 +337,8 @@ def test_cli_train_on_a_binarised_dataset(tmp_path, golden_dir):
     import yaml
     root = pathlib.Path(__file__).resolve().parents[1]
     user = {'base_config': ['configs/two_head_model.yaml'], 'binary_data_dir': str(golden_dir / 'binary'), 'max_batch_frames': 600, 'max_batch_size': 4,
-            'accumulate_grad_batches': 2, 'val_check_interval': 4, 'max_val_batch_size': 1,
+            'accumulate_grad_batches': 2, 'val_check_interval': 4, 'max_val_batch_size': 1, 'log_interval': 2, 'num_ckpt_keep': 1,
+            'permanent_ckpt_start': 4, 'permanent_ckpt_interval': 10,
             'midi_extractor_args': dict(get_config('two_head_model')['midi_extractor_args'], lay=1),
             'lr_scheduler_args': {'scheduler_cls': 'lr_scheduler.scheduler.WarmupLR', 'warmup_steps': 2, 'min_lr': 1e-5}}
     (tmp_path / 'my_experiment.yaml').write_text(yaml.safe_dump(user))     # a user's own file name: nothing is inferred from the stem
@@ -352,6 +353,18 @@ def test_cli_train_on_a_binarised_dataset(tmp_path, golden_dir):
     r = subprocess.run(cmd + ['--max_updates', '10'], capture_output=True, text=True, cwd=root, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'resumed from model_ckpt_steps_8.ckpt at step 8' in r.stdout and 'step 10:' in r.stdout
+    # DsModelCheckpoint retention (utils/training_utils.py:182-256): num_ckpt_keep 1 -> only the newest survives, except step 4 = permanent_ckpt_start
+    assert sorted(p.name for p in (tmp_path / 'exp').glob('*.ckpt')) == ['model_ckpt_steps_10.ckpt', 'model_ckpt_steps_4.ckpt']
+    # TensorBoardLogger's scalars (train.py:83-87, base_task.py:254-260, 311-316): event files of both runs + the CSV twin
+    from some_amd.training import run_log
+    logs = tmp_path / 'exp' / 'lightning_logs' / 'lastest'
+    files = sorted(logs.glob('events.out.tfevents.*'))
+    assert len(files) == 2 and all(len(run_log.read_records(f)) >= 2 for f in files)
+    rows = [ln.split(',') for ln in (logs / 'scalars.csv').read_text().splitlines()[1:]]
+    tags = {r_[1] for r_ in rows}
+    assert {'training/midi_loss', 'training/bound_loss', 'training/lr', 'training/batch_size', 'validation/total_loss', 'validation/midi_loss',
+            'metrics/midi_acc'} <= tags
+    assert sorted({int(r_[0]) for r_ in rows if r_[1] == 'training/lr'}) == [2, 4, 6, 8, 10]
 
 
 def test_gradient_accumulation_averages_the_micro_batch_gradients():

@@ -1,0 +1,120 @@
+"""Trainer-loop side files (some_amd/training/run_log.py): TensorBoard event framing, the scalar CSV, DsModelCheckpoint's retention rule
+(utils/training_utils.py:182-256), and the resume rule for the learning rate (training/base_task.py:412-456)."""
+import struct
+
+from some_amd.training import run_log
+from some_amd.training.task import warmup_lr
+
+
+def test_crc32c_known_answers():
+    assert run_log.crc32c(b'123456789') == 0xE3069283          # the CRC-32C check value (RFC 3720 appendix B.4 family)
+    assert run_log.crc32c(b'') == 0
+    assert run_log.crc32c(bytes(32)) == 0x8A9136AA             # 32 zero bytes (RFC 3720 B.4)
+
+
+def _parse_event(buf: bytes):
+    """A minimal protobuf walk over the fields ScalarLog writes."""
+    def varint(pos):
+        v = shift = 0
+        while True:
+            b = buf_[pos]
+            pos += 1
+            v |= (b & 0x7F) << shift
+            shift += 7
+            if not b & 0x80:
+                return v, pos
+
+    def walk(data):
+        nonlocal buf_
+        saved, buf_ = buf_, data
+        pos, out = 0, []
+        while pos < len(data):
+            key, pos = varint(pos)
+            num, wt = key >> 3, key & 7
+            if wt == 0:
+                v, pos = varint(pos)
+            elif wt == 1:
+                v, pos = data[pos:pos + 8], pos + 8
+            elif wt == 5:
+                v, pos = data[pos:pos + 4], pos + 4
+            else:
+                n, pos = varint(pos)
+                v, pos = data[pos:pos + n], pos + n
+            out.append((num, wt, v))
+        buf_ = saved
+        return out
+    buf_ = buf
+    ev = {'scalars': {}}
+    for num, wt, v in walk(buf):
+        if num == 1:
+            ev['wall_time'] = struct.unpack('<d', v)[0]
+        elif num == 2:
+            ev['step'] = v
+        elif num == 3:
+            ev['file_version'] = v.decode()
+        elif num == 5:
+            for n2, _, val in walk(v):
+                assert n2 == 1
+                fields = {n3: x for n3, _, x in walk(val)}
+                ev['scalars'][fields[1].decode()] = struct.unpack('<f', fields[2])[0]
+    return ev
+
+
+def test_scalar_log_writes_a_tensorboard_event_file_and_a_csv(tmp_path):
+    log = run_log.ScalarLog(tmp_path)
+    log.log_metrics({'training/bound_loss': 0.25, 'training/lr': 1e-4}, step=100)
+    log.log_metrics({'validation/total_loss': 1.5}, step=1000)
+    log.close()
+    d = tmp_path / 'lightning_logs' / 'lastest'                  # train.py:84-86 (the reference's spelling)
+    files = list(d.glob('events.out.tfevents.*'))
+    assert len(files) == 1
+    events = [_parse_event(r) for r in run_log.read_records(files[0])]            # read_records verifies both masked CRCs of every record
+    assert events[0]['file_version'] == 'brain.Event:2' and events[0]['step'] == 0
+    assert events[1]['step'] == 100 and abs(events[1]['scalars']['training/bound_loss'] - 0.25) < 1e-7
+    assert abs(events[1]['scalars']['training/lr'] - 1e-4) < 1e-10
+    assert events[2]['step'] == 1000 and events[2]['scalars'] == {'validation/total_loss': 1.5}
+    rows = (d / 'scalars.csv').read_text().splitlines()
+    assert rows[0] == 'step,tag,value,wall_time' and rows[1].startswith('100,training/bound_loss,0.25,') and len(rows) == 4
+    raw = bytearray(files[0].read_bytes())                       # a flipped payload byte is caught by the framing
+    raw[-6] ^= 1
+    files[0].write_bytes(bytes(raw))
+    try:
+        run_log.read_records(files[0])
+        raise SystemExit('corruption not detected')
+    except AssertionError:
+        pass
+
+
+def test_checkpoint_keeper_follows_ds_model_checkpoint(tmp_path):
+    """save_top_k newest (monitor 'step', mode 'max') + permanent checkpoints: start 2000, interval 1000 -> 2000, 3000, ... survive."""
+    k = run_log.CheckpointKeeper(tmp_path, num_ckpt_keep=2, permanent_ckpt_start=2000, permanent_ckpt_interval=1000)
+    lines = []
+    for step in range(500, 4001, 500):
+        p = k.path_for(step)
+        p.write_bytes(b'x')
+        lines += k.saved(p)
+    left = sorted(k.step_of(p) for p in tmp_path.glob('*.ckpt'))
+    assert left == [2000, 3000, 3500, 4000]                      # the window (3500, 4000) + the permanent ones that have left it
+    assert 'Checkpoint model_ckpt_steps_2000.ckpt is now permanent.' in lines and 'Removed checkpoint model_ckpt_steps_2500.ckpt.' in lines
+    # a restart finds the newest checkpoint and does not count permanent files against the window
+    k2 = run_log.CheckpointKeeper(tmp_path, 2, 2000, 1000)
+    assert k2.step_of(k2.existing(tmp_path)[-1]) == 4000 and [k2.step_of(p) for p in k2.window] == [3500]
+    # interval <= 9 or start 0 disables permanent checkpoints (utils/training_utils.py:194)
+    k3 = run_log.CheckpointKeeper(tmp_path / 'b', 1, 2000, 9)
+    (tmp_path / 'b').mkdir()
+    for step in (2000, 2009):
+        p = k3.path_for(step)
+        p.write_bytes(b'x')
+        k3.saved(p)
+    assert sorted(k3.step_of(p) for p in (tmp_path / 'b').glob('*.ckpt')) == [2009]
+
+
+def test_learning_rate_on_resume_follows_the_current_config():
+    """on_load_checkpoint re-simulates the scheduler from the CURRENT optimizer_args / lr_scheduler_args at the checkpoint's step count
+    (training/base_task.py:438-456): here the rate is a pure function of (step, config), so a resumed run with a changed base lr or warm-up
+    continues on the new schedule - the values the reference's WarmupLR gives (tests/golden/lr_schedule.json pins the function itself)."""
+    assert warmup_lr(5001, 1e-4, 5000, 1e-5) == 1e-4 * 5000 ** 0.5 * 5001 ** -0.5
+    resumed_step = 12000
+    old = warmup_lr(resumed_step + 1, 1e-4, 5000, 1e-5)
+    new = warmup_lr(resumed_step + 1, 3e-4, 2000, 1e-5)
+    assert abs(new - 3e-4 * (2000 / (resumed_step + 1)) ** 0.5) < 1e-12 and new != old

@@ -174,7 +174,8 @@ for n, off in zip(sizes, offs):
     p.requires_grad_(True)
     p.grad = grad[off:off + n]
     views.append(p)
-sync = BucketedGradSync(grad, [(p, off, n) for p, off, n in zip(views, offs, sizes)], None, bucket_bytes=5000 * 4)
+STATIC = os.environ.get('STATIC') == '1'
+sync = BucketedGradSync(grad, [(p, off, n) for p, off, n in zip(views, offs, sizes)], None, bucket_bytes=5000 * 4, static_graph=STATIC)
 assert sync.bounds == [(0, 4160), (4160, 8320), (8320, 12480), (12480, 16640)]
 def loss_fn(skip_last=False):
     x = torch.full((64,), 0.5 + rank)
@@ -203,7 +204,8 @@ for skip_last in (False, True):
     assert torch.equal(grad, want_two), (grad - want_two).abs().max()
     # last layers first, in a FIXED descending order (collectives pair up across ranks by issue order): bucket k leaves only after
     # every bucket above it.  The first pass in which the top bucket's parameters get no gradient (skip_last) therefore sends
-    # everything from finish(); the parameters are then known to be absent and the next pass overlaps again.
+    # everything from finish(); with static_graph the parameters are then known to be absent and the next pass overlaps again,
+    # without it every pass that leaves them out is sent from finish() (always correct, whatever the other rank does).
     assert launched_in_backward == sorted(launched_in_backward, reverse=True)
     assert len(launched_in_backward) == (0 if skip_last else len(sync.bounds))
     assert sync.launch_order == list(reversed(range(len(sync.bounds))))
@@ -214,19 +216,33 @@ for skip_last in (False, True):
     in_backward = list(sync.launch_order)
     sync.finish()
     assert torch.equal(grad, want)
-    assert len(in_backward) >= 3 and sync.launch_order == list(reversed(range(len(sync.bounds))))
+    assert len(in_backward) >= (3 if STATIC or not skip_last else 0) and sync.launch_order == list(reversed(range(len(sync.bounds))))
 # a parameter counted as absent that reports after all (skip_last -> full model): its gradient is in the buffer before its bucket
 # leaves - correct result, and it is no longer absent afterwards
 grad.zero_()
 loss_fn(False).backward()
 want = grad.clone()
 dist.all_reduce(want)
-assert sync.absent == {6, 7}
+assert sync.absent == ({6, 7} if STATIC else set())
 grad.zero_()
 sync.arm()
 loss_fn(False).backward()
 sync.finish()
 assert torch.equal(grad, want) and sync.absent == set()
+if not STATIC:
+    # a gradient path that switches on and off from step to step, DIFFERENTLY on the two ranks: never an error, always the sum
+    for step in range(6):
+        skip = (step + rank) % 2 == 1
+        grad.zero_()
+        loss_fn(skip).backward()
+        want = grad.clone()
+        dist.all_reduce(want)
+        grad.zero_()
+        sync.arm()
+        loss_fn(skip).backward()
+        sync.finish()
+        assert torch.equal(grad, want), step
+        assert sync.launch_order == list(reversed(range(len(sync.bounds))))
 # a parameter that reports twice in one armed pass raises instead of launching its bucket early
 sync.arm()
 sync.mark(views[7])
@@ -247,7 +263,8 @@ print('ok', rank)
 '''
 
 
-def test_bucketed_gradient_sync_overlaps_backward_and_equals_one_all_reduce(tmp_path):
+@pytest.mark.parametrize('static_graph', [False, True])
+def test_bucketed_gradient_sync_overlaps_backward_and_equals_one_all_reduce(tmp_path, static_graph):
     """grad_sync.BucketedGradSync on gloo, world size 2 (CPU): buckets are launched from inside the backward pass, last
     layers first; the reduced flat gradient equals a single all-reduce bit for bit, with gradient accumulation and with
     parameters that receive no gradient."""
@@ -260,7 +277,7 @@ def test_bucketed_gradient_sync_overlaps_backward_and_equals_one_all_reduce(tmp_
     script = tmp_path / 'sync_worker.py'
     script.write_text(_SYNC_WORKER)
     root = pathlib.Path(__file__).resolve().parents[1]
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), PORT=str(port), REPO=str(root)),
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), PORT=str(port), REPO=str(root), STATIC=str(int(static_graph))),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs

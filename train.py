@@ -54,6 +54,7 @@ def _load_config(config: str) -> dict:
 def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_clips):
     from some_amd.training import data
     from some_amd.training.loader import PrefetchLoader
+    from some_amd.training.run_log import CheckpointKeeper, ScalarLog
     from some_amd.training.samplers import DsBatchSampler, DsEvalBatchSampler
     from some_amd.training.task import MIDIExtractionTrainer
     cfg = _load_config(config)
@@ -104,48 +105,69 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
                     sums[k] = sums.get(k, 0.0) + float(v)
         acc = sums['midi_acc_correct'] / max(sums['midi_acc_total'], 1.0)
         print(f'validation @ {step}: ' + ', '.join(f'{k}={v / n:.5f}' for k, v in sums.items() if k.endswith('loss')) + f', midi_acc={acc:.4f}')
+        if scalar_log is not None:         # training/base_task.py:311-316
+            val = {k: v / n for k, v in sums.items() if k.endswith('loss')}
+            scalar_log.log_metrics({'validation/total_loss': sum(val.values()), **{f'validation/{k}': v for k, v in val.items()}}, step)
+            scalar_log.log_metrics({'metrics/midi_acc': acc}, step)
 
     total = max_updates if max_updates is not None else cfg.get('max_updates', 100000)
     # train.py:98-108 of the reference: continue from the newest checkpoint of the experiment directory, if any
-    existing = sorted(work.glob('model_ckpt_steps_*.ckpt'), key=lambda p: int(p.stem.rsplit('_', 1)[1]))
+    existing = CheckpointKeeper.existing(work)
     if existing:
+        # the learning rate is a pure function of (global_step, the CURRENT config's optimizer_args / lr_scheduler_args) - what the reference's
+        # on_load_checkpoint re-simulation (training/base_task.py:412-456) arrives at: a changed lr / warmup in the config takes effect on resume
         trainer.load_checkpoint(torch.load(existing[-1], map_location='cpu'))
         if rank == 0:
             print(f'resumed from {existing[-1].name} at step {trainer.global_step}')
-    keep, interval = cfg.get('num_ckpt_keep', 5), cfg.get('val_check_interval', 1000)
+    interval = cfg.get('val_check_interval', 1000)
+    # utils/training_utils.py:182-256 (DsModelCheckpoint): newest num_ckpt_keep + permanent checkpoints; train.py:83-87 (TensorBoardLogger)
+    keeper = CheckpointKeeper(work, cfg.get('num_ckpt_keep', 5), cfg.get('permanent_ckpt_start', 0), cfg.get('permanent_ckpt_interval', 0))
+    scalar_log = ScalarLog(work) if rank == 0 else None
     # training/base_task.py:374-380: DataLoader(num_workers=ds_workers, prefetch_factor=dataloader_prefetch_factor, pin_memory=True,
     # persistent_workers=True) - here worker threads collating into pinned buffers + uploads on a copy stream (training/loader.py)
     loader = PrefetchLoader(train_set, cfg, trainer.ops.device, workers=int(cfg.get('ds_workers', 4)),
                             prefetch_factor=int(cfg.get('dataloader_prefetch_factor', 2)))
     steps_per_epoch = max(1, len(sampler) // accumulate)
-    saved, epoch = list(existing), trainer.global_step // steps_per_epoch
+    epoch = trainer.global_step // steps_per_epoch
     skip = trainer.global_step % steps_per_epoch          # resumed inside an epoch: its first `skip` updates have been applied already
     t_train = time.perf_counter()
+
+    def update(micro):
+        out = trainer.training_step(micro if len(micro) > 1 else micro[0])
+        step = trainer.global_step
+        if rank == 0 and (step % log_interval == 0 or step == total):
+            print(f'step {step}: ' + ', '.join(f'{k}={float(v):.5f}' for k, v in out.items() if k.endswith('loss')) +
+                  f', lr={out["lr"]:.3e}, loss_scale={trainer.loss_scale:g}')
+        if scalar_log is not None and step % int(cfg.get('log_interval', 100)) == 0 and not out['skipped']:       # training/base_task.py:254-260
+            scalar_log.log_metrics({**{f'training/{k}': float(v) for k, v in out.items() if k.endswith('loss') and k != 'total_loss'},
+                                    'training/batch_size': float(sum(int(m['units'].shape[0]) for m in micro)) / len(micro), 'training/lr': out['lr']}, step)
+        if rank == 0 and (step % interval == 0 or step == total) and not out['skipped']:
+            path = keeper.path_for(step)
+            torch.save(trainer.checkpoint(), path)
+            if val_sampler is not None:
+                validate(step)
+            for line in keeper.saved(path):
+                print(line)
+
     while trainer.global_step < total:
         sampler.set_epoch(epoch)
         plan = list(sampler)[skip * accumulate:]
+        if not plan:
+            raise RuntimeError(f'epoch {epoch}: the batch sampler produced no batch for rank {rank} (dataset too small for this world size?)')
         epoch, skip = epoch + 1, 0
         micro = []
         for mb in loader.batches(plan):
             micro.append(mb)
             if len(micro) < accumulate:
                 continue
-            out = trainer.training_step(micro if accumulate > 1 else micro[0])
+            update(micro)
             micro = []
-            step = trainer.global_step
-            if rank == 0 and (step % log_interval == 0 or step == total):
-                print(f'step {step}: ' + ', '.join(f'{k}={float(v):.5f}' for k, v in out.items() if k.endswith('loss')) +
-                      f', lr={out["lr"]:.3e}, loss_scale={trainer.loss_scale:g}')
-            if rank == 0 and (step % interval == 0 or step == total) and not out['skipped']:
-                path = work / f'model_ckpt_steps_{step}.ckpt'
-                torch.save(trainer.checkpoint(), path)
-                saved.append(path)
-                if val_sampler is not None:
-                    validate(step)
-                while len(saved) > keep:
-                    saved.pop(0).unlink(missing_ok=True)
-            if step >= total:
+            if trainer.global_step >= total:
                 break
+        if micro and trainer.global_step < total:
+            # fewer than accumulate_grad_batches micro-batches left at the end of the epoch: Lightning steps the optimiser on what has
+            # accumulated (DsBatchSampler pads the batch count to a multiple, so this is for resumed / sliced plans)
+            update(micro)
     torch.cuda.synchronize()
     if rank == 0:
         wall = time.perf_counter() - t_train
@@ -153,6 +175,8 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
         print(f'loader: {st["batches"]} batches, waited {st["wait_s"]:.2f} s of {wall:.2f} s for data ({100.0 * st["wait_s"] / max(wall, 1e-9):.1f} %), '
               f'host collate {st["host_collate_s"]:.2f} s in {loader.workers} worker threads')
     loader.close()
+    if scalar_log is not None:
+        scalar_log.close()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
