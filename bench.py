@@ -182,6 +182,9 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit(f'--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} processes')
     dev_index = local_rank % max(1, torch.cuda.device_count())
+    if world > 1:                     # one process per GPU on a shared host: every rank on its own cores (some_amd/sharding.py)
+        from some_amd import sharding
+        sharding.bind_rank_to_cores(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     dist = None

@@ -137,6 +137,60 @@ def test_wav_loader_resamples_like_librosa_kaiser_best(tmp_path, file_sr):
     assert resample(want, sr, sr) is not None and np.array_equal(resample(want, sr, sr), want)
 
 
+def test_load_pcm_fast_path_equals_scipy_and_falls_back(tmp_path):
+    """load_pcm's two-syscall reader (mono int16 PCM at the target rate: what DiffSinger datasets hold) returns scipy's samples bit for
+    bit; every other layout - stereo, float, another rate, an extensible header, extra chunks in front of the data, a truncated file -
+    takes the scipy / load_wav path and gives load_wav's result."""
+    import struct
+    from scipy.io import wavfile
+    from some_amd.utils import audio
+    rng = np.random.default_rng(3)
+    sr = 44100
+    pcm = rng.integers(-32768, 32767, size=12345, dtype=np.int16)
+    wavfile.write(str(tmp_path / 'mono.wav'), sr, pcm)
+    fast = audio._read_pcm16_mono(tmp_path / 'mono.wav', sr)
+    assert fast is not None and fast.dtype == np.int16 and np.array_equal(fast, pcm)
+    got, got_sr = audio.load_pcm(tmp_path / 'mono.wav', sr)
+    assert got_sr == sr and got.dtype == np.int16 and np.array_equal(got, pcm)
+    # a LIST chunk between fmt and data (what many editors write) is skipped, odd chunk sizes are word aligned
+    raw = (tmp_path / 'mono.wav').read_bytes()
+    extra = b'LIST' + struct.pack('<I', 5) + b'abcde' + b'\0'
+    body = raw[12:36] + extra + raw[36:]
+    (tmp_path / 'list.wav').write_bytes(b'RIFF' + struct.pack('<I', 4 + len(body)) + b'WAVE' + body)
+    assert np.array_equal(audio._read_pcm16_mono(tmp_path / 'list.wav', sr), pcm)
+    assert np.array_equal(audio.load_pcm(tmp_path / 'list.wav', sr)[0], pcm)
+    # fallbacks
+    wavfile.write(str(tmp_path / 'stereo.wav'), sr, np.stack([pcm, pcm[::-1]], axis=1))
+    wavfile.write(str(tmp_path / 'float.wav'), sr, (pcm / 32768.0).astype(np.float32))
+    wavfile.write(str(tmp_path / 'rate.wav'), 22050, pcm[:2000])
+    for name in ('stereo.wav', 'float.wav', 'rate.wav'):
+        assert audio._read_pcm16_mono(tmp_path / name, sr) is None
+        want, _ = audio.load_wav(tmp_path / name, sr, mono=True)
+        got, _ = audio.load_pcm(tmp_path / name, sr)
+        assert got.dtype == np.float32 and np.array_equal(got, want)
+    # pooled sample buffers: same samples, the buffer is reused after give(), a truncated file hands its buffer back
+    pool = audio.PcmPool(max_bytes=8 << 20)
+    a, _ = audio.load_pcm(tmp_path / 'mono.wav', sr, pool)
+    assert np.array_equal(a, pcm) and a.base is not None and a.base.shape[0] == audio.PcmPool.STEP
+    first = a.base
+    pool.give(a)
+    b, _ = audio.load_pcm(tmp_path / 'list.wav', sr, pool)
+    assert b.base is first and np.array_equal(b, pcm)
+    c, _ = audio.load_pcm(tmp_path / 'mono.wav', sr, pool)                 # pool exhausted? no: a second block fits in 8 MiB
+    d, _ = audio.load_pcm(tmp_path / 'mono.wav', sr, pool)
+    e, _ = audio.load_pcm(tmp_path / 'mono.wav', sr, pool)                 # 4 blocks x 2 MiB = the cap; the 5th is a plain array
+    f, _ = audio.load_pcm(tmp_path / 'mono.wav', sr, pool)
+    assert f.base is None and np.array_equal(f, pcm) and pool.bytes == 8 << 20
+    pool.give(f)                                                           # a foreign array is simply dropped
+    for x in (b, c, d, e):
+        pool.give(x)
+    assert sum(len(v) for v in pool._free.values()) == 4 and not pool._owned
+    (tmp_path / 'short.wav').write_bytes(raw[:-100])                      # data chunk longer than the file
+    assert audio._read_pcm16_mono(tmp_path / 'short.wav', sr) is None
+    (tmp_path / 'junk.wav').write_bytes(b'not a wave file at all, just bytes' * 4)
+    assert audio._read_pcm16_mono(tmp_path / 'junk.wav', sr) is None
+
+
 def test_config_inheritance(tmp_path, monkeypatch):
     from some_amd.utils.config_utils import read_full_config
     monkeypatch.chdir(tmp_path)

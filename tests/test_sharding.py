@@ -73,3 +73,27 @@ def test_two_rank_gloo_batch_infer(tmp_path, golden_dir):
     # both ranks did part of the work (chunks processed), neither did all of it
     seen = [int((tmp_path / f'rank{r}.seen').read_text()) for r in range(2)]
     assert all(s > 0 for s in seen)
+
+
+def test_rank_core_slices_are_disjoint_whole_cores_and_size_the_worker_pools(monkeypatch):
+    """Every rank of a node gets its own run of physical cores (SMT siblings together); pools are sized from that share."""
+    import os
+    from some_amd import sharding
+    allowed = sorted(os.sched_getaffinity(0))
+    for world in (1, 2, 4):
+        slices = [sharding.rank_core_slice(r, world, allowed) for r in range(world)]
+        flat = [c for s in slices for c in s]
+        assert len(flat) == len(set(flat)) and set(flat) <= set(allowed)
+        if len(sharding._core_groups(allowed)) >= world:
+            assert all(slices) and len({len(s) for s in slices}) == 1
+            groups = sharding._core_groups(allowed)
+            for s in slices:                                   # no physical core is split between two ranks
+                assert all(set(g) <= set(s) or not (set(g) & set(s)) for g in groups)
+    assert sharding._parse_cpulist('0-2,7,9-10\n') == [0, 1, 2, 7, 9, 10]
+    # pool sizes: an unbound rank divides the visible cores by the world size, a bound one uses its own affinity set
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda _pid: set(range(256)))
+    monkeypatch.setattr(sharding, '_BOUND', False)
+    assert sharding.host_workers(8) == (4, 4) and sharding.host_workers(64) == (2, 1)
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda _pid: set(range(32)))
+    monkeypatch.setattr(sharding, '_BOUND', True)
+    assert sharding.host_workers(8) == (4, 4)

@@ -66,6 +66,8 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
     world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     if world > 1:
+        from some_amd import sharding
+        sharding.bind_rank_to_cores(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))       # loader threads stay next to this rank's GPU
         torch.distributed.init_process_group(os.environ.get('SOME_AMD_DIST_BACKEND', 'nccl'))
     if rank == 0:
         work.mkdir(parents=True, exist_ok=True)
