@@ -71,6 +71,7 @@ class BucketedGradSync:
         self.launch_order: List[int] = []                 # diagnostics: order in which buckets went out this step
         self.fire_order: List[int] = []                   # diagnostics: parameter indices in reporting order
         self.absent: set = set()                          # parameters without a gradient in the previous armed pass
+        self.before_launch = None                         # optional callable run right before a bucket's all-reduce is issued
         self._hooks = []
         self._index = {}
         for i, (p, _, _) in enumerate(params):
@@ -127,6 +128,8 @@ class BucketedGradSync:
 
     def _launch(self, bucket: int):
         a, b = self.bounds[bucket]
+        if self.before_launch is not None:
+            self.before_launch()                   # the trainer's two lanes: the current stream first waits for the other lane's kernels
         self.work[bucket] = torch.distributed.all_reduce(self.flat_grad[a:b], op=torch.distributed.ReduceOp.SUM, group=self.pg,
                                                          async_op=True)
         self.launched[bucket] = True

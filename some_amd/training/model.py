@@ -168,14 +168,19 @@ class TrainableMidiConforms:
             x = o.mask_rows(x, mask_u8)
         for i in range(self.lay):
             pre = f'model.cf_lay.{i}'
+            fork = o.fork_point()                      # the bound stream's block runs on lane 1, behind what is enqueued up to HERE
             m = self._block(x, pre + '.att1', batch)
-            b = self._block(x1, pre + '.att2', batch)
+            with o.lane(1, after=fork):
+                b = self._block(x1, pre + '.att2', batch)
             gm = o.glu(o.linear(m, P[pre + '.glu1.0.weight'], P[pre + '.glu1.0.bias']))
             gb = o.glu(o.linear(b, P[pre + '.glu2.0.weight'], P[pre + '.glu2.0.bias']))
             x, x1 = o.axpy(1.0, gb, m), o.axpy(1.0, gm, b)                                   # Gcf.forward :82-87
             if mask_u8 is not None:
                 x = o.mask_rows(x, mask_u8)
-        x, x1 = self._block(x, 'model.att1', batch), self._block(x1, 'model.att2', batch)
+        fork = o.fork_point()
+        x = self._block(x, 'model.att1', batch)
+        with o.lane(1, after=fork):
+            x1 = self._block(x1, 'model.att2', batch)
         midi = o.linear(x, P['model.outln.weight'], P['model.outln.bias'])
         bound = o.reshape(o.sigmoid(o.linear(x1, P['model.cutheard.weight'], P['model.cutheard.bias'])), -1)
         return midi, bound

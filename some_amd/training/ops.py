@@ -26,10 +26,24 @@ class TrainOps:
             raise RuntimeError('the training operators need an AMD GPU (no CPU fallback)')
         self.engine = engine
         self.lib, self.h, self.device = engine.lib, engine.handle, engine.device
-        self._scratch: Optional[torch.Tensor] = None
+        self._scratch: Dict[int, torch.Tensor] = {}         # per lane: two lanes reduce through their scratch at the same time
         self._pinned_stream = None
         self.tape: Optional['Tape'] = None        # set by the trainer for the duration of a forward + backward pass
-        self._partial: Optional[torch.Tensor] = None
+        self._partials: Dict[int, torch.Tensor] = {}
+        # Two LANES (trainer's tape only): the midi and the bound stream of a Gcf layer are independent between the cross gates
+        # (Gconform.py:82-87), forward and backward, so the model issues the bound stream's block on lane 1 = a second HIP stream.
+        # At the reference's batch shape (8 phrases, ~4 100 frames) a step is ~860 launches of 5 - 35 us, most of them far from filling
+        # 256 CUs (a GEMM is 66 workgroups): the device is busy the whole step although hardly used (profiles/r04_train_graph_probe.txt).
+        # Tensors carry the lane that produced them on the tape; a consumer on the other lane waits on an event of the producer's
+        # stream and tells the caching allocator (record_stream).  SOME_AMD_TRAIN_LANES=1: everything on one stream (A/B runs).
+        self.lanes = 2 if os.environ.get('SOME_AMD_TRAIN_LANES', '2') != '1' else 1
+        self._lane = 0
+        self._lane_streams = [None, None]          # torch streams of the pinned step: [the caller's, the helper]
+        self._lane_ptrs = [None, None]
+        self._side_stream = None
+        self._lane_version = [0, 0]                # operators enqueued per lane
+        self._lane_seen = {(0, 1): -1, (1, 0): -1} # (producer, consumer) -> the producer's version the consumer has waited for
+        self._fork_cover = None                    # inside lane(i, after=fork): (the fork's lane, its version at the fork point)
         self.gemm_precision = 'f16x3' if engine.c_config.precision == _lib.PRECISION_F16X3 else 'f32'
         self.attention_precision = self.gemm_precision      # forward + backward: split-f16 or exact-f32 MFMA kernels
         self._hi = 0                                        # GEMM flag bits of the one-product modes (set_mixed_precision)
@@ -93,10 +107,9 @@ class TrainOps:
         M, N = dy.shape
         K = x.shape[1]
         need = int(self.lib.some_train_gemm16_bytes(self.h, N, K, M, K + 4))
-        if self._partial is None or self._partial.numel() < need:
-            self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
-        self.check(self.lib.some_train_gemm16_wgrad(self.h, _p(dy), N, _p(x), K, _p(dw), _p(db), N, K, M, self._op16, 1, _p(self._partial),
-                                                    self._partial.numel(), self.stream()))
+        part = self.partial(need)
+        self.check(self.lib.some_train_gemm16_wgrad(self.h, _p(dy), N, _p(x), K, _p(dw), _p(db), N, K, M, self._op16, 1, _p(part),
+                                                    part.numel(), self.stream()))
 
     # ---- 16-bit stored operands (mixed precision) ---------------------------------------------------------------------
     @property
@@ -164,10 +177,9 @@ class TrainOps:
         M, N = dy16.shape
         K = x16.shape[1]
         need = int(self.lib.some_train_gemm16_bytes(self.h, N, K, M, K + 4))
-        if self._partial is None or self._partial.numel() < need:
-            self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
+        part = self.partial(need)
         self.check(self.lib.some_train_gemm16_wgrad16(self.h, _p(dy16), dy16.stride(0), _p(x16), x16.stride(0), _p(dw), _p(db), N, K, M, self._hi_mode, int(accumulate),
-                                                      _p(self._partial), self._partial.numel(), self.stream()))
+                                                      _p(part), part.numel(), self.stream()))
 
     def silu16(self, x: torch.Tensor) -> torch.Tensor:
         out = torch.empty(x.shape, dtype=self.dtype16, device=self.device)
@@ -210,20 +222,98 @@ class TrainOps:
     # ---- plumbing -------------------------------------------------------------------------------------------
     def stream(self):
         # looking the current stream up costs 3.4 us - a third of an operator call's host time (tools/host_overhead_probe.py); a training
-        # step runs on ONE stream, so the trainer pins it for the duration of the step (forward and the autograd thread's backward)
-        return self._pinned_stream or C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # step runs on the caller's stream (+ the helper stream of lane 1), so the trainer pins them for the duration of the step
+        if self._pinned_stream is not None:
+            return self._lane_ptrs[self._lane]
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def pin_stream(self):
-        self._pinned_stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        main = torch.cuda.current_stream(self.device)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(self.device)
+        self._lane_streams = [main, self._side_stream]
+        self._lane_ptrs = [C.c_void_p(main.cuda_stream), C.c_void_p(self._side_stream.cuda_stream)]
+        self._pinned_stream = self._lane_ptrs[0]
+        self._lane = 0
+        self._lane_version = [0, 0]
+        self._lane_seen = {(0, 1): -1, (1, 0): -1}
 
     def unpin_stream(self):
+        if self._pinned_stream is not None and self._lane_streams[0] is not None:
+            torch.cuda.set_stream(self._lane_streams[0])           # (an exception inside a lane must not leave torch on the helper stream)
         self._pinned_stream = None
+        self._lane = 0
+        self._fork_cover = None
+
+    # ---- lanes ---------------------------------------------------------------------------------------------------
+    def two_lanes(self) -> bool:
+        return self.lanes == 2 and self.tape is not None and self._pinned_stream is not None
+
+    def fork_point(self):
+        """An event on the CURRENT lane's stream at this point of the enqueue order (None when lanes are off): ``lane(i, after=...)``
+        starts lane i behind it - and not behind what is enqueued on this lane later."""
+        if not self.two_lanes():
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self._lane_streams[self._lane])
+        return ev, self._lane, self._lane_version[self._lane]
+
+    def lane(self, index: int, after=None):
+        """Context: the operators issued inside run on lane ``index`` (its HIP stream, its allocator pool, its scratch)."""
+        return _Lane(self, index if self.two_lanes() else self._lane, after)
+
+    def wait_lane(self, producer: int, force: bool = False):
+        """The current lane waits for everything enqueued on ``producer`` so far (skipped when it already has)."""
+        me = self._lane
+        if producer == me:
+            return
+        if not force and self._lane_seen[(producer, me)] == self._lane_version[producer]:
+            return
+        ev = torch.cuda.Event()
+        ev.record(self._lane_streams[producer])
+        self._lane_streams[me].wait_event(ev)
+        self._lane_seen[(producer, me)] = self._lane_version[producer]
+
+    def adopt(self, t: torch.Tensor, producer: int, version: int = -1):
+        """Make ``t`` (produced on lane ``producer`` as its ``version``-th operator) safe to use on the current lane: order the streams -
+        unless the lane was started behind a fork point that already covers the producer - and tell the caching allocator that the
+        tensor's memory is in use on this lane's stream too."""
+        if producer != self._lane:
+            cover = self._fork_cover
+            if not (cover is not None and cover[0] == producer and 0 <= version <= cover[1]):
+                self.wait_lane(producer)
+            t.record_stream(self._lane_streams[self._lane])
+
+    def sync_other_lane(self):
+        """The current lane waits for the other one (before a collective that reads what both have written)."""
+        if self._pinned_stream is not None and self.lanes == 2 and self._lane_streams[1] is not None:
+            self.wait_lane(1 - self._lane, force=True)
+
+    def join_lanes(self):
+        """Lane 0 waits for lane 1 (end of the backward pass: the gradient norm and the optimiser run on the caller's stream)."""
+        if self._pinned_stream is not None and self._lane_version[1] > 0:
+            keep, self._lane = self._lane, 0
+            self.wait_lane(1, force=True)
+            self._lane = keep
+
+    def _enter_lane(self, index: int):
+        """Switch the lane operators are issued on; torch's own kernels and allocations follow (current stream)."""
+        self._lane = index
+        torch.cuda.set_stream(self._lane_streams[index])
 
     def scratch(self, M: int, N: int) -> torch.Tensor:
         need = int(self.lib.some_train_scratch_bytes(self.h, M, N))
-        if self._scratch is None or self._scratch.numel() < need:
-            self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._scratch
+        buf = self._scratch.get(self._lane)
+        if buf is None or buf.numel() < need:
+            buf = self._scratch[self._lane] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return buf
+
+    def partial(self, need: int) -> torch.Tensor:
+        """Partial-plane buffer of the split-K weight-gradient GEMMs, one per lane."""
+        buf = self._partials.get(self._lane)
+        if buf is None or buf.numel() < need:
+            buf = self._partials[self._lane] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return buf
 
     def check(self, rc):
         _lib.check(self.h, rc)
@@ -321,11 +411,9 @@ class TrainOps:
             # accumulated in the kernel's staging registers into column K of the output
             ldc = K + (4 if with_bias else 0)
             out = self.new(N, ldc)
-            need = int(self.lib.some_train_gemm16_bytes(self.h, N, K, M, ldc))
-            if self._partial is None or self._partial.numel() < need:
-                self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
+            part = self.partial(int(self.lib.some_train_gemm16_bytes(self.h, N, K, M, ldc)))
             self.check(self.lib.some_train_gemm16(self.h, _p(dy), N, 1, _p(x), K, 1, None, _p(out), ldc, N, K, M, self._op16,
-                                                  K if with_bias else -1, _p(self._partial), self._partial.numel(), self.stream()))
+                                                  K if with_bias else -1, _p(part), part.numel(), self.stream()))
             if not with_bias:
                 return out, None
             return out[:, :K].contiguous(), out[:, K].contiguous()
@@ -347,10 +435,8 @@ class TrainOps:
         Kx = K + extra
         out = self.new(N, Kx)
         if use3:
-            need = int(self.lib.some_train_gemm_splitk_bytes(self.h, N, Kx, Mp))
-            if self._partial is None or self._partial.numel() < need:
-                self._partial = torch.empty(need, dtype=torch.uint8, device=self.device)
-            self.check(self.lib.some_train_gemm_splitk(self.h, _p(dyt), Mp, _p(xt), _p(out), N, Kx, Mp, self._hi_mode, _p(self._partial), self._partial.numel(),
+            part = self.partial(int(self.lib.some_train_gemm_splitk_bytes(self.h, N, Kx, Mp)))
+            self.check(self.lib.some_train_gemm_splitk(self.h, _p(dyt), Mp, _p(xt), _p(out), N, Kx, Mp, self._hi_mode, _p(part), part.numel(),
                                                        self.stream()))
         else:
             self.check(self.lib.some_op_gemm(self.h, _lib.EPI_NONE, _p(dyt), Mp, _p(xt), None, None, Kx, _p(out), Kx, N, Kx, Mp, 1.0, 0, None, 0,
@@ -501,14 +587,27 @@ class Tape:
         self.ops = ops
         self.records = []
         self.produced = set()
+        self.lane_of = {}             # id(tensor) -> the lane that produced it (absent: lane 0, or ready before the pass began)
 
     def apply(self, fn, *args):
         ctx = _Ctx()
         produced = self.produced
+        ops = self.ops
+        lane = ops._lane
+        if ops.lanes == 2:
+            lane_of = self.lane_of
+            for a in args:                                      # operands produced on the other lane: order the streams
+                if isinstance(a, torch.Tensor):
+                    src = lane_of.get(id(a))
+                    if src is not None and src[0] != lane:
+                        ops.adopt(a, src[0], src[1])
         ctx.needs_input_grad = needs = tuple(isinstance(a, torch.Tensor) and (a.requires_grad or id(a) in produced) for a in args)
         out = fn.forward(ctx, *args)
+        ops._lane_version[lane] += 1
+        if ops.lanes == 2 and isinstance(out, torch.Tensor):
+            self.lane_of[id(out)] = (lane, ops._lane_version[lane])
         if True in needs:
-            self.records.append((fn, ctx, args, out))
+            self.records.append((fn, ctx, args, out, lane))
             produced.add(id(out))
         return out
 
@@ -516,14 +615,22 @@ class Tape:
         """seeds: (tensor, gradient) pairs - the losses with their weights."""
         grads = {}
         for t, g in seeds:
-            grads[id(t)] = g if id(t) not in grads else grads[id(t)] + g
+            grads[id(t)] = (g, 0) if id(t) not in grads else (grads[id(t)][0] + g, 0)
         records, ops = self.records, self.ops
+        two = ops.two_lanes()
         while records:
-            fn, ctx, args, out = records.pop()                  # releases the saved activations as the pass moves on
-            g = grads.pop(id(out), None)
-            if g is None:
+            fn, ctx, args, out, lane = records.pop()            # releases the saved activations as the pass moves on
+            entry = grads.pop(id(out), None)
+            if entry is None:
                 continue                                        # an output nothing differentiable consumed
-            for a, ga, need in zip(args, fn.backward(ctx, g), ctx.needs_input_grad):
+            g, g_lane = entry
+            if two and lane != ops._lane:
+                ops._enter_lane(lane)
+            if g_lane != lane and isinstance(g, torch.Tensor):
+                ops.adopt(g, g_lane)
+            results = fn.backward(ctx, g)
+            ops._lane_version[lane] += 1
+            for a, ga, need in zip(args, results, ctx.needs_input_grad):
                 if ga is None or not need:
                     continue
                 if a.requires_grad:                             # a parameter: accumulate where autograd's AccumulateGrad would
@@ -531,11 +638,50 @@ class Tape:
                         a.grad = ga.clone()
                     else:
                         a.grad.add_(ga)
+                    ops._lane_version[lane] += 1
                     ops.deposited(a)
                 else:
                     prev = grads.get(id(a))
-                    grads[id(a)] = ga if prev is None else prev + ga
+                    if prev is None:
+                        grads[id(a)] = (ga, lane)
+                    else:
+                        if prev[1] != lane:
+                            ops.adopt(prev[0], prev[1])
+                        grads[id(a)] = (prev[0] + ga, lane)
+                        ops._lane_version[lane] += 1
+        if two:
+            ops._enter_lane(0)
+            ops.join_lanes()
         self.produced.clear()
+        self.lane_of.clear()
+
+
+class _Lane:
+    """``with ops.lane(i, after=event)``: see TrainOps.lane."""
+
+    def __init__(self, ops: 'TrainOps', index: int, after):
+        self.ops, self.index, self.after = ops, index, after
+        self.prev = None
+
+    def __enter__(self):
+        ops = self.ops
+        self.prev = ops._lane
+        if self.index != self.prev:
+            if self.after is not None:
+                event, src, version = self.after
+                ops._lane_streams[self.index].wait_event(event)
+                ops._fork_cover = (src, version)
+            else:
+                ops._lane = self.index
+                ops.wait_lane(self.prev)
+            ops._enter_lane(self.index)
+        return self
+
+    def __exit__(self, *exc):
+        if self.index != self.prev:
+            self.ops._fork_cover = None
+            self.ops._enter_lane(self.prev)
+        return False
 
 
 class _CatRows(torch.autograd.Function):

@@ -81,6 +81,9 @@ class MIDIExtractionTrainer:
         # post-accumulate hook even when backward returned None for it, so mark() + hook counted every sunk parameter twice and buckets
         # were all-reduced when half of their gradients were in the buffer.  BucketedGradSync now ignores that echo and raises on any
         # other double report - tests/test_train_host.py::test_gradient_sync_mark_stands_in_for_the_hook.)
+        if self.grad_sync is not None:
+            # a bucket holds gradients written on both lanes (ops.py): its all-reduce is ordered behind the issuing lane's stream only
+            self.grad_sync.before_launch = self.ops.sync_other_lane
         if config.get('some_amd_grad_sinks', True):
             self.ops.register_grad_sinks(self.model.params.views.values(), self.grad_sync.mark if self.grad_sync is not None else None)
 
