@@ -36,6 +36,10 @@ constexpr float kPShift = 14.f;                 // P is carried as 2^kPShift p <
 
 __device__ __forceinline__ float exp2_(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Round 4, measured and not kept (tools/patches/r04_attention_psplit_fma_mix.patch, profiles/r04_experiments.md): the P split as four
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 per two probabilities instead of and / and / sub / sub / cvt_pkrtz / cvt_pkrtz - 64 instead of 96 VALU
+// instructions per key tile, and 2.55 vs 2.40 ms (the mix instructions write one half of their destination: a read-modify-write chain per
+// dword, and they do not issue at the plain-VALU rate next to MFMAs).
 // Measured and not kept (profiles/r02_experiments.md; the switches live in the git history, not in the shipped source): lazy rescale
 // (2.59 vs 2.53 ms), packed-fp32 softmax (2.59), global loads pinned to the head of the step (noise), 64 queries per wavefront at
 // one wavefront per SIMD (3.21 vs 2.62), priority over QK + softmax instead of PV (+1 %).  Kept: V^T tiles through buffer loads,
