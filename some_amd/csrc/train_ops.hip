@@ -179,10 +179,21 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // owns kLnChunk rows, its
 // wavefront w the rows w, w + 8, ...; every lane keeps the running sums of its 8 columns, the eight wavefronts' sums are combined in a fixed
 // tree through LDS and written as partial[chunk][2][512] for col_final_kernel (fixed order: deterministic).
-constexpr int kLnChunk = 128, kLnWaves = 8;
+// Rows per workgroup (round 4): 128 filled 13 % of the CUs at the reference's batch shape (4 160 frames -> 33 workgroups, 30 us per call for
+// 25 MB of traffic), so the chunk shrinks with M - 16 rows up to 8 192 frames, 64 up to 16 384, else 128; the partial
+// planes are summed in chunk order whatever their number (deterministic for a given M).  Measured (interleaved, two lanes): 8 x 520 frames
+// 9.7 -> 9.2 ms per step with 16-row chunks; at 8 x 2584 frames 128 rows stay best (26.5 - 27.0 ms vs 27.5 - 28.0 with 32, 27.0 - 27.4 with 64:
+// the two lanes' kernels fill the CUs together and more partial planes only add work).
+constexpr int kLnWaves = 8;
+#ifdef LN_CHUNK_FIXED                 // (tools/build_variant.py A/B builds)
+inline int ln_chunk_rows(int) { return LN_CHUNK_FIXED; }
+#else
+inline int ln_chunk_rows(int M) { return M <= 8192 ? 16 : M <= 16384 ? 64 : 128; }
+#endif
 __global__ __launch_bounds__(64 * kLnWaves) void ln_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ g,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const float* __restrict__ add, float* __restrict__ dx, float* __restrict__ partial, int M) {
+                                                            const float* __restrict__ add, float* __restrict__ dx, float* __restrict__ partial, int M,
+                                                            int kLnChunk) {
     // add (may be null): a second gradient of x - the residual branch around the LayerNorm - summed into dx here instead of by a
     // separate pass; (ln gradient) + add as its own rounding step (no FMA), i.e. the bits a separate addition would give
     __shared__ float red[2][kLnWaves][kLnDim];
@@ -425,7 +436,7 @@ constexpr int kDwChunk = 64;
 __global__ __launch_bounds__(256) void dwconv_bwd_w_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                     const int32_t* __restrict__ clip_of_row, const int32_t* __restrict__ frame_offsets,
                                                                     int M, int C, float* __restrict__ partial) {
-    __shared__ float red[4][64];
+    __shared__ float red[4][kTaps][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
     const int r0 = blockIdx.y * kDwChunk, r1 = min(M, r0 + kDwChunk);
     float acc[kTaps];
@@ -461,15 +472,15 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_partial_kernel(const float* 
             }
         }
     }
-    for (int k = 0; k < kTaps; ++k) {
-        red[ty][threadIdx.x & 63] = acc[k];
-        __syncthreads();
-        if (ty == 0 && c < C) {
-            const int l = threadIdx.x;
-            partial[((size_t)blockIdx.y * kTaps + k) * C + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
-        }
-        __syncthreads();
-    }
+    // the four wavefronts' sums of all 31 taps through LDS in ONE exchange (round 4: a barrier pair per tap - 62 barriers - was most of the
+    // kernel's 72 us); wavefront ty then combines the taps k = ty, ty + 4, ... in the same fixed tree (0 + 1) + (2 + 3)
+    const int l = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) red[ty][k][l] = acc[k];
+    __syncthreads();
+    if (c < C)
+        for (int k = ty; k < kTaps; k += 4)
+            partial[((size_t)blockIdx.y * kTaps + k) * C + c] = (red[0][k][l] + red[1][k][l]) + (red[2][k][l] + red[3][k][l]);
 }
 __global__ __launch_bounds__(256) void dwconv_bwd_w_final_kernel(const float* __restrict__ partial, int P, int n, float* __restrict__ dw, int accumulate) {
     // 64 elements per workgroup, wavefront g sums the chunks p = g, g + 4, ... in ascending order, combined as (0 + 1) + (2 + 3)
@@ -656,7 +667,10 @@ hipError_t launch_reduce_wgrad(const float* partial, int slices, size_t stride, 
 // ---- launchers -----------------------------------------------------------------------------------------------------------
 static inline int n_chunks(int M) { return (M + kChunkRows - 1) / kChunkRows; }
 size_t train_col_scratch_bytes(int M, int N) { return (size_t)n_chunks(M) * 2 * N * sizeof(float); }
-size_t train_ln_scratch_bytes(int M) { return (size_t)((M + 127) / 128) * 2 * 512 * sizeof(float); }      // ln_bwd_fused_kernel: 128-row chunks
+size_t train_ln_scratch_bytes(int M) {      // ln_bwd_fused_kernel: one [2][512] partial plane per chunk of ln_chunk_rows(M) rows
+    const int chunk = ln_chunk_rows(M);
+    return (size_t)((M + chunk - 1) / chunk) * 2 * 512 * sizeof(float);
+}
 size_t train_dwconv_w_scratch_bytes(int M, int C) { return (size_t)((M + kDwChunk - 1) / kDwChunk) * kTaps * C * sizeof(float); }
 
 hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, int split_out, hipStream_t s) {
@@ -698,8 +712,9 @@ hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, void* y
 hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, const float* add, float* dx,
                          float* dgamma, float* dbeta, int accumulate, int M, float* scratch, hipStream_t s) {
     if (M <= 0) return hipSuccess;
-    const int P = (M + kLnChunk - 1) / kLnChunk;
-    hipLaunchKernelGGL(ln_bwd_fused_kernel, dim3((unsigned)P), dim3(64 * kLnWaves), 0, s, dy, x, g, mean, rstd, add, dx, scratch, M);
+    const int chunk = ln_chunk_rows(M);
+    const int P = (M + chunk - 1) / chunk;
+    hipLaunchKernelGGL(ln_bwd_fused_kernel, dim3((unsigned)P), dim3(64 * kLnWaves), 0, s, dy, x, g, mean, rstd, add, dx, scratch, M, chunk);
     hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)(kLnDim / 64)), dim3(256), 0, s, scratch, P, kLnDim, dbeta, dgamma, accumulate);
     return hipGetLastError();
 }
