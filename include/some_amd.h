@@ -145,7 +145,10 @@ size_t some_workspace_bytes(const SomeHandle* h, int64_t total_frames, int32_t B
  * masked_fill on the midi stream, Gconform.py:126-132), NULL = all ones (what inference passes).
  * Outputs: midi_dev [total_frames, outdim], bound_dev [total_frames] (already sigmoid).
  * workspace_dev: at least some_workspace_bytes(total_frames, B) bytes, 256-byte aligned.  total_frames <= 262143 per call
- * (50 minutes of audio; SOME_EINVAL beyond - split the batch).
+ * (50 minutes of audio; SOME_EINVAL beyond - split the batch); in f16x3 mode additionally total_frames + 15 * B < 1 048 450.
+ * Batch invariance: clip b's output rows depend on clip b alone - the same bits whether it is passed alone, at any position of a packed
+ * batch or beside any neighbours (the reference runs every chunk by itself, inference/base_infer.py:46-53): attention key tiles are
+ * counted from the clip's own first frame, every other kernel is row- or clip-local.
  * Streams: everything is ordered after the work already on `stream` and complete before anything enqueued on it
  * afterwards.  Inside, the two model streams of a layer (midi / bound, Gconform.py:82-87) run on `stream` and on a helper
  * stream the handle owns, forked and joined with events around every layer (SOME_AMD_DUAL_STREAM=0, kernel profiling, or a

@@ -543,6 +543,9 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
     if (workspace_bytes < some_workspace_bytes(h, total_frames, B)) return fail(h, SOME_ENOMEM, "some_forward: workspace too small");
     if (reinterpret_cast<uintptr_t>(workspace_dev) & 255) return fail(h, SOME_EINVAL, "some_forward: workspace must be 256-byte aligned");
     if ((size_t)B * kHeads * kStreams > 0x7fffffffu / 64) return fail(h, SOME_EINVAL, "some_forward: B too large");
+    // the attention operands live in clip-aligned rows (every clip padded to a multiple of 16 rows) behind 2 GiB buffer descriptors of 2 KiB rows
+    if (h->precision == SOME_PRECISION_F16X3 && attn_rows_cover(total_frames, B) > 1048575)
+        return fail(h, SOME_EINVAL, "some_forward: too many short clips in one call (total_frames + 15 * B must stay below 1048450; split the batch)");
 
     const SomeConfig& c = h->cfg;
     const ArenaLayout& L = h->lay;

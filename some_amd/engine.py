@@ -267,6 +267,9 @@ class Engine:
         if m > MAX_FORWARD_FRAMES:
             raise ValueError(f'{m} frames in one forward call: the library takes at most {MAX_FORWARD_FRAMES} (32-bit byte offsets into '
                              f'the [frames, 2048] hidden activations; about 50 minutes of audio) - pack fewer clips per batch, or cut the clip')
+        if m + 15 * batch.B >= 1048450:
+            raise ValueError(f'{batch.B} clips / {m} frames in one forward call: the attention operands (every clip padded to a multiple of 16 rows) '
+                             f'must stay below 1 048 450 rows - pack fewer clips per batch')
         midi = torch.empty((m, self.outdim), dtype=torch.float32, device=self.device)
         bound = torch.empty((m,), dtype=torch.float32, device=self.device)
         mask_u8 = None

@@ -97,6 +97,14 @@ def test_forward_requires_weights_and_gpu_pointers():
     mc = (1000 + 15 * 1000 + 126) // 64 * 64
     assert lib.some_workspace_bytes(eng.handle, 1000, 1000) >= 2 * (1000 * 512 * 3 * 4 + mc * 4096 + 2048 * mc) + 4 * mc
     assert lib.some_op_qkv_attention_f16x3_bytes(2584, 1) >= 2688 * 4096 + 2048 * 2688 + 4 * 2688
+    # argument checks that need no GPU: with an (unused) arena pointer attached, oversized batches are refused before anything is launched
+    import ctypes as C
+    fake = C.c_void_p(1 << 20)
+    assert lib.some_attach_arena(eng.handle, fake, lib.some_arena_bytes(eng.handle)) == _lib.SOME_OK
+    assert lib.some_forward(eng.handle, fake, fake, 1, 262144, 262144, None, 0, fake, fake, fake, 1 << 40, None) == _lib.SOME_EINVAL
+    assert b'total_frames too large' in lib.some_last_error(eng.handle)
+    assert lib.some_forward(eng.handle, fake, fake, 70000, 70000, 1, None, 0, fake, fake, fake, 1 << 40, None) == _lib.SOME_EINVAL
+    assert b'too many short clips' in lib.some_last_error(eng.handle)
     assert lib.some_decode_scratch_bytes(eng.handle, 1000) >= 1000 * 13
 
 
