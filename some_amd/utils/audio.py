@@ -165,8 +165,8 @@ def _read_pcm16_mono(path, sr: int, pool: 'PcmPool' = None):
                     return None
                 fmt_ok = True
             elif tag == b'data':
-                if not fmt_ok or size % 2 or size == 0:
-                    return None
+                if not fmt_ok or size % 2 or size == 0 or pos + 8 + size > os.fstat(fd).st_size:
+                    return None                    # (a streamed / truncated file: no buffer is allocated for a size the file does not have)
                 data = pool.take(size // 2) if pool is not None else np.empty(size // 2, dtype='<i2')
                 if os.preadv(fd, [memoryview(data).cast('B')], pos + 8) != size:
                     if pool is not None:
