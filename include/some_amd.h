@@ -368,6 +368,14 @@ int some_train_adamw(SomeHandle* h, float* param_dev, const float* grad_dev, flo
                      int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                      float grad_scale, void* stream);
 
+/* The same AdamW step with Lightning's gradient_clip_val (torch.nn.utils.clip_grad_norm_; configs/base.yaml:49, train.py:88) applied on the
+ * DEVICE: grad_scale = min(1, clip_norm / (sqrt(*sumsq_dev) / grad_denominator + 1e-6)) / grad_denominator in IEEE double arithmetic, where
+ * *sumsq_dev is some_train_sumsq's result for the (summed, scaled) gradient and grad_denominator = world_size * loss_scale; clip_norm 0 = no
+ * clipping.  A non-finite *sumsq_dev leaves parameters and moments untouched.  Lets a training step end without a host synchronisation. */
+int some_train_adamw_clip(SomeHandle* h, float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
+                          int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                          const double* sumsq_dev, double clip_norm, double grad_denominator, void* stream);
+
 /* F.scaled_dot_product_attention (8 heads x 64, scale 1/8, per clip, unmasked; base_attention.py:34-44) on the fused
  * projection output qkv [M, 1536] (q | k | v), exact fp32 MFMA.  Forward also writes lse_dev [8, M] (base-2
  * log-sum-exp per head and frame) for the backward; backward recomputes the probabilities flash-style and writes

@@ -102,6 +102,8 @@ SYMBOLS = {
     'some_train_binary_emd': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, C.c_size_t, _P]),
     'some_train_sumsq': (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_size_t, _P]),
     'some_train_adamw': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, _P]),
+    'some_train_adamw_clip': (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, _P, C.c_double,
+                                       C.c_double, _P]),
     'some_train_attention_fwd': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     'some_train_attention_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     'some_train_attention_fwd_f16x3': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),

@@ -240,6 +240,8 @@ hipError_t launch_emd(const float* pred, const float* gt, int B, int T, float* d
 hipError_t launch_sumsq(const float* x, int64_t n, double* out, double* scratch, hipStream_t s);
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                         int step, float grad_scale, hipStream_t s);
+hipError_t launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int step, const double* sumsq, double clip, double denom, hipStream_t s);
 
 // ---- profiling ------------------------------------------------------------------------------------
 struct ProfRecord { std::string name; hipEvent_t e0, e1; double flops, bytes; };

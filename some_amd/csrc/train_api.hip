@@ -424,6 +424,18 @@ int some_train_adamw(SomeHandle* h, float* param_dev, const float* grad_dev, flo
     return SOME_OK;
 }
 
+int some_train_adamw_clip(SomeHandle* h, float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
+                          int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                          const double* sumsq_dev, double clip_norm, double grad_denominator, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, n >= 0 && step >= 1 && grad_denominator > 0.0 && clip_norm >= 0.0, "some_train_adamw_clip: bad argument (step counts from 1)");
+    if (n == 0) return SOME_OK;
+    T_CHECK(h, param_dev && grad_dev && exp_avg_dev && exp_avg_sq_dev && sumsq_dev, "some_train_adamw_clip: null pointer");
+    T_TRY(h, launch_adamw_clip(param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, n, lr, beta1, beta2, eps, weight_decay, step, sumsq_dev, clip_norm,
+                               grad_denominator, st(stream)));
+    return SOME_OK;
+}
+
 int some_train_attention_fwd(SomeHandle* h, const float* qkv_dev, const int32_t* frame_offsets_dev, int32_t B,
                              int32_t max_frames, int32_t M, float* out_dev, float* lse_dev, void* stream) {
     if (!h) return SOME_EINVAL;

@@ -603,6 +603,29 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     p[i] = pi - (lr / bc1) * (mi / denom);
 }
 
+// The same update with the gradient scale taken from DEVICE memory: grad_scale = min(1, clip / (sqrt(sumsq) / denom + 1e-6)) / denom - the
+// trainer's clip_grad_norm arithmetic (torch.nn.utils.clip_grad_norm_; task.py) in the same IEEE double operations, so the step needs no
+// host readback of the gradient norm.  A non-finite sumsq leaves everything untouched (the host finds out one step later).
+__global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                          int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                                          float bc1, float bc2_sqrt, const double* __restrict__ sumsq, double clip, double denom) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double ss = *sumsq;
+    if (!(ss == ss) || ss == INFINITY) return;
+    const double norm = sqrt(ss) / denom;
+    const double coef = clip > 0.0 ? fmin(1.0, clip / (norm + 1e-6)) : 1.0;
+    const float grad_scale = (float)(coef / denom);
+    const float gi = g[i] * grad_scale;
+    float pi = p[i] * (1.f - lr * weight_decay);
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float den = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / den);
+}
+
 }  // namespace
 
 // out[i] = sum over slices of partial[s][i] (split-K partial planes), slice order
@@ -808,6 +831,15 @@ hipError_t launch_sumsq(const float* x, int64_t n, double* out, double* scratch,
     const int blocks = n <= 0 ? 1 : (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, scratch);
     hipLaunchKernelGGL(sum_partials_f64_kernel, dim3(1), dim3(64), 0, s, scratch, blocks, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int step, const double* sumsq, double clip, double denom, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_clip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1,
+                       sqrtf(bc2), sumsq, clip, denom);
     return hipGetLastError();
 }
 

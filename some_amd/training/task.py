@@ -3,6 +3,7 @@ training/base_task.py optimiser wiring, lr_scheduler/scheduler.py:42-59, configs
 training operators.  Data-parallel: one process per GPU, gradients summed with ONE all-reduce of the flat gradient
 buffer (RCCL over xGMI on the GPUs, gloo in the CPU tests) and averaged inside the fused AdamW launch."""
 import ctypes as C
+import math
 import os
 import time
 from typing import Dict, Optional
@@ -59,6 +60,10 @@ class MIDIExtractionTrainer:
         self.growth_interval = int(config.get('some_amd_loss_scale_growth_interval', 200))
         self._clean_steps = 0
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=self.ops.device)
+        # training_step(sync=False): gradient-norm checks of updates that have been enqueued but not looked at yet - (event, pinned copy of
+        # the squared norm, step) - at most ``_max_in_flight`` of them
+        self._pending = []
+        self._max_in_flight = 2
         # SOME_AMD_TRAIN_TAPE=0 / some_amd_tape: false: forward + backward through torch.autograd (A/B runs; same kernels, same gradients)
         self.use_tape = bool(config.get('some_amd_tape', True)) and os.environ.get('SOME_AMD_TRAIN_TAPE', '1') != '0'
         self.host_enqueue_s = 0.0                 # cumulative host time spent enqueuing training steps (up to the step's one sync)
@@ -103,18 +108,39 @@ class MIDIExtractionTrainer:
             losses['midi_loss'] = self.ops.bce_with_logits(probs, sample['probs'].reshape(B * T, -1).float())
         return losses
 
-    def training_step(self, sample) -> Dict[str, float]:
+    def training_step(self, sample, sync: bool = True) -> Dict[str, float]:
         """One optimiser update: forward, losses, backward, gradient all-reduce, AdamW with the WarmupLR rate.  A list of
         batches is one update over ``accumulate_grad_batches`` micro-batches (configs/base.yaml:50, train.py:89): their
-        gradients accumulate in the flat buffer, each loss weighted 1 / n as Lightning does."""
+        gradients accumulate in the flat buffer, each loss weighted 1 / n as Lightning does.
+
+        ``sync=False`` (honoured when no loss scaling is active: bf16 operands or exact-f32 GEMMs): the update is enqueued WITHOUT reading the
+        gradient norm back - the clip factor is computed on the device (some_train_adamw_clip: the same double arithmetic, bit-identical
+        parameters) - so the host goes on to enqueue the next step while this one's tail runs; the returned losses are device tensors,
+        ``grad_norm`` is None, and a non-finite gradient (which leaves the parameters untouched) raises FloatingPointError from a LATER
+        call or from ``flush()``.  At most two updates are in flight."""
         t_begin = time.perf_counter()
         self.ops.pin_stream()
         try:
-            return self._training_step(sample, t_begin)
+            return self._training_step(sample, t_begin, sync)
         finally:
             self.ops.unpin_stream()
 
-    def _training_step(self, sample, t_begin) -> Dict[str, float]:
+    def flush(self):
+        """Wait for the updates enqueued with ``sync=False`` and raise if one of them saw a non-finite gradient."""
+        self._check_pending(block=True)
+
+    def _check_pending(self, block: bool, keep: int = 0):
+        while len(self._pending) > keep:
+            ev, host, step = self._pending[0]
+            if not block and not ev.query():
+                return
+            ev.synchronize()
+            self._pending.pop(0)
+            v = float(host[0])
+            if not (v == v and v != float('inf')):
+                raise FloatingPointError(f'non-finite gradient in update {step} (its parameters were left untouched)')
+
+    def _training_step(self, sample, t_begin, sync: bool = True) -> Dict[str, float]:
         P = self.model.params
         P.zero_grad()
         self.model.train()
@@ -153,6 +179,27 @@ class MIDIExtractionTrainer:
         sc = self.ops.scratch(1, 1)
         self.ops.check(self.ops.lib.some_train_sumsq(self.ops.h, C.c_void_p(P.grad.data_ptr()), P.numel, C.c_void_p(self._sumsq.data_ptr()),
                                                      C.c_void_p(sc.data_ptr()), sc.numel(), self.ops.stream()))
+        clip = self.config.get('clip_grad_norm', None)
+        if not sync and scale == 1.0:
+            self._check_pending(block=False)
+            self._check_pending(block=True, keep=self._max_in_flight - 1)       # bounded run-ahead
+            lr = warmup_lr(self.global_step + 1, self.base_lr, self.warmup_steps, self.min_lr)
+            self.global_step += 1
+            p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+            self.ops.check(self.ops.lib.some_train_adamw_clip(self.ops.h, p(P.flat), p(P.grad), p(self.exp_avg), p(self.exp_avg_sq), P.numel, lr,
+                                                              self.betas[0], self.betas[1], self.eps, self.weight_decay, self.global_step,
+                                                              p(self._sumsq), float(clip or 0.0), float(self.world * scale), self.ops.stream()))
+            self.ops.weights_version += 1
+            host = torch.empty(1, dtype=torch.float64).pin_memory()
+            host.copy_(self._sumsq, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending.append((ev, host, self.global_step))
+            self.host_enqueue_s += time.perf_counter() - t_begin
+            out = dict(losses)
+            out.update(total_loss=total, lr=lr, grad_scale=scale, skipped=False, grad_norm=None)
+            return out
+        self._check_pending(block=True)
         self.host_enqueue_s += time.perf_counter() - t_begin      # host time to enqueue the step, up to its one synchronisation
         sumsq = float(self._sumsq.item())
         skipped = False
@@ -162,12 +209,11 @@ class MIDIExtractionTrainer:
                 raise FloatingPointError('non-finite gradient')
             self.loss_scale, self._clean_steps, skipped = scale * 0.5, 0, True
         else:
-            grad_norm = sumsq ** 0.5 / (scale * self.world)
+            grad_norm = math.sqrt(sumsq) / (scale * self.world)       # (sqrt: correctly rounded, as on the device - adamw_clip_kernel)
             if scale != 1.0:
                 self._clean_steps += 1
                 if self._clean_steps % self.growth_interval == 0 and self.loss_scale < 2.0 ** 24:
                     self.loss_scale = scale * 2.0
-        clip = self.config.get('clip_grad_norm', None)
         clip_coef = min(1.0, clip / (grad_norm + 1e-6)) if (clip and not skipped) else 1.0       # torch.nn.utils.clip_grad_norm_
         lr = warmup_lr(self.global_step + 1, self.base_lr, self.warmup_steps, self.min_lr)
         if not skipped:
@@ -190,6 +236,7 @@ class MIDIExtractionTrainer:
         """Lightning-layout checkpoint: ``state_dict`` with the ``model.`` prefix (what the inference classes read) plus
         everything needed to continue bit-identically: step, flat AdamW moments, loss-scale state, dropout call counter."""
         P = self.model.params
+        self.flush()
         return {
             'state_dict': {'model.' + k: v.cpu() for k, v in P.state_dict().items()},
             'global_step': self.global_step,
@@ -219,6 +266,7 @@ class MIDIExtractionTrainer:
     def sync_eval_engine(self):
         """Pack the current parameters (+ BatchNorm running statistics) into the inference engine: evaluation runs
         the INFERENCE kernels - eval-mode semantics (dropout off, BatchNorm folded from running stats) for free."""
+        self.flush()
         self.engine.load_state_dict({k: v.cpu() for k, v in self.model.params.state_dict().items()})
 
     @torch.no_grad()

@@ -444,3 +444,43 @@ def test_two_lanes_equal_one_lane_bit_for_bit(precision):
         assert a['grad_norm'] == b['grad_norm']
     assert torch.equal(g2, g1) and torch.equal(p2, p1)
     assert all(torch.equal(b2[k], b1[k]) for k in b1)
+
+
+@pytest.mark.parametrize('precision', ['bf16', None])
+def test_update_without_host_sync_equals_the_synchronous_one(precision):
+    """training_step(sync=False): the clip factor of Lightning's gradient_clip_val is computed on the device from the gradient norm
+    (some_train_adamw_clip) instead of on the host after a readback - the same IEEE double operations, so parameters and optimiser moments
+    after five updates (clipping active: the first norms are far above clip_grad_norm 1) are bit-identical; a non-finite gradient leaves the
+    parameters untouched and raises at flush()."""
+    from some_amd.training.task import MIDIExtractionTrainer
+    cfg = get_config('two_head_model', lay=2) if precision else dict(_cfg(), some_amd_precision='f32')
+    if precision:
+        cfg = dict(cfg, pl_trainer_precision=precision)
+    outs = []
+    for sync in (True, False):
+        tr = MIDIExtractionTrainer(cfg, device='cuda', seed=3)
+        assert tr.loss_scale == 1.0
+        norms = []
+        for i in range(5):
+            out = tr.training_step(_sample() if i % 2 == 0 else [_sample(), _sample()], sync=sync)
+            norms.append(out['grad_norm'])
+            assert (out['grad_norm'] is None) == (not sync) and not out['skipped']
+        tr.flush()
+        torch.cuda.synchronize()
+        assert tr.global_step == 5
+        outs.append((tr.model.params.flat.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), norms))
+    (p1, m1, v1, norms), (p0, m0, v0, _) = outs
+    assert max(norms) > 1.0                                      # clipping was exercised
+    assert torch.equal(p1, p0) and torch.equal(m1, m0) and torch.equal(v1, v0)
+    # a poisoned gradient: the asynchronous update is skipped on the device and reported afterwards
+    tr = MIDIExtractionTrainer(cfg, device='cuda', seed=3)
+    tr.training_step(_sample(), sync=False)
+    tr.flush()
+    before = tr.model.params.flat.clone()
+    bad = dict(_sample())
+    bad['units'] = bad['units'].clone()
+    bad['units'][0, 0, 0] = float('nan')
+    tr.training_step(bad, sync=False)
+    with pytest.raises(FloatingPointError, match='non-finite gradient'):
+        tr.flush()
+    assert torch.equal(tr.model.params.flat, before)

@@ -24,7 +24,7 @@ sys.path.insert(0, str(ROOT))
 
 
 def run(data_dir, precision='bf16', max_batch_frames=80000, max_batch_size=8, workers=4, prefetch_factor=2, max_steps=None, device='cuda:0',
-        world=1, rank=0):
+        world=1, rank=0, sync=False):
     from some_amd.configs import get_config
     from some_amd.training import data
     from some_amd.training.loader import PrefetchLoader
@@ -59,16 +59,18 @@ def run(data_dir, precision='bf16', max_batch_frames=80000, max_batch_size=8, wo
     t0 = time.perf_counter()
     last = t0
     for mb, idx in zip(loader.batches(plan), plan):
-        out = trainer.training_step(mb)                       # ends with the step's one host sync (gradient norm)
+        out = trainer.training_step(mb, sync=sync)            # as train.py runs it: no host synchronisation per update (sync=True: one)
         now = time.perf_counter()
         step_ms.append((now - last) * 1e3)
         last = now
         skipped += bool(out['skipped'])
-        losses.append(float(out['total_loss']))
+        losses.append(out['total_loss'])                      # a device tensor: read after the epoch
         frames_valid += int(sum(train_set.sizes[i] for i in idx))
         frames_padded += int(mb['units'].shape[0] * mb['units'].shape[1])
+    trainer.flush()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    losses = [float(v) for v in losses]
     loader.close()
     st = loader.stats
     ms = np.asarray(step_ms)
@@ -82,6 +84,7 @@ def run(data_dir, precision='bf16', max_batch_frames=80000, max_batch_size=8, wo
                     f'{len(train_set)} items, {int(train_set.sizes.sum()) * hop_s / 3600:.2f} h; DsBatchSampler max_batch_frames {max_batch_frames}, '
                     f'max_batch_size {max_batch_size}; one epoch{" (truncated)" if max_steps else ""}',
         'n_gpus': world, 'updates': len(step_ms), 'skipped_updates': skipped, 'epoch_wall_s': round(wall, 3),
+        'host_sync_per_update': bool(sync),
         'audio_s_per_s_trained': round(frames_valid * hop_s / wall, 1), 'frames_per_s': round(frames_valid / wall, 1),
         'padding_overhead': round(frames_padded / max(frames_valid, 1), 4),
         'step_ms': {'mean': round(float(ms.mean()), 2), 'p10': round(float(np.percentile(ms, 10)), 2), 'p50': round(float(np.percentile(ms, 50)), 2),
@@ -104,12 +107,13 @@ def main():
     ap.add_argument('--workers', type=int, default=4)
     ap.add_argument('--prefetch_factor', type=int, default=2)
     ap.add_argument('--max_steps', type=int, default=None)
+    ap.add_argument('--sync', action='store_true', help='read the gradient norm back after every update (round-3 behaviour)')
     a = ap.parse_args()
     world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     if world > 1:
         torch.distributed.init_process_group(os.environ.get('SOME_AMD_DIST_BACKEND', 'nccl'))
-    res = run(a.dir, a.precision, a.max_batch_frames, a.max_batch_size, a.workers, a.prefetch_factor, a.max_steps, f'cuda:{local}', world, rank)
+    res = run(a.dir, a.precision, a.max_batch_frames, a.max_batch_size, a.workers, a.prefetch_factor, a.max_steps, f'cuda:{local}', world, rank, a.sync)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -135,7 +135,9 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
     t_train = time.perf_counter()
 
     def update(micro):
-        out = trainer.training_step(micro if len(micro) > 1 else micro[0])
+        # sync=False: no gradient-norm readback per update where no loss scaling is active (bf16 / exact-f32) - the host enqueues the next
+        # step while this one's tail runs; the losses below are device tensors, read only on the steps that print or log them
+        out = trainer.training_step(micro if len(micro) > 1 else micro[0], sync=False)
         step = trainer.global_step
         if rank == 0 and (step % log_interval == 0 or step == total):
             print(f'step {step}: ' + ', '.join(f'{k}={float(v):.5f}' for k, v in out.items() if k.endswith('loss')) +
@@ -170,6 +172,7 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
             # fewer than accumulate_grad_batches micro-batches left at the end of the epoch: Lightning steps the optimiser on what has
             # accumulated (DsBatchSampler pads the batch count to a multiple, so this is for resumed / sliced plans)
             update(micro)
+    trainer.flush()
     torch.cuda.synchronize()
     if rank == 0:
         wall = time.perf_counter() - t_train
