@@ -64,6 +64,7 @@ class MIDIExtractionTrainer:
         # the squared norm, step) - at most ``_max_in_flight`` of them
         self._pending = []
         self._max_in_flight = 2
+        self._norm_slots = None               # pinned ring for those copies (allocated at the first asynchronous update)
         # SOME_AMD_TRAIN_TAPE=0 / some_amd_tape: false: forward + backward through torch.autograd (A/B runs; same kernels, same gradients)
         self.use_tape = bool(config.get('some_amd_tape', True)) and os.environ.get('SOME_AMD_TRAIN_TAPE', '1') != '0'
         self.host_enqueue_s = 0.0                 # cumulative host time spent enqueuing training steps (up to the step's one sync)
@@ -190,7 +191,10 @@ class MIDIExtractionTrainer:
                                                               self.betas[0], self.betas[1], self.eps, self.weight_decay, self.global_step,
                                                               p(self._sumsq), float(clip or 0.0), float(self.world * scale), self.ops.stream()))
             self.ops.weights_version += 1
-            host = torch.empty(1, dtype=torch.float64).pin_memory()
+            if self._norm_slots is None:
+                self._norm_slots = torch.empty(2 * self._max_in_flight, dtype=torch.float64).pin_memory()
+            k = self.global_step % self._norm_slots.numel()
+            host = self._norm_slots[k:k + 1]
             host.copy_(self._sumsq, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
