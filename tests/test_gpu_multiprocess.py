@@ -61,6 +61,22 @@ def test_bench_under_torchrun_with_one_nccl_rank():
     assert res['notes_decoded_last_step'] > 0 and res['value'] > 0
 
 
+def test_bench_with_two_ranks_sharing_the_gpu():
+    """bench.py --gpus 2 as the driver's scaling run launches it, with gloo standing in for RCCL on this one-GPU box: every rank pins itself
+    to its own cores (sharding.bind_rank_to_cores), takes the broadcast weight arena, runs its own 4 clips, and rank 0 reports the
+    max-over-ranks time - value = the audio of BOTH ranks per second, n_gpus 2, weak scaling."""
+    r = _torchrun(2, [str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--lay', '1', '--batch', '4', '--seconds', '5',
+                      '--no-cpu-baseline', '--no-f32-leg', '--no-latency', '--no-secondary', '--no-live-pmc', '--no-kernel-profile'],
+                  env={'SOME_AMD_DIST_BACKEND': 'gloo'})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                   # rank 0 only
+    res = json.loads(lines[0])
+    assert res['process_group'] == {'backend': 'gloo', 'world_size': 2} and res['n_gpus'] == 2 and res['scaling'] == 'weak'
+    assert abs(res['value'] - 2 * 4 * 5.0 * 2 / (res['ms_per_step'] * 2 * 1e-3)) < 0.02 * res['value']
+    assert res['notes_decoded_last_step'] > 0 and 'e2e_batch_infer' not in res and 'train_epoch' not in res
+
+
 def test_batch_infer_one_nccl_rank_and_two_gloo_ranks_equal_the_plain_run(tmp_path):
     _dataset(tmp_path, rows=7, seconds=6.0)
     base = [str(ROOT / 'batch_infer.py'), '--dataset', str(tmp_path), '--model', str(tmp_path / 'model' / 'model.ckpt'), '--overwrite']
