@@ -234,6 +234,22 @@ assert tr1.grad_sync is None
 for _ in range(2):
     tr1.training_step(sample)
 assert torch.equal(tr1.model.params.flat, flat), 'bucketed and single all-reduce disagree'
+# what train.py runs for the reference's configs: bf16 operands, two lanes, updates without a host synchronisation - replicas stay
+# identical, and identical to the synchronous steps
+cfg16 = dict(cfg, pl_trainer_precision='bf16', some_amd_ddp_bucket_mb=4)
+res16 = []
+for sync in (False, True):
+    t16 = MIDIExtractionTrainer(cfg16, device='cuda:0', seed=100 + rank)
+    for _ in range(3):
+        o16 = t16.training_step(sample, sync=sync)
+    t16.flush()
+    assert t16.ops._lane_version[1] > 0 and t16.grad_sync is not None
+    f16 = t16.model.params.flat
+    pair = [torch.empty_like(f16), torch.empty_like(f16)]
+    dist.all_gather(pair, f16)
+    assert torch.equal(pair[0], pair[1]), 'bf16 replicas diverged'
+    res16.append(f16.clone())
+assert torch.equal(res16[0], res16[1]), 'asynchronous and synchronous updates disagree under data parallelism'
 torch.save({'flat': flat.cpu(), 'loss': float(out['total_loss'])}, os.environ['OUT'] + f'.{rank}')
 dist.barrier()
 dist.destroy_process_group()
