@@ -47,7 +47,9 @@ def _offline_evidence(kernel_name: str) -> dict:
     out = {}
     if key is None:
         return out
-    for hbm_file, busy_file in (('r02f_pmc_hbm_traffic.json', 'r02f_pmc_mfma_busy.json'),        # newest committed passes first
+    for hbm_file, busy_file in (('r04n_pmc_hbm_traffic.json', 'r04n_pmc_mfma_busy.json'),        # newest committed passes first
+                                ('r03f_pmc_hbm_traffic.json', 'r03f_pmc_mfma_busy.json'),
+                                ('r02f_pmc_hbm_traffic.json', 'r02f_pmc_mfma_busy.json'),
                                 ('r02_pmc_hbm_traffic.json', 'r02_pmc_mfma_busy.json'),
                                 ('r01_pmc_hbm_traffic_f16x3.json', 'r01_pmc_mfma_busy.json')):
         try:
