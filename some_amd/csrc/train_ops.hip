@@ -81,27 +81,38 @@ __global__ __launch_bounds__(256) void col_partial_kernel(int M, int N, float* _
     }
 }
 
-// Sums of the chunk partials in double: a workgroup owns 64 columns, its wavefront g adds the chunks p = g, g + 4, ... in
-// ascending order and the four sub-sums are combined as (0 + 1) + (2 + 3) - a fixed order (deterministic), four times the
-// parallelism of one thread per column (162 chunks at 8 x 2584 frames: 44 -> 12 us per call, 57 calls per training step).
+// Sums of the chunk partials in double: a workgroup owns 64 columns, its wavefront g (of kColWaves = 16) adds the chunks p = g, g + 16, ...
+// in ascending order and the sixteen sub-sums are combined in a fixed binary tree - deterministic for a given chunk count.  (Round 3: four
+// wavefronts, 162 chunks at 8 x 2584 frames: 12 - 15 us per call x 57 calls per training step; round 4's 16-row LayerNorm chunks at small
+// batches make it 260 chunks - a dependent chain of 65 loads per wavefront was 19 us per call.)
+constexpr int kColWaves = 16;
 __device__ __forceinline__ bool col_total(const float* __restrict__ partial, int P, int N, int& n, double& a, double& b) {
-    __shared__ double red[2][4][64];
+    __shared__ double red[2][kColWaves][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     n = blockIdx.x * 64 + c;
     a = 0.0; b = 0.0;
-    if (n < N)
-        for (int p = g; p < P; p += 4) { a += partial[(size_t)p * 2 * N + n]; b += partial[(size_t)p * 2 * N + N + n]; }
+    if (n < N) {
+#pragma unroll 4
+        for (int p = g; p < P; p += kColWaves) { a += partial[(size_t)p * 2 * N + n]; b += partial[(size_t)p * 2 * N + N + n]; }
+    }
     red[0][g][c] = a;
     red[1][g][c] = b;
     __syncthreads();
     if (g != 0 || n >= N) return false;
-    a = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-    b = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    double t[2][kColWaves];
+#pragma unroll
+    for (int k = 0; k < kColWaves; ++k) { t[0][k] = red[0][k][c]; t[1][k] = red[1][k][c]; }
+#pragma unroll
+    for (int w = 1; w < kColWaves; w *= 2)
+#pragma unroll
+        for (int k = 0; k < kColWaves; k += 2 * w) { t[0][k] += t[0][k + w]; t[1][k] += t[1][k + w]; }
+    a = t[0][0];
+    b = t[1][0];
     return true;
 }
 
 // out1[n] (+)= sum_p partial[p][0][n], out2[n] (+)= sum_p partial[p][1][n]
-__global__ __launch_bounds__(256) void col_final_kernel(const float* __restrict__ partial, int P, int N, float* out1, float* out2,
+__global__ __launch_bounds__(64 * kColWaves) void col_final_kernel(const float* __restrict__ partial, int P, int N, float* out1, float* out2,
                                                          int accumulate) {
     int n;
     double a, b;
@@ -258,7 +269,7 @@ __global__ __launch_bounds__(64 * kLnWaves) void ln_bwd_fused_kernel(const float
 }
 
 // ---- BatchNorm1d(train) over the M rows of [M, C] -------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int P, int C, int M, float eps, float momentum,
+__global__ __launch_bounds__(64 * kColWaves) void bn_finalize_kernel(const float* __restrict__ partial, int P, int C, int M, float eps, float momentum,
                                                            float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                            float* running_mean, float* running_var) {
     int n;
@@ -709,7 +720,7 @@ template <class F>
 static hipError_t col_reduce(int M, int N, F f, float* out1, float* out2, int accumulate, float* scratch, hipStream_t s) {
     const int P = n_chunks(M);
     hipLaunchKernelGGL(col_partial_kernel<F>, dim3((unsigned)((N + 63) / 64), (unsigned)P), dim3(256), 0, s, M, N, scratch, f);
-    hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, scratch, P, N, out1, out2, accumulate);
+    hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64 * kColWaves), 0, s, scratch, P, N, out1, out2, accumulate);
     return hipGetLastError();
 }
 
@@ -738,7 +749,7 @@ hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const 
     const int chunk = ln_chunk_rows(M);
     const int P = (M + chunk - 1) / chunk;
     hipLaunchKernelGGL(ln_bwd_fused_kernel, dim3((unsigned)P), dim3(64 * kLnWaves), 0, s, dy, x, g, mean, rstd, add, dx, scratch, M, chunk);
-    hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)(kLnDim / 64)), dim3(256), 0, s, scratch, P, kLnDim, dbeta, dgamma, accumulate);
+    hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)(kLnDim / 64)), dim3(64 * kColWaves), 0, s, scratch, P, kLnDim, dbeta, dgamma, accumulate);
     return hipGetLastError();
 }
 
@@ -747,7 +758,7 @@ hipError_t launch_bn_fwd(const float* x, const float* g, const float* b, int M, 
     if (M <= 0) return hipSuccess;
     const int P = n_chunks(M);
     hipLaunchKernelGGL(col_partial_kernel<ColStatsF>, dim3((unsigned)((C + 63) / 64), (unsigned)P), dim3(256), 0, s, M, C, scratch, ColStatsF{x, C});
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, scratch, P, C, M, eps, momentum, save_mean, save_rstd,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64 * kColWaves), 0, s, scratch, P, C, M, eps, momentum, save_mean, save_rstd,
                        running_mean, running_var);
     const int64_t n4 = (int64_t)M * C / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, g, b, save_mean, save_rstd, y, n4, C);
