@@ -104,6 +104,7 @@ class TrainableMidiConforms:
         self._seed = seed
         self._calls = 0
         self._shadow_list = None
+        self._block_cache = {}
 
     # ---- dropout: one independent (seed, counter) stream per call site and step; fused into the neighbouring pass --------
     def _drop(self, kind: str):
@@ -130,30 +131,42 @@ class TrainableMidiConforms:
             self._shadow_list = ws
         return self._shadow_list
 
-    def _ffn_block(self, x, pre: str, i: int, name: str):
+    def _block_params(self, pre: str):
+        """The parameter / buffer tensors of block ``pre`` in call order, looked up once (the views never move): ~60 formatted dictionary
+        lookups per block and pass otherwise."""
+        hit = self._block_cache.get(pre)
+        if hit is None:
+            P = self.params
+            a, c = pre + '.att', pre + '.conv'
+            ffn = lambda i, f: (P[f'{pre}.norm{i}.weight'], P[f'{pre}.norm{i}.bias'], P[f'{pre}{f}.ln1.weight'], P[f'{pre}{f}.ln1.bias'],   # noqa: E731
+                                P[f'{pre}{f}.ln2.weight'], P[f'{pre}{f}.ln2.bias'])
+            hit = self._block_cache[pre] = {
+                'ffn1': ffn(1, '.ffn1'), 'ffn2': ffn(4, '.ffn2'),
+                'att': (P[f'{pre}.norm2.weight'], P[f'{pre}.norm2.bias'], P[a + '.to_q.weight'], P[a + '.to_kv.weight'], P[a + '.to_out.0.weight'],
+                        P[a + '.to_out.0.bias']),
+                'conv': (P[f'{pre}.norm3.weight'], P[f'{pre}.norm3.bias'], P[c + '.pointwise_conv1.weight'], P[c + '.pointwise_conv1.bias'],
+                         P[c + '.depthwise_conv.weight'], P[c + '.depthwise_conv.bias'], P[c + '.norm.weight'], P[c + '.norm.bias'],
+                         P[c + '.norm.running_mean'], P[c + '.norm.running_var'], P[c + '.pointwise_conv2.weight'], P[c + '.pointwise_conv2.bias']),
+                'tracked': P[c + '.norm.num_batches_tracked'],
+                'ln5': (P[f'{pre}.norm5.weight'], P[f'{pre}.norm5.bias']),
+            }
+        return hit
+
+    def _ffn_block(self, x, params):
         """x = ffn(norm_i(x)) * 0.5 + x (Gconform.py:57,60), the FFN's output dropout included - one fused operator in mixed precision."""
-        P, o = self.params, self.ops
-        f = pre + name
         latent, out = self._drop('ffn_latent'), self._drop('ffn_out')                # the call order of the unfused composition
-        return o.ffn_block(x, P[f'{pre}.norm{i}.weight'], P[f'{pre}.norm{i}.bias'], P[f + '.ln1.weight'], P[f + '.ln1.bias'], P[f + '.ln2.weight'],
-                           P[f + '.ln2.bias'], 0.5, latent[0], latent[1], out[0], out[1])
+        return self.ops.ffn_block(x, *params, 0.5, latent[0], latent[1], out[0], out[1])
 
     def _block(self, x, pre: str, batch):
         """conform_blocke.forward (Gconform.py:56-63)."""
-        P, o = self.params, self.ops
-        ln = lambda t, i: o.layernorm(t, P[f'{pre}.norm{i}.weight'], P[f'{pre}.norm{i}.bias'])   # noqa: E731
-        x = self._ffn_block(x, pre, 1, '.ffn1')
-        a, c = pre + '.att', pre + '.conv'
-        x = o.attention_block(x, P[f'{pre}.norm2.weight'], P[f'{pre}.norm2.bias'], P[a + '.to_q.weight'], P[a + '.to_kv.weight'],
-                              P[a + '.to_out.0.weight'], P[a + '.to_out.0.bias'], batch, *self._drop('attention'))
-        x = o.conv_block(x, P[f'{pre}.norm3.weight'], P[f'{pre}.norm3.bias'], P[c + '.pointwise_conv1.weight'], P[c + '.pointwise_conv1.bias'],
-                         P[c + '.depthwise_conv.weight'], P[c + '.depthwise_conv.bias'], P[c + '.norm.weight'], P[c + '.norm.bias'],
-                         P[c + '.norm.running_mean'], P[c + '.norm.running_var'], P[c + '.pointwise_conv2.weight'], P[c + '.pointwise_conv2.bias'],
-                         batch, *self._drop('conv'))
+        o, bp = self.ops, self._block_params(pre)
+        x = self._ffn_block(x, bp['ffn1'])
+        x = o.attention_block(x, *bp['att'], batch, *self._drop('attention'))
+        x = o.conv_block(x, *bp['conv'], batch, *self._drop('conv'))
         with torch.no_grad():
-            P[c + '.norm.num_batches_tracked'].add_(1)
-        x = self._ffn_block(x, pre, 4, '.ffn2')
-        return ln(x, 5)
+            bp['tracked'].add_(1)
+        x = self._ffn_block(x, bp['ffn2'])
+        return o.layernorm(x, *bp['ln5'])
 
     def forward(self, units: torch.Tensor, batch: ClipBatch, mask: Optional[torch.Tensor] = None):
         """Gmidi_conform.forward (Gconform.py:119-140) + midi_conforms.forward(sig=False)."""

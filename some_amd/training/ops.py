@@ -30,6 +30,7 @@ class TrainOps:
         self._pinned_stream = None
         self.tape: Optional['Tape'] = None        # set by the trainer for the duration of a forward + backward pass
         self._partials: Dict[int, torch.Tensor] = {}
+        self._size_cache: Dict[tuple, int] = {}
         # Two LANES (trainer's tape only): the midi and the bound stream of a Gcf layer are independent between the cross gates
         # (Gconform.py:82-87), forward and backward, so the model issues the bound stream's block on lane 1 = a second HIP stream.
         # At the reference's batch shape (8 phrases, ~4 100 frames) a step is ~860 launches of 5 - 35 us, most of them far from filling
@@ -106,8 +107,7 @@ class TrainOps:
         """dw [N, K] += dy^T x, db [N] += column sums of dy, straight into the gradient arrays (some_train_gemm16_wgrad)."""
         M, N = dy.shape
         K = x.shape[1]
-        need = int(self.lib.some_train_gemm16_bytes(self.h, N, K, M, K + 4))
-        part = self.partial(need)
+        part = self.partial(self._bytes('some_train_gemm16_bytes', N, K, M, K + 4))
         self.check(self.lib.some_train_gemm16_wgrad(self.h, _p(dy), N, _p(x), K, _p(dw), _p(db), N, K, M, self._op16, 1, _p(part),
                                                     part.numel(), self.stream()))
 
@@ -176,8 +176,7 @@ class TrainOps:
         """dw [N, K] (+)= dy16^T x16, db [N] (+)= column sums of dy16 (some_train_gemm16_wgrad16)."""
         M, N = dy16.shape
         K = x16.shape[1]
-        need = int(self.lib.some_train_gemm16_bytes(self.h, N, K, M, K + 4))
-        part = self.partial(need)
+        part = self.partial(self._bytes('some_train_gemm16_bytes', N, K, M, K + 4))
         self.check(self.lib.some_train_gemm16_wgrad16(self.h, _p(dy16), dy16.stride(0), _p(x16), x16.stride(0), _p(dw), _p(db), N, K, M, self._hi_mode, int(accumulate),
                                                       _p(part), part.numel(), self.stream()))
 
@@ -301,8 +300,16 @@ class TrainOps:
         self._lane = index
         torch.cuda.set_stream(self._lane_streams[index])
 
+    def _bytes(self, fn, *key) -> int:
+        """A sizing entry point of the library, memoised per argument tuple (140 of these calls per step at 2 us each otherwise)."""
+        k = (fn,) + key
+        v = self._size_cache.get(k)
+        if v is None:
+            v = self._size_cache[k] = int(getattr(self.lib, fn)(self.h, *key))
+        return v
+
     def scratch(self, M: int, N: int) -> torch.Tensor:
-        need = int(self.lib.some_train_scratch_bytes(self.h, M, N))
+        need = self._bytes('some_train_scratch_bytes', M, N)
         buf = self._scratch.get(self._lane)
         if buf is None or buf.numel() < need:
             buf = self._scratch[self._lane] = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -316,7 +323,8 @@ class TrainOps:
         return buf
 
     def check(self, rc):
-        _lib.check(self.h, rc)
+        if rc:
+            _lib.check(self.h, rc)
 
     def new(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
@@ -411,7 +419,7 @@ class TrainOps:
             # accumulated in the kernel's staging registers into column K of the output
             ldc = K + (4 if with_bias else 0)
             out = self.new(N, ldc)
-            part = self.partial(int(self.lib.some_train_gemm16_bytes(self.h, N, K, M, ldc)))
+            part = self.partial(self._bytes('some_train_gemm16_bytes', N, K, M, ldc))
             self.check(self.lib.some_train_gemm16(self.h, _p(dy), N, 1, _p(x), K, 1, None, _p(out), ldc, N, K, M, self._op16,
                                                   K if with_bias else -1, _p(part), part.numel(), self.stream()))
             if not with_bias:
@@ -435,7 +443,7 @@ class TrainOps:
         Kx = K + extra
         out = self.new(N, Kx)
         if use3:
-            part = self.partial(int(self.lib.some_train_gemm_splitk_bytes(self.h, N, Kx, Mp)))
+            part = self.partial(self._bytes('some_train_gemm_splitk_bytes', N, Kx, Mp))
             self.check(self.lib.some_train_gemm_splitk(self.h, _p(dyt), Mp, _p(xt), _p(out), N, Kx, Mp, self._hi_mode, _p(part), part.numel(),
                                                        self.stream()))
         else:
