@@ -161,7 +161,8 @@ def main():
     ap.add_argument('--no-live-pmc', action='store_true', help='skip the rocprofv3 --pmc child passes for roofline.traffic / MFMA-busy')
     ap.add_argument('--no-e2e', action='store_true', help='skip the whole-command leg of BASELINE configs[3]: batch_infer.py over --e2e-rows '
                     'synthetic 30 s WAVs on disk -> CSV (tools/batch_infer_bench.py), both arithmetic modes, rows re-checked one by one')
-    ap.add_argument('--e2e-rows', type=int, default=2000, help='rows of the e2e leg (BASELINE configs[3] names 10 000: --e2e-rows 10000, ~2 min more)')
+    ap.add_argument('--e2e-rows', type=int, default=10000, help='rows of the e2e leg (BASELINE configs[3] names 10 000 x 30 s clips)')
+    ap.add_argument('--e2e-f32-rows', type=int, default=2000, help='rows the exact-f32 arm of the e2e leg annotates (the first N of the same dataset)')
     ap.add_argument('--no-train', action='store_true', help='skip the whole-command leg of BASELINE configs[4] on this GPU: one epoch of train.py '
                     'two_head_model bf16 over a synthetic 3 h binarised dataset (tools/train_epoch_bench.py)')
     ap.add_argument('--train-hours', type=float, default=3.0)
@@ -448,7 +449,9 @@ def main():
             t_leg = time.perf_counter()
             cold = _tool_json(tool, 1500)
             warm = _tool_json(tool + ['--check', '24'], 1500)
-            f32 = _tool_json(tool + ['--check', '24'], 1500, env={'SOME_AMD_PRECISION': 'f32'})
+            # exact-f32 arm: the first --e2e-f32-rows rows of the same dataset, its CSV compared with the f16x3 CSV (rows / note boundaries differing)
+            f32 = _tool_json(tool + ['--check', '24', '--limit', str(min(args.e2e_f32_rows, args.e2e_rows)), '--out', 'out_f32.csv', '--compare', 'out.csv'],
+                             1500, env={'SOME_AMD_PRECISION': 'f32'})
             result['e2e_batch_infer'] = dict(warm, gemm_precision='f16x3', cold_start=cold, exact_f32_mode=dict(f32, gemm_precision='f32'),
                                              leg_wall_s=round(time.perf_counter() - t_leg, 1))
         if whole_command_legs and not args.no_train:

@@ -428,6 +428,7 @@ def gen_train():
         g = p.grad.detach().numpy().astype(np.float64).reshape(-1)
         proj = np.random.default_rng(zlib.crc32(name.encode())).standard_normal(g.size)
         out['grad.' + name] = np.array(list(g[:8]) + [0.0] * max(0, 8 - g.size) + [g.sum(), np.abs(g).sum(), np.sqrt((g * g).sum()), (g * proj).sum()])
+        out['sk.' + name] = grad_sketch(name, g)
         names.append(name)
     # Lightning's gradient_clip_val = clip_grad_norm (configs/base.yaml:49, train.py:88), algorithm 'norm'
     out['grad_norm'] = np.array(float(torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.get('clip_grad_norm', 1.0))))
@@ -441,6 +442,123 @@ def gen_train():
     out['names'] = np.array(names)
     np.savez_compressed(OUT / 'train_step.npz', **out)
     print('train_step.npz', len(out), 'bound_loss', bound_loss.item(), 'midi_loss', midi_loss.item())
+
+
+def _grad_digest(name, p):
+    import zlib
+    g = p.grad.detach().float().numpy().astype(np.float64).reshape(-1)
+    proj = np.random.default_rng(zlib.crc32(name.encode())).standard_normal(g.size)
+    return np.array(list(g[:8]) + [0.0] * max(0, 8 - g.size) + [g.sum(), np.abs(g).sum(), np.sqrt((g * g).sum()), (g * proj).sum()])
+
+
+def grad_sketch(name, g, buckets=64):
+    """64-bucket count sketch of a gradient tensor (seeded signs, element i -> bucket i % 64): ||sketch(a) - sketch(b)|| estimates
+    ||a - b|| to about 10 % - a whole-tensor error measure that fits in a fixture (tests/test_gpu_train_step.py recomputes it)."""
+    import zlib
+    g = np.asarray(g, dtype=np.float64).reshape(-1)
+    signs = np.random.default_rng(zlib.crc32(name.encode()) + 1).integers(0, 2, g.size) * 2.0 - 1.0
+    return np.bincount(np.arange(g.size) % buckets, weights=g * signs, minlength=buckets)
+
+
+def gen_train_bf16():
+    """The SAME step as gen_train (same weights, batch, losses) run the way Lightning's ``precision='bf16'`` runs it
+    (train.py:65, configs/midi_conformer.yaml:35): forward and losses under ``torch.autocast(dtype=torch.bfloat16)``, fp32 master
+    weights, backward through the recorded dtypes.  Stored: the losses and the per-parameter gradient digests of gen_train - the
+    yardstick for the HIP bf16 path: how far the REFERENCE'S OWN bf16 arithmetic sits from its fp32 step, tensor by tensor."""
+    import copy
+    cfg = get_config('two_head_model', lay=1)
+    for k in ('conv_drop', 'ffn_latent_drop', 'ffn_out_drop', 'attention_drop'):
+        cfg['midi_extractor_args'][k] = 0.0
+    model = RefModel(copy.deepcopy(cfg)).train()
+    sd = synth.synth_state_dict(cfg, 31)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    ref_losses = _load_file('ref_bound_loss', REF / 'modules/losses/bound_loss.py')
+    t = {k: torch.from_numpy(v) for k, v in synth.synth_train_batch().items()}
+    mask = t['unit2note'] > 0
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        probs, bounds = model(x=t['units'], f0=None, mask=mask, sig=False)
+        bound_loss = ref_losses.BinaryEMDLoss()(bounds, t['bounds'])
+        midi_loss = torch.nn.BCEWithLogitsLoss()(probs, t['probs'])
+    (bound_loss + midi_loss).backward()
+    out = {'bound_loss': np.array(float(bound_loss)), 'midi_loss': np.array(float(midi_loss)),
+           'probs_dtype': np.array(str(probs.dtype)), 'bounds_dtype': np.array(str(bounds.dtype))}
+    names = []
+    for name, p in model.named_parameters():
+        out['grad.' + name] = _grad_digest(name, p)
+        out['sk.' + name] = grad_sketch(name, p.grad.detach().float().numpy())
+        names.append(name)
+    out['grad_norm'] = np.array(float(torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.get('clip_grad_norm', 1.0))))
+    out['names'] = np.array(names)
+    np.savez_compressed(OUT / 'train_step_bf16.npz', **out)
+    print('train_step_bf16.npz', len(out), 'bound_loss', float(bound_loss), 'midi_loss', float(midi_loss), probs.dtype, bounds.dtype)
+
+
+TRAJ_STEPS = 8
+TRAJ_PARAMS = ('model.inln.weight', 'model.cf_lay.1.att2.ffn2.ln1.weight', 'model.cf_lay.2.att1.att.to_out.0.weight')
+
+
+def gen_train_trajectory():
+    """TRAJ_STEPS consecutive fp32 updates of the configs[4] model (two_head_model: lay 3) through the reference's own pieces:
+    ``midi_conforms`` + BinaryEMDLoss + BCEWithLogitsLoss (training/me_task.py:79-111), ``torch.optim.AdamW`` built as
+    training/base_task.py:331-344 builds it, the reference's ``WarmupLR`` stepped once per update (base_task.py:346-358:
+    interval 'step'), ``clip_grad_norm_`` (train.py:88).  A DIFFERENT batch every step; warm-up shortened to 4 updates so the
+    window covers the linear ramp, the peak and the 1/sqrt decay and the weights really move (lr up to 1e-4).  Dropout is 0 (torch's
+    mask stream cannot be reproduced elsewhere; the HIP dropout is gated statistically in tests/test_gpu_train_ops.py).
+    Stored per step: both losses, the pre-clip gradient norm, the rate used, digests of three parameters after the update, and the
+    BatchNorm running statistics + num_batches_tracked of one conv module; at the end a digest of every parameter."""
+    import copy
+    cfg = get_config('two_head_model')
+    assert cfg['midi_extractor_args']['lay'] == 3
+    for k in ('conv_drop', 'ffn_latent_drop', 'ffn_out_drop', 'attention_drop'):
+        cfg['midi_extractor_args'][k] = 0.0
+    model = RefModel(copy.deepcopy(cfg)).train()
+    sd = synth.synth_state_dict(cfg, 47)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    ref_losses = _load_file('ref_bound_loss', REF / 'modules/losses/bound_loss.py')
+    sched_mod = _load_file('ref_scheduler', REF / 'lr_scheduler/scheduler.py')
+    oa = cfg['optimizer_args']
+    opt = torch.optim.AdamW(model.parameters(), lr=oa['lr'], betas=(oa['beta1'], oa['beta2']), weight_decay=oa['weight_decay'])
+    sched = sched_mod.WarmupLR(opt, warmup_steps=4, min_lr=cfg['lr_scheduler_args']['min_lr'])
+    params = dict(model.named_parameters())
+    bufs = dict(model.named_buffers())
+    bn = [k for k in bufs if k.endswith('running_mean')][2]                     # one conv module's BatchNorm
+    bn_var, bn_cnt = bn.replace('running_mean', 'running_var'), bn.replace('running_mean', 'num_batches_tracked')
+    for k in TRAJ_PARAMS:
+        assert k in params, (k, list(params)[:40])
+    out = {'steps': np.array(TRAJ_STEPS), 'warmup_steps': np.array(4), 'weights_seed': np.array(47), 'bn_name': np.array(bn),
+           'traj_params': np.array(TRAJ_PARAMS)}
+    rows = {k: [] for k in ('bound_loss', 'midi_loss', 'grad_norm', 'lr', 'bn_cnt')}
+    for step in range(TRAJ_STEPS):
+        t = {k: torch.from_numpy(v) for k, v in synth.synth_train_batch(B=2 + step % 2, T=80 + 16 * (step % 3), seed=100 + step).items()}
+        mask = t['unit2note'] > 0
+        opt.zero_grad(set_to_none=True)
+        probs, bounds = model(x=t['units'], f0=None, mask=mask, sig=False)
+        bound_loss = ref_losses.BinaryEMDLoss()(bounds, t['bounds'])
+        midi_loss = torch.nn.BCEWithLogitsLoss()(probs, t['probs'])
+        (bound_loss + midi_loss).backward()
+        rows['bound_loss'].append(bound_loss.item())
+        rows['midi_loss'].append(midi_loss.item())
+        rows['grad_norm'].append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.get('clip_grad_norm', 1.0))))
+        rows['lr'].append(opt.param_groups[0]['lr'])
+        opt.step()
+        sched.step()
+        rows['bn_cnt'].append(int(bufs[bn_cnt]))
+        for k in TRAJ_PARAMS:
+            v = params[k].detach().numpy().astype(np.float64).reshape(-1)
+            out[f'p{step}.{k}'] = np.array(list(v[:8]) + [v.sum(), np.sqrt((v * v).sum())])
+        out[f'bn{step}.mean'] = bufs[bn].detach().numpy().copy()
+        out[f'bn{step}.var'] = bufs[bn_var].detach().numpy().copy()
+    for k, v in rows.items():
+        out[k] = np.array(v)
+    names = []
+    for name, p in params.items():
+        v = p.detach().numpy().astype(np.float64).reshape(-1)
+        out['final.' + name] = np.array(list(v[:8]) + [0.0] * max(0, 8 - v.size) + [v.sum(), np.sqrt((v * v).sum())])
+        out['init.' + name] = np.array([np.sqrt((np.asarray(sd[name], dtype=np.float64) ** 2).sum())])
+        names.append(name)
+    out['names'] = np.array(names)
+    np.savez_compressed(OUT / 'train_trajectory.npz', **out)
+    print('train_trajectory.npz', len(out), 'losses', rows['bound_loss'], rows['midi_loss'], 'lr', rows['lr'], 'norm', rows['grad_norm'])
 
 
 def gen_lr_schedule():
@@ -654,6 +772,8 @@ if __name__ == '__main__':
     gen_batch_csv()
     gen_deploy()
     gen_train()
+    gen_train_bf16()
+    gen_train_trajectory()
     gen_lr_schedule()
     gen_e2e()
     gen_fullsize()

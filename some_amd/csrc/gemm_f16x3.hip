@@ -1203,7 +1203,11 @@ hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a_in, bool out_split, 
     GemmArgs a = a_in;
     a.m_begin = 0;
     if (a.a_rows <= 0) a.a_rows = a.M;
-    if (a.row_map != nullptr && tile == 3) return hipErrorInvalidValue;      // the DMA-ring kernel has no row gather
+    if (a.row_map != nullptr && tile == 3) {
+        // the DMA-ring kernel has no row gather: a forced SOME_AMD_TILE=3 falls back to the register-staged tile its grid size would pick
+        auto blocks = [&](int bm, int bn) { long n = 0; for (int g = 0; g < a.groups; ++g) n += (long)((a.M + bm - 1) / bm) * ((a.g[g].N + bn - 1) / bn); return n; };
+        tile = blocks(256, 256) >= 512 ? 2 : blocks(256, 128) >= 512 ? 1 : blocks(128, 128) >= 256 ? 0 : 4;
+    }
     if (a.k_slices > 1) {
         if (epi != EPI_NONE || out_split || tile == 3) return hipErrorInvalidValue;
         return launch_one(epi, a, false, tile, s);

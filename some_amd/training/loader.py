@@ -72,10 +72,12 @@ class PrefetchLoader:
         # worker threads pin memory (torch.full(..., pin_memory=True)): a new host thread defaults to device 0, so under one process per GPU
         # every rank's workers would create a context on GPU 0 and pin there - bind them to this rank's device first (what torch's
         # DataLoader pin thread does)
-        init = (lambda: torch.cuda.set_device(self.device)) if self.cuda else None
+        # (an index-less torch.device('cuda') - the trainer's default - names the CURRENT device: resolve it here, set_device() rejects it)
+        dev_index = (self.device.index if self.device.index is not None else torch.cuda.current_device()) if self.cuda else None
+        init = (lambda: torch.cuda.set_device(dev_index)) if self.cuda else None
         self.pool = None if self.on_device or self.workers == 0 else concurrent.futures.ThreadPoolExecutor(self.workers, thread_name_prefix='some-loader',
                                                                                                              initializer=init)
-        self.copy_stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.copy_stream = torch.cuda.Stream(dev_index) if self.cuda else None
         self.stats = {'batches': 0, 'wait_s': 0.0, 'host_collate_s': 0.0}
 
     # ---- host side ----------------------------------------------------------------------------------------------

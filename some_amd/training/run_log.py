@@ -120,8 +120,16 @@ class CheckpointKeeper:
         self.keep = int(num_ckpt_keep)
         self.start, self.interval = int(permanent_ckpt_start or 0), int(permanent_ckpt_interval or 0)
         self.enable_permanent = self.start > 0 and self.interval > 9                     # utils/training_utils.py:194
-        self.window: List[pathlib.Path] = [p for p in self.existing(self.work) if not self.is_permanent(self.step_of(p))]
-        self.window = self.window[-self.keep:] if self.keep > 0 else self.window           # older non-permanent files are left alone, as Lightning leaves them
+        # restart: the newest `keep` files are the window whatever their step (permanence is decided when one LEAVES the window, as
+        # _remove_checkpoint does, utils/training_utils.py:243-256); older files are left alone, as Lightning leaves them.
+        # keep < 0 (save_top_k = -1): keep everything; keep = 0 (save_top_k = 0): save nothing - see wants()
+        found = self.existing(self.work)
+        self.window: List[pathlib.Path] = found[-self.keep:] if self.keep > 0 else (found if self.keep < 0 else [])
+
+    def wants(self, step: int) -> bool:
+        """Should a checkpoint be written at ``step``?  Lightning's ``save_top_k = 0`` writes none; a permanent step is kept regardless here
+        (the reference would never have written it - keeping it costs nothing and loses nothing)."""
+        return self.keep != 0 or self.is_permanent(step)
 
     @staticmethod
     def step_of(path) -> int:
@@ -146,6 +154,9 @@ class CheckpointKeeper:
         if path not in self.window:
             self.window.append(path)
         while self.keep >= 0 and len(self.window) > self.keep:
+            if self.keep == 0 and self.is_permanent(self.step_of(self.window[0])):
+                lines.append(f'Checkpoint {self.window.pop(0).name} is now permanent.')
+                continue
             old = self.window.pop(0)
             if self.is_permanent(self.step_of(old)):
                 lines.append(f'Checkpoint {old.name} is now permanent.')

@@ -118,13 +118,20 @@ class MIDIExtractionTrainer:
         gradient norm back - the clip factor is computed on the device (some_train_adamw_clip: the same double arithmetic, bit-identical
         parameters) - so the host goes on to enqueue the next step while this one's tail runs; the returned losses are device tensors,
         ``grad_norm`` is None, and a non-finite gradient (which leaves the parameters untouched) raises FloatingPointError from a LATER
-        call or from ``flush()``.  At most two updates are in flight."""
+        call or from ``flush()``.  At most two updates are in flight.  After that error the trainer's state is INVALID (later updates were
+        already applied with the step counter advanced past the skipped one): training_step / checkpoint refuse until load_checkpoint."""
+        self._refuse_if_failed()
         t_begin = time.perf_counter()
         self.ops.pin_stream()
         try:
             return self._training_step(sample, t_begin, sync)
         finally:
             self.ops.unpin_stream()
+
+    def _refuse_if_failed(self):
+        if getattr(self, 'failed_step', None) is not None:
+            raise RuntimeError(f'the trainer state is invalid since the non-finite gradient of update {self.failed_step} '
+                               f'(asynchronous updates ran on past it): reload a checkpoint with load_checkpoint()')
 
     def flush(self):
         """Wait for the updates enqueued with ``sync=False`` and raise if one of them saw a non-finite gradient."""
@@ -139,7 +146,14 @@ class MIDIExtractionTrainer:
             self._pending.pop(0)
             v = float(host[0])
             if not (v == v and v != float('inf')):
-                raise FloatingPointError(f'non-finite gradient in update {step} (its parameters were left untouched)')
+                # The bad update left parameters and moments untouched on the device, but up to _max_in_flight later updates have been
+                # enqueued on top with the step counter (AdamW bias correction, WarmupLR) already advanced past it.  The trainer is NOT
+                # state-equivalent to a synchronous run from here on: drop the run-ahead bookkeeping, mark the trainer, and make every
+                # later training_step / checkpoint refuse until the caller reloads a checkpoint (load_checkpoint clears the mark).
+                self._pending.clear()
+                self.failed_step = step
+                raise FloatingPointError(f'non-finite gradient in update {step} (its parameters were left untouched; {self.global_step - step} later '
+                                         f'update(s) were already enqueued - reload a checkpoint before continuing, the trainer state is invalid)')
 
     def _training_step(self, sample, t_begin, sync: bool = True) -> Dict[str, float]:
         P = self.model.params
@@ -240,6 +254,7 @@ class MIDIExtractionTrainer:
         """Lightning-layout checkpoint: ``state_dict`` with the ``model.`` prefix (what the inference classes read) plus
         everything needed to continue bit-identically: step, flat AdamW moments, loss-scale state, dropout call counter."""
         P = self.model.params
+        self._refuse_if_failed()
         self.flush()
         return {
             'state_dict': {'model.' + k: v.cpu() for k, v in P.state_dict().items()},
@@ -256,6 +271,8 @@ class MIDIExtractionTrainer:
         P.load_state_dict({(k[6:] if k.startswith('model.') else k): v for k, v in ckpt['state_dict'].items()})
         self.ops.weights_version += 1              # (see _training_step)
         self.global_step = int(ckpt.get('global_step', 0))
+        self.failed_step = None
+        self._pending.clear()
         st = ckpt.get('some_amd_trainer')
         if st is not None:                      # a reference / inference-only checkpoint has no optimiser state: fresh moments
             if list(st['param_names']) != list(P.param_names):

@@ -153,32 +153,135 @@ def test_validation_step_eval_mode_and_metric():
     assert abs(train_mode_loss.item() - res['midi_loss'].item()) > 1e-6
 
 
-@pytest.mark.parametrize('precision,operand,loss_tol,grad_tol', [('16-mixed', 'f16', 2e-3, 2e-2), ('bf16', 'bf16', 1.5e-2, 1.2e-1)])
-def test_mixed_precision_step_close_to_reference(golden_dir, precision, operand, loss_tol, grad_tol):
-    """pl_trainer_precision '16-mixed' -> f16 operands, 'bf16' (configs/midi_conformer.yaml:35) -> bf16 operands on the matrix pipe
-    (one product), fp32 accumulation and fp32 everything else.  Against the reference's fp32 step: f16 (11-bit significand) losses
-    within 2e-3 and gradients within 2e-2 of each tensor's norm; bf16 (8 bits - the reference's own autocast arithmetic) about 8 x that."""
+def _sketch(name, g, buckets=64):
+    """oracle/make_golden.py:grad_sketch restated (the fixture side runs in the build container only): 64-bucket count sketch,
+    ||sketch(a) - sketch(b)|| estimates ||a - b|| to about 10 %."""
+    g = np.asarray(g, dtype=np.float64).reshape(-1)
+    signs = np.random.default_rng(zlib.crc32(name.encode()) + 1).integers(0, 2, g.size) * 2.0 - 1.0
+    return np.bincount(np.arange(g.size) % buckets, weights=g * signs, minlength=buckets)
+
+
+def test_f16_mixed_step_close_to_reference(golden_dir):
+    """pl_trainer_precision '16-mixed' -> f16 operands on the matrix pipe (one product), fp32 accumulation and fp32 everything else:
+    losses within 2e-3 and every gradient tensor within 2e-2 (relative L2, count sketch) of the reference's fp32 step."""
     from some_amd.training.task import MIDIExtractionTrainer
     g = np.load(golden_dir / 'train_step.npz')
-    tr = MIDIExtractionTrainer(dict(_cfg(), pl_trainer_precision=precision), device='cuda')
-    assert tr.mixed and tr.mixed_operand == operand and (tr.loss_scale > 1.0) == (operand == 'f16')
+    tr = MIDIExtractionTrainer(dict(_cfg(), pl_trainer_precision='16-mixed'), device='cuda')
+    assert tr.mixed and tr.mixed_operand == 'f16' and tr.loss_scale > 1.0
     tr.model.params.load_state_dict(synth.synth_state_dict(_cfg(), 31))
     out = tr.training_step(_sample())
     assert not out['skipped']
-    assert abs(out['bound_loss'].item() - float(g['bound_loss'])) < loss_tol * abs(float(g['bound_loss']))
-    assert abs(out['midi_loss'].item() - float(g['midi_loss'])) < loss_tol * abs(float(g['midi_loss']))
+    assert abs(out['bound_loss'].item() - float(g['bound_loss'])) < 2e-3 * abs(float(g['bound_loss']))
+    assert abs(out['midi_loss'].item() - float(g['midi_loss'])) < 2e-3 * abs(float(g['midi_loss']))
     worst = 0.0
     for name in g['names']:
         key = str(name)
-        ref = g['grad.' + key]
-        if ref[10] < 1e-6:
+        if g['grad.' + key][10] < 1e-6:
             continue
         mine = tr.model.params.views[key].grad.detach().double().cpu().numpy().reshape(-1) / out['grad_scale']
-        worst = max(worst, abs(np.sqrt((mine * mine).sum()) - ref[10]) / ref[10], np.abs(mine[:8] - ref[:min(8, mine.size)]).max() / ref[10])
-    print(f'mixed precision ({operand}): worst gradient error relative to the tensor norm:', worst)
-    assert worst < grad_tol
-    if operand == 'bf16':
-        assert worst > 1e-3          # it really is the 8-bit arithmetic, not the f16 path under another name
+        worst = max(worst, np.linalg.norm(_sketch(key, mine) - g['sk.' + key]) / g['grad.' + key][10])
+    print('16-mixed: worst gradient tensor error (relative L2):', worst)
+    assert worst < 2e-2
+
+
+def test_bf16_step_is_within_the_references_own_bf16_error(golden_dir):
+    """BASELINE configs[4] trains in bf16 (configs/midi_conformer.yaml:35 -> Lightning precision='bf16', train.py:65).  The yardstick is
+    the REFERENCE's bf16 arithmetic itself: tests/golden/train_step_bf16.npz is the same step run under torch.autocast(bfloat16)
+    (oracle/make_golden.py:gen_train_bf16), which sits 0.2 % .. 2.6 % (relative L2 per gradient tensor) from the reference's fp32 step.
+    The HIP bf16 step (bf16 operands on the matrix pipe, fp32 accumulation, fp32 everything between the GEMMs - it rounds in fewer
+    places than autocast, which also stores every linear output in bf16) must sit no further from that fp32 step than
+    1.5 x the reference's own distance, tensor by tensor, and its losses no further than 1.5 x the autocast losses' distance.
+    (Round 4 gated this at 12 % of the gradient norm against fp32 alone.)"""
+    from some_amd.training.task import MIDIExtractionTrainer
+    g = np.load(golden_dir / 'train_step.npz')
+    gb = np.load(golden_dir / 'train_step_bf16.npz')
+    assert str(gb['probs_dtype']) == 'torch.bfloat16'            # the fixture really is the autocast arithmetic
+    tr = MIDIExtractionTrainer(dict(_cfg(), pl_trainer_precision='bf16'), device='cuda')
+    assert tr.mixed and tr.mixed_operand == 'bf16' and tr.loss_scale == 1.0
+    tr.model.params.load_state_dict(synth.synth_state_dict(_cfg(), 31))
+    out = tr.training_step(_sample())
+    assert not out['skipped']
+    eps = 2e-4                                                     # the fp32 gate's own level
+    for k in ('bound_loss', 'midi_loss'):
+        ref32, ref16 = float(g[k]), float(gb[k])
+        assert abs(out[k].item() - ref32) <= 1.5 * abs(ref16 - ref32) + eps * abs(ref32), (k, out[k].item(), ref32, ref16)
+    assert abs(out['grad_norm'] - float(g['grad_norm'])) <= 1.5 * abs(float(gb['grad_norm']) - float(g['grad_norm'])) + eps * float(g['grad_norm'])
+    rows = []
+    for name in g['names']:
+        key = str(name)
+        norm = g['grad.' + key][10]
+        if norm < 1e-6:
+            continue
+        mine = tr.model.params.views[key].grad.detach().double().cpu().numpy().reshape(-1) / out['grad_scale']
+        err_hip = np.linalg.norm(_sketch(key, mine) - g['sk.' + key]) / norm
+        err_ref = np.linalg.norm(gb['sk.' + key] - g['sk.' + key]) / norm
+        rows.append((err_hip / (1.5 * err_ref + eps), err_hip, err_ref, key))
+    rows.sort(reverse=True)
+    hip = np.array([r[1] for r in rows]); ref = np.array([r[2] for r in rows])
+    print(f'bf16 step, relative L2 error per gradient tensor vs the reference fp32 step: HIP median {np.median(hip):.2e} max {hip.max():.2e} | '
+          f'reference autocast median {np.median(ref):.2e} max {ref.max():.2e} | worst ratio to the gate {rows[0][0]:.2f} ({rows[0][3]})')
+    assert rows[0][0] <= 1.0, rows[:5]
+    assert np.median(hip) > 2e-4          # it really is the 8-bit arithmetic, not the split-f16 path under another name
+
+
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_training_trajectory_matches_reference(golden_dir, precision):
+    """Eight consecutive updates of the configs[4] model (two_head_model, lay 3) against the reference's own model + losses +
+    torch.optim.AdamW + WarmupLR (tests/golden/train_trajectory.npz, oracle/make_golden.py:gen_train_trajectory): a different batch
+    every update, warm-up of 4 so the window holds the ramp, the peak and the decay.  Pins what one step cannot: AdamW's bias
+    correction and moment carry-over, the rate schedule's indexing, BatchNorm running statistics and their counter, and that errors
+    do not compound - losses, gradient norm, three parameters and one BatchNorm after EVERY update, all parameters at the end."""
+    from some_amd.training.task import MIDIExtractionTrainer
+    g = np.load(golden_dir / 'train_trajectory.npz')
+    cfg = get_config('two_head_model')
+    assert cfg['midi_extractor_args']['lay'] == 3
+    for k in ('conv_drop', 'ffn_latent_drop', 'ffn_out_drop', 'attention_drop'):
+        cfg['midi_extractor_args'][k] = 0.0
+    cfg['lr_scheduler_args'] = dict(cfg['lr_scheduler_args'], warmup_steps=int(g['warmup_steps']))
+    tr = MIDIExtractionTrainer(dict(cfg, some_amd_precision=precision), device='cuda')
+    tr.model.params.load_state_dict(synth.synth_state_dict(cfg, int(g['weights_seed'])))
+    P = tr.model.params
+    bn = str(g['bn_name'])
+    steps = int(g['steps'])
+    tol = 2e-4
+    moved = 0.0
+    worst = dict(loss=0.0, norm=0.0, param=0.0, bn=0.0)
+    for step in range(steps):
+        sample = {k: torch.from_numpy(v).cuda() for k, v in synth.synth_train_batch(B=2 + step % 2, T=80 + 16 * (step % 3), seed=100 + step).items()}
+        out = tr.training_step(sample)
+        assert not out['skipped']
+        assert out['lr'] == pytest.approx(float(g['lr'][step]), rel=1e-12), step
+        for k in ('bound_loss', 'midi_loss'):
+            e = abs(out[k].item() - float(g[k][step])) / abs(float(g[k][step]))
+            worst['loss'] = max(worst['loss'], e)
+            assert e < tol, (step, k, out[k].item(), float(g[k][step]))
+        e = abs(out['grad_norm'] - float(g['grad_norm'][step])) / float(g['grad_norm'][step])
+        worst['norm'] = max(worst['norm'], e)
+        assert e < tol, (step, out['grad_norm'], float(g['grad_norm'][step]))
+        moved += float(g['lr'][step])                 # AdamW moves a weight by at most ~lr per update: the scale of the comparison
+        for key in g['traj_params']:
+            key = str(key)
+            v = P.views[key].detach().double().cpu().numpy().reshape(-1)
+            ref = g[f'p{step}.{key}']
+            e = np.abs(v[:8] - ref[:8]).max() / moved
+            worst['param'] = max(worst['param'], e)
+            assert e < 2e-2, (step, key, v[:8], ref[:8])                              # element-wise: within 2 % of the distance travelled
+            assert abs(np.sqrt((v * v).sum()) - ref[9]) < tol * ref[9], (step, key)
+        for leaf, want in (('running_mean', g[f'bn{step}.mean']), ('running_var', g[f'bn{step}.var'])):
+            got = P[bn.replace('running_mean', leaf)].cpu().numpy()
+            e = np.abs(got - want).max() / np.abs(want).max()
+            worst['bn'] = max(worst['bn'], e)
+            assert e < tol, (step, leaf, e)
+        assert int(P[bn.replace('running_mean', 'num_batches_tracked')]) == int(g['bn_cnt'][step]) == step + 1
+    assert tr.global_step == steps
+    # every parameter at the end: norm to 2e-4, and the distance travelled from the initial weights (sum digest) on the right scale
+    for name in g['names']:
+        key = str(name)
+        v = P.views[key].detach().double().cpu().numpy().reshape(-1)
+        ref = g['final.' + key]
+        assert abs(np.sqrt((v * v).sum()) - ref[9]) < tol * max(ref[9], 1e-3), key
+        np.testing.assert_allclose(v[:min(8, v.size)], ref[:min(8, v.size)], rtol=0, atol=2e-2 * moved + 1e-9, err_msg=key)
+    print(f'{precision}: trajectory worst relative errors over {steps} updates:', {k: float(f'{v:.3g}') for k, v in worst.items()})
 
 
 def test_bf16_operand_kernels_match_torch_bf16():

@@ -181,12 +181,13 @@ def test_golden_recipe_reproduces_committed_fixtures_in_one_process(tmp_path, go
     import subprocess
     import sys
     root = __import__('pathlib').Path(__file__).resolve().parents[1]
-    names = ['gen_batch_infer_fns', 'gen_batch_csv', 'gen_deploy', 'gen_samplers', 'gen_lr_schedule', 'gen_midi_msgs', 'gen_slicer']
+    names = ['gen_batch_infer_fns', 'gen_batch_csv', 'gen_deploy', 'gen_samplers', 'gen_lr_schedule', 'gen_midi_msgs', 'gen_slicer',
+             'gen_train_bf16', 'gen_train_trajectory']
     r = subprocess.run([sys.executable, str(root / 'oracle' / 'make_golden.py')] + names, env=dict(os.environ, SOME_GOLDEN_OUT=str(tmp_path)),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     made = sorted(p.name for p in tmp_path.iterdir() if p.is_file())
-    assert len(made) >= 7, made
+    assert len(made) >= 9, made
     for name in made:
         assert (tmp_path / name).read_bytes() == (golden_dir / name).read_bytes(), name
 

@@ -98,7 +98,7 @@ def test_checkpoint_keeper_follows_ds_model_checkpoint(tmp_path):
     assert 'Checkpoint model_ckpt_steps_2000.ckpt is now permanent.' in lines and 'Removed checkpoint model_ckpt_steps_2500.ckpt.' in lines
     # a restart finds the newest checkpoint and does not count permanent files against the window
     k2 = run_log.CheckpointKeeper(tmp_path, 2, 2000, 1000)
-    assert k2.step_of(k2.existing(tmp_path)[-1]) == 4000 and [k2.step_of(p) for p in k2.window] == [3500]
+    assert k2.step_of(k2.existing(tmp_path)[-1]) == 4000 and [k2.step_of(p) for p in k2.window] == [3500, 4000]       # the newest `keep`, permanent or not
     # interval <= 9 or start 0 disables permanent checkpoints (utils/training_utils.py:194)
     k3 = run_log.CheckpointKeeper(tmp_path / 'b', 1, 2000, 9)
     (tmp_path / 'b').mkdir()
@@ -107,6 +107,18 @@ def test_checkpoint_keeper_follows_ds_model_checkpoint(tmp_path):
         p.write_bytes(b'x')
         k3.saved(p)
     assert sorted(k3.step_of(p) for p in (tmp_path / 'b').glob('*.ckpt')) == [2009]
+    # Lightning's save_top_k: 0 saves nothing (wants() is False, and a file registered anyway is not kept), -1 keeps everything
+    k0 = run_log.CheckpointKeeper(tmp_path / 'c', 0, 0, 0)
+    (tmp_path / 'c').mkdir()
+    assert not k0.wants(1000)
+    kall = run_log.CheckpointKeeper(tmp_path / 'c', -1, 0, 0)
+    for step in (1000, 2000, 3000):
+        assert kall.wants(step)
+        p = kall.path_for(step)
+        p.write_bytes(b'x')
+        assert kall.saved(p) == []
+    assert sorted(kall.step_of(p) for p in (tmp_path / 'c').glob('*.ckpt')) == [1000, 2000, 3000]
+    assert [kall.step_of(p) for p in run_log.CheckpointKeeper(tmp_path / 'c', -1, 0, 0).window] == [1000, 2000, 3000]
 
 
 def test_learning_rate_on_resume_follows_the_current_config():

@@ -55,6 +55,9 @@ def main():
     ap.add_argument('--distinct', type=int, default=0, help='number of distinct WAV files (the other rows are hard links); 0: all')
     ap.add_argument('--check', type=int, default=0, help='recompute this many sampled rows one by one (host Slicer + infer) and compare the CSV cells')
     ap.add_argument('--json', action='store_true', help='print one JSON object instead of the sentence')
+    ap.add_argument('--limit', type=int, default=0, help='annotate only the first N rows of the dataset (a sub-dataset directory sharing the WAV files)')
+    ap.add_argument('--out', default='out.csv', help='name of the CSV written into --dir')
+    ap.add_argument('--compare', default=None, help='another CSV in --dir (e.g. the other arithmetic mode\'s): count rows / note boundaries that differ')
     ap.add_argument('--train_updates', type=int, default=0,
                     help='train the checkpoint for this many updates on synthetic sung clips first (train.py): random weights emit ~1500 '
                          'notes per clip, a trained model ~60, and the per-row word alignment scales with the note count')
@@ -93,6 +96,17 @@ def main():
         else:
             synth.save_checkpoint(get_config('midi_conformer', lay=args.lay), root / 'model' / 'model.ckpt', seed=1)
         print(f'dataset: {args.clips} x {args.seconds:g} s int16 WAVs written in {time.perf_counter() - t0:.1f} s', file=sys.stderr)
+    data_root, n_rows = root, args.clips
+    if args.limit and args.limit < args.clips:
+        # the first N rows as a dataset of their own: same WAV files (symlinked directory), truncated transcriptions.csv
+        data_root, n_rows = root / f'first_{args.limit}', args.limit
+        if rank == 0 and not (data_root / 'transcriptions.csv').exists():
+            data_root.mkdir(exist_ok=True)
+            if not (data_root / 'wavs').exists():
+                os.symlink(root / 'wavs', data_root / 'wavs')
+            with open(root / 'transcriptions.csv', encoding='utf8') as f:
+                lines = f.readlines()
+            (data_root / 'transcriptions.csv').write_text(''.join(lines[:1 + args.limit]), encoding='utf8')
     import batch_infer as bi
     import torch
     import utils.config_utils
@@ -101,18 +115,18 @@ def main():
         time.sleep(0 if rank == 0 else 2)
     cached = any((root / 'model').glob('*.arena'))
     t0 = time.perf_counter()
-    bi.batch_infer.callback(dataset=str(root), model=str(root / 'model' / 'model.ckpt'), round_midi=False, csv=str(root / f'out.csv'), overwrite=True)
+    bi.batch_infer.callback(dataset=str(data_root), model=str(root / 'model' / 'model.ckpt'), round_midi=False, csv=str(root / args.out), overwrite=True)
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:
-        rows = list(csv.DictReader(open(root / 'out.csv', encoding='utf8')))
+        rows = list(csv.DictReader(open(root / args.out, encoding='utf8')))
         filled = sum(1 for r in rows if r.get('note_seq'))
-        res = {'workload': f'batch_infer.py --dataset DIR --model CKPT --csv: {args.clips} rows x {args.seconds:g} s int16 WAVs '
+        res = {'workload': f'batch_infer.py --dataset DIR --model CKPT --csv: {n_rows} rows x {args.seconds:g} s int16 WAVs '
                            f'({args.distinct or args.clips} distinct files) + transcriptions.csv -> CSV, lay {args.lay}, {world} process(es), '
                            f'model load included ({"warm" if cached else "cold"} weight cache)',
-               'rows': args.clips, 'rows_annotated': filled, 'wall_s': round(dt, 3), 'rows_per_s': round(args.clips / dt, 1),
-               'audio_s_per_s': round(args.clips * args.seconds / dt, 1), 'host_stages_s_rank0': {k: round(float(v), 3) for k, v in bi.LAST_STAGES.items()}}
+               'rows': n_rows, 'rows_annotated': filled, 'wall_s': round(dt, 3), 'rows_per_s': round(n_rows / dt, 1),
+               'audio_s_per_s': round(n_rows * args.seconds / dt, 1), 'host_stages_s_rank0': {k: round(float(v), 3) for k, v in bi.LAST_STAGES.items()}}
         if args.check > 0:
             # per-row recomputation through the reference's own granularity: Slicer.slice on the host + infer() per file
             import yaml
@@ -146,12 +160,28 @@ def main():
             res['recheck_note'] = ('rows recomputed alone through host Slicer + infer(), the reference\'s own granularity (batch_infer.py:49-81): a '
                                    'clip\'s result does not depend on its batch (clip-local attention key tiles), so the CSV cells are expected to be '
                                    'identical STRINGS')
+        if args.compare:
+            # this run's CSV against another arithmetic mode's (same rows by name): rows differing as strings, note boundaries (frames) differing
+            other = {r['name']: r for r in csv.DictReader(open(root / args.compare, encoding='utf8'))}
+            n_cmp = bad = notes = moved = 0
+            for r in rows:
+                o = other.get(r['name'])
+                if o is None or not r.get('note_dur') or not o.get('note_dur'):
+                    continue
+                n_cmp += 1
+                bad += (r['note_seq'] != o['note_seq']) or (r['note_dur'] != o['note_dur'])
+                ta = np.round(np.cumsum([float(x) for x in r['note_dur'].split()]) * 44100 / 512).astype(int)
+                tb = np.round(np.cumsum([float(x) for x in o['note_dur'].split()]) * 44100 / 512).astype(int)
+                notes += len(tb)
+                moved += len(set(ta.tolist()) ^ set(tb.tolist()))
+            res['compared_with'] = {'csv': args.compare, 'rows': n_cmp, 'rows_differing_as_strings': int(bad), 'note_boundaries': int(notes),
+                                    'note_boundaries_differing': int(moved)}
         if args.json:
             import json
             print(json.dumps(res))
         else:
-            print(f'batch_infer.py end to end ({world} process(es), model load + weight pack included): {args.clips} x {args.seconds:g} s in '
-                  f'{dt:.2f} s -> {args.clips * args.seconds / dt:.0f} audio-s/s; {filled}/{len(rows)} rows annotated')
+            print(f'batch_infer.py end to end ({world} process(es), model load + weight pack included): {n_rows} x {args.seconds:g} s in '
+                  f'{dt:.2f} s -> {n_rows * args.seconds / dt:.0f} audio-s/s; {filled}/{len(rows)} rows annotated')
     if tmp is not None:
         tmp.cleanup()
 

@@ -129,7 +129,7 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
     # persistent_workers=True) - here worker threads collating into pinned buffers + uploads on a copy stream (training/loader.py)
     loader = PrefetchLoader(train_set, cfg, trainer.ops.device, workers=int(cfg.get('ds_workers', 4)),
                             prefetch_factor=int(cfg.get('dataloader_prefetch_factor', 2)))
-    steps_per_epoch = max(1, len(sampler) // accumulate)
+    steps_per_epoch = max(1, -(-len(sampler) // accumulate))      # leftover micro-batches step the optimiser too (loop below): ceil
     epoch = trainer.global_step // steps_per_epoch
     skip = trainer.global_step % steps_per_epoch          # resumed inside an epoch: its first `skip` updates have been applied already
     t_train = time.perf_counter()
@@ -147,11 +147,13 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
                                     'training/batch_size': float(sum(int(m['units'].shape[0]) for m in micro)) / len(micro), 'training/lr': out['lr']}, step)
         if rank == 0 and (step % interval == 0 or step == total) and not out['skipped']:
             path = keeper.path_for(step)
-            torch.save(trainer.checkpoint(), path)
+            if keeper.wants(step):                       # num_ckpt_keep = 0: Lightning's save_top_k = 0 saves nothing (but permanent steps)
+                torch.save(trainer.checkpoint(), path)
             if val_sampler is not None:
                 validate(step)
-            for line in keeper.saved(path):
-                print(line)
+            if path.exists():
+                for line in keeper.saved(path):
+                    print(line)
 
     while trainer.global_step < total:
         sampler.set_epoch(epoch)
