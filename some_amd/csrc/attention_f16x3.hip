@@ -400,14 +400,421 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Args a, int nqb
     }
 }
 
+
+// =====================================================================================================================
+// Round 5: the inference kernel with the instruction stream PLACED.  profiles/r05_coissue_probe2.md: on a gfx950 SIMD up to five
+// plain VALU instructions (v_exp_f32 counts double) and at most one ds_read_b128 hide in the 32-cycle shadow of every
+// v_mfma_f32_32x32x16_f16 - 33.5 - 35.5 cycles per MFMA - but only where they are PUT there; the compiler's own order of the kernel
+// above (7 VALU per gap in the QK product, a 32-instruction O-rescale blob with the matrix pipe idle, back-to-back MFMA pairs in the PV
+// product) runs at 48.7.  Same operator, same operand layouts, same tiling (128 queries per workgroup, 32 per wavefront, 64-key tiles
+// counted from the clip's first frame, K ring one tile ahead of the V^T ring, one barrier per tile); what changes:
+//   * a tile step is 48 SLOTS = one MFMA + its share of everything else, fenced by sched_barrier(0): phase A = the 24 MFMAs of
+//     S(i+1) = K(i+1) Q^T beside exp2 of tile i and the P split of its first two slabs; phase B = the 24 MFMAs of O += V(i)^T P(i)^T
+//     beside the other two slabs' split, the row sums, the row maximum of S(i+1) and the K / V^T staging traffic.  About 4 VALU per
+//     slot by construction, fragment reads issued one slab ahead into the registers the previous slab has just retired;
+//   * the P split is 4 instructions per two probabilities instead of 6: hi = cvt_pkrtz(p0, p1), lo_j = p_j - f32(hi_j) as ONE
+//     v_fma_mix_f32 each (f16 source, full f32 destination - not the half-register v_fma_mixlo_f16 that round 4 measured slower),
+//     lo = cvt_pkrtz(lo0, lo1).  hi is the round-toward-zero f16 of p (what the mask produced), lo the rtz f16 of the exact rest;
+//   * LAZY rescale: the running maximum moves only when a tile's row maximum exceeds it by more than kLazy (2^4.5 in p) for some
+//     query of the wavefront - a wavefront-uniform branch between tiles; otherwise O and l are left alone (no 32 multiplies per tile)
+//     and P is taken against the old maximum.  P is carried as 2^kPShiftI p <= 2^(11 + 4.5) < 65504, so the f16 halves cannot
+//     overflow.  The decision depends on the wavefront's 32 queries and their clip's keys only: results stay independent of packing.
+#ifndef SOME_ATTN_ABL
+#define SOME_ATTN_ABL 0      // measurement builds only (tools/build_variant.py -DSOME_ATTN_ABL=mask): 1 no softmax VALU, 2 no fragment reads,
+#endif                       // 4 no staging traffic, 8 no barrier in the loop - results are garbage, only the time means something
+constexpr int kAbl = SOME_ATTN_ABL;
+#ifndef SOME_ATTN_DBG_WG
+#define SOME_ATTN_DBG_WG 2048      // (timeline builds, tools/attn_probe.hip) a workgroup of the second round
+#endif
+#ifndef SOME_ATTN_PRIO
+#define SOME_ATTN_PRIO 2      // s_setprio 1 over phase B (1) or phase A (2); measured 2.338 (0) / 2.333 (1) / 2.310 ms (2), profiles/r05_experiments.md
+#endif
+#ifndef SOME_ATTN_STAGE_SLOT
+#define SOME_ATTN_STAGE_SLOT 8
+#endif
+constexpr float kPShiftI = 11.f;
+constexpr float kLazy = 4.5f;
+
+// p - f32(half of hi_pk) as ONE v_fma_mix_f32: hipcc selects it for fma(fpext(f16), f32, f32) when the multiplier is not a constant it
+// can fold (`mone` = -1.0f built from a kernel argument), and - unlike inline asm - then knows the one-wait-state hazard between a
+// v_fma_mix write and a dependent read, so it puts an independent instruction there instead of an s_nop.
+__device__ __forceinline__ float mix_sub_(half_t h, float mone, float p) { return __builtin_fmaf((float)h, mone, p); }
+
+template <bool V>
+struct Flag { static constexpr bool value = V; };
+
+__global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nqb) {
+    constexpr int QB = 128;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int slot = jj / nqb, qb = jj % nqb;
+    const int unit = slot * 8 + xcd;
+    const int hg = unit % (kHeads * a.groups), b = unit / (kHeads * a.groups);
+    if (b >= a.B) return;
+    const int head = hg % kHeads, g = hg / kHeads;
+    const int fo = a.frame_offsets[b];                               // output rows (packed coordinates)
+    const int T = a.frame_offsets[b + 1] - fo;
+    const int f0 = a.pad_offsets[b];                                 // operand rows / V^T columns (clip-aligned)
+    const int q0 = qb * QB;
+    if (q0 >= T) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kg = lane >> 5;
+    constexpr size_t ROW_B = 2048;
+    const char* __restrict__ Qp = reinterpret_cast<const char*>(a.q[g]) + head * 256;
+    const char* __restrict__ Kp = reinterpret_cast<const char*>(a.k[g]) + head * 256;
+    const char* __restrict__ Vh = reinterpret_cast<const char*>(a.vt[g]) + (size_t)head * kHeadDim * a.ldv * 2;
+
+    half8 qh[4], ql[4];
+    {
+        const int q = q0 + wave * 32 + l31;
+        const bool qv = q < T;
+        const char* row = Qp + (size_t)(f0 + (qv ? q : 0)) * ROW_B;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int off = (s >> 1) * 128 + (s & 1) * 32 + kg * 16;
+            qh[s] = *reinterpret_cast<const half8*>(row + off);
+            ql[s] = *reinterpret_cast<const half8*>(row + off + 64);
+            if (!qv) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { qh[s][i] = (half_t)0; ql[s][i] = (half_t)0; }
+            }
+        }
+    }
+
+    const int srow = tid >> 4, sc = tid & 15;
+    const int kt0 = f0;
+    const int n = (T + KT - 1) / KT;
+    f32x4 rk[4], rv[4];
+    const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(Kp), 0, (int)((size_t)a.M * ROW_B - head * 256 > 0x7fffffffull ? 0x7fffffffull : (size_t)a.M * ROW_B - head * 256), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(Vh), 0, (int)((size_t)(2 * kDim - head * kHeadDim) * a.ldv * 2), 0x00020000);
+    uint32_t voff_v[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        voff_v[p] = (uint32_t)(srow + 16 * p) * (uint32_t)a.ldv * 2u + (uint32_t)(sc & 7) * 16u + (sc < 8 ? 0u : (uint32_t)kDim * (uint32_t)a.ldv * 2u);
+    auto gload_k1 = [&](int i, int p) {
+        rk[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsk, (uint32_t)(kt0 + i * KT + srow + 16 * p) * (uint32_t)ROW_B + sc * 16u, 0, 0));
+    };
+    auto gload_v1 = [&](int i, int p) {
+        rv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsv, voff_v[p], (uint32_t)(kt0 + i * KT) * 2u, 0));
+    };
+    auto kbuf = [&](int i) { return lds + (i & 1) * K_DW; };
+    auto vbuf = [&](int i) { return lds + 2 * K_DW + (i & 1) * V_DW; };
+    auto lstore_k1 = [&](int i, int p) { *reinterpret_cast<f32x4*>(kbuf(i) + (srow + 16 * p) * LDR + sc * 4) = rk[p]; };
+    auto lstore_v1 = [&](int i, int p) { *reinterpret_cast<f32x4*>(vbuf(i) + (srow + 16 * p) * LDR + sc * 4) = rv[p]; };
+
+    // fragments: kf = {kh0, kl0, kh1, kl1} of a k = 16 slab of the K tile (two 32-key sub-tiles), vf = {vh0, vl0, vh1, vl1} of a
+    // 16-key slab of the V^T tile (two 32-row d halves).  Every read lands in the register its predecessor has just left.
+    half8 kf[4], vf[4];
+    auto read_k1 = [&](int i, int s, int j) {        // j: 0 kh0, 1 kl0, 2 kh1, 3 kl1
+        if ((kAbl & 2) && i > 1) return;
+        const float* kp = kbuf(i) + l31 * LDR + kg * 4 + (s >> 1) * 32 + (s & 1) * 8;
+        kf[j] = *reinterpret_cast<const half8*>(kp + (j >> 1) * 32 * LDR + (j & 1) * 16);
+    };
+    auto read_v1 = [&](int i, int q, int j) {        // slab q = 2 sub + sp; j: 0 vh0, 1 vl0, 2 vh1, 3 vl1
+        if ((kAbl & 2) && i > 0) return;
+        const float* vp = vbuf(i) + l31 * LDR + 4 * kg + 16 * (q >> 1) + 8 * (q & 1);
+        vf[j] = *reinterpret_cast<const half8*>(vp + (j >> 1) * 32 * LDR + (j & 1) * 32);
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f, nm = 0.f;
+    const float c = 0.125f * 1.4426950408889634f;
+
+    // Row maximum of a tile's raw scores (both lane halves), scaled; then the lazy update of the running maximum.
+    auto rowmax = [&](const f32x16& s0, const f32x16& s1) {
+        float mxa = max2_(s0[0], s1[0]), mxb = max2_(s0[1], s1[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) {
+            mxa = max3_(mxa, s0[r], s1[r]);
+            mxb = max3_(mxb, s0[r + 1], s1[r + 1]);
+        }
+        float mx = max2_(mxa, mxb);
+        mx = max2_(mx, __shfl_xor(mx, 32, 64));
+        return mx * c;
+    };
+    auto lazy_rescale = [&](float mx) {
+        if (__builtin_amdgcn_ballot_w64(mx > m_run + kLazy) != 0) {      // wavefront-uniform (first tile: m_run = -inf)
+            const float m_new = max2_(m_run, mx);                        // finite: every tile holds at least one key of the clip
+            const float alpha = exp2_(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+        nm = kPShiftI - m_run;
+    };
+    auto mask_tile = [&](int i, f32x16& s0, f32x16& s1) {
+        const int gbase = i * KT;                                        // clip-local key index of the tile's first key
+        if (gbase + KT > T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k0 = gbase + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (k0 >= T) s0[r] = -INFINITY;
+                if (k0 + 32 >= T) s1[r] = -INFINITY;
+            }
+        }
+    };
+
+    const float mone = __builtin_bit_cast(float, 0xBF800000u | ((uint32_t)a.B >> 30));      // -1.0f the compiler cannot fold (B < 2^30)
+    // P split state: pair j of slab q covers P elements 8 q + 2 j, + 1 (element e: e < 16 ? c0[e] : c1[e - 16])
+    uint32_t hpk[4][4];            // [slab][pair] packed hi halves
+    uint32_t lpk[4][4];            // [slab][pair] packed lo halves
+    float lo0_[4][4];              // first half-step's leftover
+    auto pel = [&](const f32x16& c0, const f32x16& c1, int e) -> float { return e < 16 ? c0[e] : c1[e - 16]; };
+    auto split_half = [&](f32x16& c0, f32x16& c1, int q, int j, int half) {
+        const float p0 = pel(c0, c1, 8 * q + 2 * j), p1 = pel(c0, c1, 8 * q + 2 * j + 1);
+        if (half == 0) {
+            const half2_t hh = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+            hpk[q][j] = __builtin_bit_cast(uint32_t, hh);
+            lo0_[q][j] = mix_sub_(hh[0], mone, p0);
+        } else {
+            const half2_t hh = __builtin_bit_cast(half2_t, hpk[q][j]);
+            const float l1 = mix_sub_(hh[1], mone, p1);
+            lpk[q][j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo0_[q][j], l1));
+        }
+    };
+    auto frag_of = [&](const uint32_t (&w)[4]) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = {w[0], w[1], w[2], w[3]};
+        return __builtin_bit_cast(half8, v);
+    };
+    float ps0 = 0.f, ps1 = 0.f;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // One tile step.  c0 / c1: raw scores of tile i on entry, its probabilities afterwards.  n0 / n1: receive S(i+1).
+    //   FULL: tiles i + 1 .. i + 3 all exist and tile i + 1 needs no masking (interior of the clip).  QK = false: last tile (no S(i+1)).
+    auto step = [&](int i, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1, auto full_, auto qk_) {
+        constexpr bool FULL = decltype(full_)::value, QK = decltype(qk_)::value;
+        // ---- phase A: S(i+1) = K(i+1) Q^T  |  P(i) = exp2(S(i) c + nm), split of slabs 0 and 1, staging
+        if (SOME_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+        if constexpr (QK) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) read_k1(i + 1, 0, j);
+        }
+#pragma unroll
+        for (int t = 0; t < 24; ++t) {
+            const int s = t / 6, u = t % 6;
+            if constexpr (QK) {
+                // kl0 qh, kl1 qh, kh0 ql, kh1 ql, kh0 qh, kh1 qh
+                const half8& ka = kf[u == 0 ? 1 : u == 1 ? 3 : (u & 1) ? 2 : 0];
+                const half8& qb_ = (u == 2 || u == 3) ? ql[s] : qh[s];
+                f32x16& acc = (u & 1) ? n1 : n0;
+                acc = mfma_hi<false>(ka, qb_, (t < 2) ? zero16 : acc);
+                // the next slab's fragments into the registers that have just been read for the last time
+                if (s < 3) {
+                    if (u == 0) read_k1(i + 1, s + 1, 1);
+                    if (u == 1) read_k1(i + 1, s + 1, 3);
+                    if (u == 4) read_k1(i + 1, s + 1, 0);
+                    if (u == 5) read_k1(i + 1, s + 1, 2);
+                }
+            }
+            // staging, EARLY in the step (slots 8 - 15): K tile i + 2 and V^T tile i + 1 out of the registers into the rings, the next loads
+            // behind them.  The ring stores then have 32 slots to drain before the barrier's lgkmcnt(0); at the END of the step they cost
+            // 0.6 ms per launch (profiles/r05_experiments.md: ablations 16 / 32 / 8 - it is the store -> barrier wait, not the loads)
+            if (t >= SOME_ATTN_STAGE_SLOT && t < SOME_ATTN_STAGE_SLOT + 8 && !(kAbl & 4)) {
+                const int p = (t - SOME_ATTN_STAGE_SLOT) & 3;
+                if (t < SOME_ATTN_STAGE_SLOT + 4) {
+                    if (!(kAbl & 32)) { if (FULL || i + 2 < n) lstore_k1(i + 2, p); } else asm volatile("" :: "v"(rk[p]));
+                    if (!(kAbl & 16)) { if (FULL || i + 3 < n) gload_k1(i + 3, p); }
+                } else {
+                    if (!(kAbl & 32)) { if (FULL || i + 1 < n) lstore_v1(i + 1, p); } else asm volatile("" :: "v"(rv[p]));
+                    if (!(kAbl & 16)) { if (FULL || i + 2 < n) gload_v1(i + 2, p); }
+                }
+            }
+            if (t >= 20) read_v1(i, 0, t - 20);                   // first slab of the PV product (V^T tile i: visible since the last barrier)
+            if ((kAbl & 1) && i > 0) {
+            } else if (t < 8) {
+#pragma unroll
+                for (int e = 2 * t; e < 2 * t + 2; ++e) c0[e] = exp2_(fmaf(c0[e], c, nm));
+            } else {
+                const int j = t - 8;                              // 0 .. 15
+                c1[j] = exp2_(fmaf(c1[j], c, nm));
+                split_half(c0, c1, j >> 3, (j >> 1) & 3, j & 1);  // slab 0 in slots 8 - 15, slab 1 in 16 - 23
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (SOME_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        if constexpr (QK && !FULL) mask_tile(i + 1, n0, n1);
+        // ---- phase B: O += V(i)^T P(i)^T  |  split of slabs 2 and 3, row sums, row maximum of S(i+1)
+        float mxa = 0.f, mxb = 0.f;
+        if (SOME_ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < 24; ++t) {
+            const int q = t / 6, u = t % 6;
+            {
+                // vl0 ph, vl1 ph, vh0 pl, vh1 pl, vh0 ph, vh1 ph
+                const half8& va = vf[u == 0 ? 1 : u == 1 ? 3 : (u & 1) ? 2 : 0];
+                const half8 pb = (u == 2 || u == 3) ? frag_of(lpk[q]) : frag_of(hpk[q]);
+                if (u & 1) o1 = mfma_hi<false>(va, pb, o1);
+                else o0 = mfma_hi<false>(va, pb, o0);
+                if (q < 3) {
+                    if (u == 0) read_v1(i, q + 1, 1);
+                    if (u == 1) read_v1(i, q + 1, 3);
+                    if (u == 4) read_v1(i, q + 1, 0);
+                    if (u == 5) read_v1(i, q + 1, 2);
+                }
+            }
+            // split: slab 2 in slots 2 - 9, slab 3 in slots 8 - 15 (half a pair per slot)
+            if (!((kAbl & 1) && i > 0)) {
+            if (t >= 2 && t < 10) split_half(c0, c1, 2, (t - 2) >> 1, (t - 2) & 1);
+            if (t >= 8 && t < 16) split_half(c0, c1, 3, (t - 8) >> 1, (t - 8) & 1);
+            // row sums: 32 probabilities over slots 0 - 15
+            if (t < 16) { ps0 += pel(c0, c1, 2 * t); ps1 += pel(c0, c1, 2 * t + 1); }
+            }
+            // staging: K tile i + 2 and V^T tile i + 1 out of the registers into the rings, the next loads behind them
+            // row maximum of S(i+1): two chains over slots 16 - 23
+            if constexpr (QK && !(kAbl & 1)) {
+                if (t == 16) { mxa = max2_(n0[0], n1[0]); mxb = max2_(n0[1], n1[1]); }
+                if (t > 16) {
+                    const int r = 2 * (t - 16);
+                    mxa = max3_(mxa, n0[r], n1[r]);
+                    mxb = max3_(mxb, n0[r + 1], n1[r + 1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (SOME_ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        l_run += ps0 + ps1;
+        ps0 = 0.f; ps1 = 0.f;
+        if constexpr (QK && !(kAbl & 1)) {
+            float mx = max2_(mxa, mxb);
+            mx = max2_(mx, __shfl_xor(mx, 32, 64)) * c;
+            lazy_rescale(mx);
+        }
+#ifdef SOME_ATTN_DBG
+        const bool dbg_wg = blockIdx.x == SOME_ATTN_DBG_WG;
+        unsigned long long* dbg_l = reinterpret_cast<unsigned long long*>(lds + LDS_BYTES / 4);      // (the probe launches with 4 KiB more LDS)
+        if (dbg_wg && lane == 0) dbg_l[i * 8 + wave * 2] = __builtin_amdgcn_s_memtime();
+#endif
+        if (!(kAbl & 8)) __syncthreads();
+#ifdef SOME_ATTN_DBG
+        if (dbg_wg && lane == 0) dbg_l[i * 8 + wave * 2 + 1] = __builtin_amdgcn_s_memtime();
+#endif
+    };
+
+    // ---- prologue: tiles 0 (both rings), 1 (K ring; V^T in registers), 2 (K in registers); S(0) unscheduled
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { gload_k1(0, p); gload_v1(0, p); }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { lstore_k1(0, p); lstore_v1(0, p); }
+    if (n > 1) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) gload_k1(1, p);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { lstore_k1(1, p); gload_v1(1, p); }
+    }
+    if (n > 2) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) gload_k1(2, p);
+    }
+    __syncthreads();
+    f32x16 sa0, sa1, sb0, sb1;
+    // A wavefront whose 32 queries all lie behind the clip's end (the last 128-query block of a clip: T = 2584 leaves 24 queries for
+    // wavefront 0 and none for the other three) only keeps its staging role and the barriers: its matrix-pipe and VALU slots go to the
+    // other workgroup of the CU (3 of 84 wavefront-blocks per clip and head at 30 s)
+    const bool active = q0 + wave * 32 < T;
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) read_k1(0, s, j);
+            sa0 = mfma_hi<false>(kf[1], qh[s], s == 0 ? zero16 : sa0);
+            sa1 = mfma_hi<false>(kf[3], qh[s], s == 0 ? zero16 : sa1);
+            sa0 = mfma_hi<false>(kf[0], ql[s], sa0);
+            sa1 = mfma_hi<false>(kf[2], ql[s], sa1);
+            sa0 = mfma_hi<false>(kf[0], qh[s], sa0);
+            sa1 = mfma_hi<false>(kf[2], qh[s], sa1);
+        }
+        mask_tile(0, sa0, sa1);
+        lazy_rescale(rowmax(sa0, sa1));
+    }
+    // S(0) read K ring slot 0 and the first step stores K(2) into it (the round-1 race, see attention3_kernel)
+    __syncthreads();
+    int i = 0;
+    if (active) {
+        for (; i + 4 < n; i += 2) {
+            step(i, sa0, sa1, sb0, sb1, Flag<true>{}, Flag<true>{});
+            step(i + 1, sb0, sb1, sa0, sa1, Flag<true>{}, Flag<true>{});
+        }
+        for (; i + 2 < n; i += 2) {
+            step(i, sa0, sa1, sb0, sb1, Flag<false>{}, Flag<true>{});
+            step(i + 1, sb0, sb1, sa0, sa1, Flag<false>{}, Flag<true>{});
+        }
+        if (i + 1 < n) {
+            step(i, sa0, sa1, sb0, sb1, Flag<false>{}, Flag<true>{});
+            step(i + 1, sb0, sb1, sa0, sa1, Flag<false>{}, Flag<false>{});
+        } else {
+            step(i, sa0, sa1, sb0, sb1, Flag<false>{}, Flag<false>{});
+        }
+    } else {
+        for (; i < n; ++i) {                       // the same ring traffic and barriers as step(i), nothing else
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (i + 2 < n) lstore_k1(i + 2, p);
+                if (i + 3 < n) gload_k1(i + 3, p);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (i + 1 < n) lstore_v1(i + 1, p);
+                if (i + 2 < n) gload_v1(i + 2, p);
+            }
+            __syncthreads();
+        }
+    }
+
+#ifdef SOME_ATTN_DBG
+    if (blockIdx.x == SOME_ATTN_DBG_WG) {
+        __syncthreads();
+        const unsigned long long* dbg_l = reinterpret_cast<const unsigned long long*>(lds + LDS_BYTES / 4);
+        for (int j = tid; j < n * 8; j += 256) g_attn_dbg[j] = dbg_l[j];
+    }
+#endif
+    // ---- normalise, transpose through LDS (wave-private 32 x 64 patch), SPLIT32 row stores (the last step ended with a barrier)
+    float* patch = lds + wave * (32 * LDR);
+    {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = (r & 3) + 8 * (r >> 2) + 4 * kg;
+            patch[l31 * LDR + d] = o0[r] * inv;
+            patch[l31 * LDR + 32 + d] = o1[r] * inv;
+        }
+        __syncthreads();
+        const int orow = lane >> 4, ocol = (lane & 15) * 4;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int ql_ = orow + 4 * p;
+            const int q = q0 + wave * 32 + ql_;
+            if (q < T) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(patch + ql_ * LDR + ocol);
+                half4 hh, ll;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { half_t h, l; split_f16(v[e], h, l); hh[e] = h; ll[e] = l; }
+                char* row = reinterpret_cast<char*>(a.out[g]) + ((size_t)(fo + q) * kDim + head * kHeadDim) * 4 + (ocol >> 5) * 128 + (ocol & 31) * 2;
+                *reinterpret_cast<half4*>(row) = hh;
+                *reinterpret_cast<half4*>(row + 64) = ll;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
     if (a.B <= 0 || a.max_frames <= 0) return hipSuccess;
     static bool attr_set = false;
+    static const bool placed = !(getenv("SOME_AMD_ATTN_V1") && getenv("SOME_AMD_ATTN_V1")[0] == '1');       // A/B switch: the round-1..4 kernel
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3i_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -426,6 +833,7 @@ hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
     if (!inference && a.hi_only == 2) hipLaunchKernelGGL((attention3_kernel<true, 1, true>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else if (!inference && a.hi_only) hipLaunchKernelGGL((attention3_kernel<true, 1>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else if (!inference) hipLaunchKernelGGL(attention3_kernel<true>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    else if (placed) hipLaunchKernelGGL(attention3i_kernel, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else hipLaunchKernelGGL(attention3_kernel<false>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     return hipGetLastError();
 }

@@ -272,7 +272,7 @@ def test_training_trajectory_matches_reference(golden_dir, precision):
             e = np.abs(got - want).max() / np.abs(want).max()
             worst['bn'] = max(worst['bn'], e)
             assert e < tol, (step, leaf, e)
-        assert int(P[bn.replace('running_mean', 'num_batches_tracked')]) == int(g['bn_cnt'][step]) == step + 1
+        assert int(P[bn.replace('running_mean', 'num_batches_tracked')]) == int(g['bn_cnt'][step]) == int(g['bn_cnt'][0]) + step
     assert tr.global_step == steps
     # every parameter at the end: norm to 2e-4, and the distance travelled from the initial weights (sum digest) on the right scale
     for name in g['names']:
