@@ -24,6 +24,9 @@ constexpr size_t DBG_LDS = 4096;
 #else
 constexpr size_t DBG_LDS = 0;
 #endif
+#ifndef PROBE_DMA
+#define PROBE_DMA true
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 
 int main(int argc, char** argv) {
@@ -91,10 +94,10 @@ int main(int argc, char** argv) {
         for (int g = 0; g < groups; ++g) a.out[g] = out[v][g];
         const unsigned nqb = (T + 127) / 128, units = B * 8 * groups, slots = (units + 7) / 8;
         auto launch = [&]() {
-            if (v == 0) hipLaunchKernelGGL(attention3i_kernel, dim3(slots * nqb * 8), dim3(256), LDS_BYTES + DBG_LDS, 0, a, (int)nqb);
+            if (v == 0) hipLaunchKernelGGL(attention3i_kernel<PROBE_DMA>, dim3(slots * nqb * 8), dim3(256), LDS_BYTES + DBG_LDS, 0, a, (int)nqb);
             else hipLaunchKernelGGL(attention3_kernel<false>, dim3(slots * nqb * 8), dim3(256), LDS_BYTES, 0, a, (int)nqb);
         };
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3i_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BYTES + DBG_LDS)));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3i_kernel<PROBE_DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BYTES + DBG_LDS)));
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         for (int w = 0; w < 3; ++w) launch();
         CK(hipDeviceSynchronize());
