@@ -18,6 +18,8 @@
 //               conform_ffn's output dropout, folded into the second linear
 // so the FFN's [M, 2048] intermediates exist ONLY as 16-bit arrays (h16 and a16 forward, dh16 backward) and no element-wise pass
 // runs between the four GEMMs.
+#include <cstdlib>
+
 #include "internal.h"
 #include "split.h"
 
@@ -469,7 +471,15 @@ hipError_t launch_gemm16s(int epi, const void* A16, int lda, const void* B16, in
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldh = ldh; a.plane = (uint32_t)plane_bytes;
     drop_params(p, seed, a.thr, a.keep, a.k0, a.k1);
     a.alpha = alpha;
-#define G16S_CASE(E) case E: return bf16 ? launch16s<E, true>(a, s) : launch16s<E, false>(a, s);
+    // Tile by grid size (round 5): the 128 x 256 tile gives an N = 512 GEMM over the reference's batch shape (8 x ~520 frames,
+    // configs/base.yaml:55-56) 33 x 2 = 66 workgroups on 256 CUs - a quarter of the chip, 25 - 35 us of which 4 us are arithmetic.  Below
+    // ~3/4 of a round of big tiles the 64 x 128 tile (2 wavefronts, 36 KB of LDS, up to 4 workgroups per CU) takes over: 4 x the
+    // workgroups, the same k order per element - results bit-identical (tests/test_gpu_train_ffn16.py).
+    static const int force = getenv("SOME_AMD_G16S_TILE") ? atoi(getenv("SOME_AMD_G16S_TILE")) : -1;     // A/B: 0 big, 1 small
+    const long big_wgs = (long)((M + 127) / 128) * ((N + 255) / 256);
+    const bool small = force >= 0 ? force == 1 : big_wgs < 192;
+#define G16S_CASE(E) case E: return small ? (bf16 ? launch16s<E, true, 1, 2, 3, 4>(a, s) : launch16s<E, false, 1, 2, 3, 4>(a, s)) \
+                                          : (bf16 ? launch16s<E, true>(a, s) : launch16s<E, false>(a, s));
     switch (epi) {
         G16S_CASE(G16S_F32) G16S_CASE(G16S_FFN1) G16S_CASE(G16S_DSILU) G16S_CASE(G16S_RESDROP)
     }

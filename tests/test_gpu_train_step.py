@@ -277,6 +277,10 @@ def test_training_trajectory_matches_reference(golden_dir, precision):
     # every parameter at the end: norm to 2e-4, and the distance travelled from the initial weights (sum digest) on the right scale
     for name in g['names']:
         key = str(name)
+        if key.endswith('conv.depthwise_conv.bias'):
+            # feeds BatchNorm(train), which removes it: the true gradient is 0, both sides hold rounding noise, and AdamW turns noise into
+            # +-lr steps of either sign (the one-step test skips the same tensors)
+            continue
         v = P.views[key].detach().double().cpu().numpy().reshape(-1)
         ref = g['final.' + key]
         assert abs(np.sqrt((v * v).sum()) - ref[9]) < tol * max(ref[9], 1e-3), key
