@@ -354,6 +354,11 @@ int some_train_dwconv_bwd_taps(SomeHandle* h, const float* dy_dev, const float* 
 int some_train_bce_with_logits(SomeHandle* h, const float* logits_dev, const float* target_dev, int64_t n,
                                float* dlogits_dev, float* loss_dev, void* scratch_dev, size_t scratch_bytes,
                                void* stream);
+/* nn.CrossEntropyLoss(ignore_index) over the rows of logits [M, N] with int64 class targets [M] (training/me_quant_task.py:42,77:
+ * QuantizedMIDIExtractionTask's 129-way midi loss, padding frames carry -1): loss_dev[0] = mean over the rows whose target is not
+ * ignore_index (NaN when there is none, as torch) and, when dlogits_dev is not NULL, d loss / d logits.  scratch_dev: 1025 doubles. */
+int some_train_cross_entropy(SomeHandle* h, const float* logits_dev, const int64_t* target_dev, int32_t M, int32_t N, int64_t ignore_index,
+                             float* dlogits_dev, float* loss_dev, void* scratch_dev, size_t scratch_bytes, void* stream);
 /* modules.losses.BinaryEMDLoss() (modules/losses/bound_loss.py:6-19, bidirectional=False) on [B, T] rows. */
 int some_train_binary_emd(SomeHandle* h, const float* pred_dev, const float* gt_dev, int32_t B, int32_t T,
                           float* dpred_dev, float* loss_dev, void* scratch_dev, size_t scratch_bytes, void* stream);

@@ -561,6 +561,87 @@ def gen_train_trajectory():
     print('train_trajectory.npz', len(out), 'losses', rows['bound_loss'], rows['midi_loss'], 'lr', rows['lr'], 'norm', rows['grad_norm'])
 
 
+def synth_quant_batch(B=2, T=96, seed=33):
+    """Items shaped like the quantised binarizer's (preprocessing/me_quant_binarizer.py:12-32): units, pitch, integer note classes
+    (128 = rest), note durations in frames, the 1-based frame -> note map; the second item is shorter (padding in the batch)."""
+    rng = np.random.default_rng(seed)
+    items = []
+    for b in range(B):
+        valid = T if b == 0 else T - 26
+        edges = np.sort(rng.choice(np.arange(1, valid), size=6, replace=False))
+        unit2note = 1 + np.searchsorted(edges, np.arange(valid), side='right')
+        note_midi = rng.integers(40, 80, size=7)
+        note_midi[rng.integers(0, 7)] = 128
+        items.append({'units': (rng.standard_normal((valid, 80)) * 1.5 - 4.0).astype(np.float32), 'pitch': np.zeros(valid, np.float32),
+                      'note_midi': note_midi.astype(np.int64), 'note_dur': np.bincount(unit2note, minlength=8)[1:].astype(np.int64),
+                      'unit2note': unit2note.astype(np.int64)})
+    return items
+
+
+def _ref_quant_collater():
+    """QuantizedMIDIExtractionDataset.collater (training/me_quant_task.py:14-27) executed from the reference's own source text: the module
+    itself cannot be imported here (lightning, torchmetrics), so the method's lines are compiled alone with what they name - torch, F,
+    the reference's ``collate_nd`` (utils/__init__.py:25-34, compiled the same way) - and ``super().collater`` (training/base_task.py:73-76:
+    ``{'size': len(samples)}``) written out."""
+    import ast
+    import textwrap
+    ns = {'torch': torch, 'F': torch.nn.functional}
+    tree = ast.parse((REF / 'utils/__init__.py').read_text())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'collate_nd')
+    exec(compile(ast.Module([fn], []), 'ref_collate_nd', 'exec'), ns)
+    src = (REF / 'training/me_quant_task.py').read_text()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'QuantizedMIDIExtractionDataset')
+    meth = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == 'collater')
+    text = textwrap.dedent(ast.get_source_segment(src, meth)).replace('super().collater(samples)', "{'size': len(samples)}")
+    assert "{'size': len(samples)}" in text
+    exec(compile(text, 'ref_quant_collater', 'exec'), ns)
+    return lambda samples: ns['collater'](None, samples)
+
+
+def gen_train_quant():
+    """One training step of ``QuantizedMIDIExtractionTask`` (training/me_quant_task.py:30-78): the reference model with 129 classes, raw
+    logits (softmax=False), nn.CrossEntropyLoss(ignore_index=-1) + BinaryEMDLoss, torch autograd, AdamW - digests as gen_train.  The batch
+    comes out of the reference's own collater text (_ref_quant_collater) and is stored, so the GPU test can also pin
+    some_amd.training.data.quant_collater against it."""
+    import copy
+    cfg = get_config('quant_two_head_model', lay=1)
+    assert cfg['midi_num_bins'] == 129
+    for k in ('conv_drop', 'ffn_latent_drop', 'ffn_out_drop', 'attention_drop'):
+        cfg['midi_extractor_args'][k] = 0.0
+    model = RefModel(copy.deepcopy(cfg)).train()
+    sd = synth.synth_state_dict(cfg, 37)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    ref_losses = _load_file('ref_bound_loss', REF / 'modules/losses/bound_loss.py')
+    items = synth_quant_batch()
+    batch = _ref_quant_collater()([{k: torch.from_numpy(v) for k, v in it.items()} for it in items])
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4 * (1 / 10000), betas=(0.9, 0.98), weight_decay=0)   # WarmupLR(10000) at step 1
+    mask = batch['unit2note'] > 0
+    probs, bounds = model(x=batch['units'], f0=batch['pitch'], mask=mask, softmax=False)
+    bound_loss = ref_losses.BinaryEMDLoss(bidirectional=False)(bounds, batch['bounds'])
+    midi_loss = torch.nn.CrossEntropyLoss(ignore_index=-1)(probs.transpose(1, 2), batch['midi_idx'])
+    (bound_loss + midi_loss).backward()
+    out = {'bound_loss': np.array(bound_loss.item()), 'midi_loss': np.array(midi_loss.item()), 'weights_seed': np.array(37)}
+    for i, it in enumerate(items):
+        for k, v in it.items():
+            out[f'item{i}.{k}'] = v
+    for k in ('units', 'note_midi', 'note_dur', 'unit2note', 'midi_idx', 'bounds'):
+        out['batch.' + k] = batch[k].numpy()
+    names = []
+    for name, p in model.named_parameters():
+        out['grad.' + name] = _grad_digest(name, p)
+        out['sk.' + name] = grad_sketch(name, p.grad.detach().numpy())
+        names.append(name)
+    out['grad_norm'] = np.array(float(torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.get('clip_grad_norm', 1.0))))
+    opt.step()
+    for name, p in model.named_parameters():
+        v = p.detach().numpy().astype(np.float64).reshape(-1)
+        out['after.' + name] = np.array(list(v[:8]) + [0.0] * max(0, 8 - v.size) + [v.sum()])
+    out['names'] = np.array(names)
+    np.savez_compressed(OUT / 'train_step_quant.npz', **out)
+    print('train_step_quant.npz', len(out), 'bound_loss', bound_loss.item(), 'midi_loss', midi_loss.item(), 'valid frames', int((batch['midi_idx'] >= 0).sum()))
+
+
 def gen_lr_schedule():
     """lr_scheduler.scheduler.WarmupLR (the reference's class, on a dummy optimiser) at a few update counts."""
     sched = _load_file('ref_scheduler', REF / 'lr_scheduler/scheduler.py')
@@ -774,6 +855,7 @@ if __name__ == '__main__':
     gen_train()
     gen_train_bf16()
     gen_train_trajectory()
+    gen_train_quant()
     gen_lr_schedule()
     gen_e2e()
     gen_fullsize()

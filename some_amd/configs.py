@@ -94,6 +94,14 @@ _CONFIGS = {
         model_cls='modules.model.Gmidi_conform.midi_conforms',
         task_cls='training.QuantizedMIDIExtractionTask',
         midi_extractor_args=_extractor_args(3),
+        # training keys (configs/quant_two_head_model.yaml:24-45, configs/discrete.yaml:14-15)
+        use_bound_loss=True,
+        use_midi_loss=True,
+        optimizer_args={'optimizer_cls': 'torch.optim.AdamW', 'lr': 0.0001, 'beta1': 0.9, 'beta2': 0.98, 'weight_decay': 0},
+        lr_scheduler_args={'scheduler_cls': 'lr_scheduler.scheduler.WarmupLR', 'warmup_steps': 10000, 'min_lr': 0.00001},
+        max_batch_size=8,
+        max_batch_frames=80000,
+        clip_grad_norm=1,
     ),
 }
 

@@ -236,6 +236,7 @@ hipError_t launch_dwconv_train(const float* x, const float* w, const float* bias
 hipError_t launch_dwconv_bwd_w(const float* dy, const float* x, const int32_t* clip_of_row, const int32_t* frame_offsets, int M, int C, float* dw,
                                int accumulate, float* scratch, hipStream_t s);
 hipError_t launch_bce(const float* x, const float* t, int64_t n, float* dx, float* loss, double* scratch, hipStream_t s);
+hipError_t launch_cross_entropy(const float* x, const int64_t* target, int M, int N, int64_t ignore, float* dx, float* loss, double* scratch, hipStream_t s);
 hipError_t launch_emd(const float* pred, const float* gt, int B, int T, float* dpred, float* loss, double* scratch, hipStream_t s);
 hipError_t launch_sumsq(const float* x, int64_t n, double* out, double* scratch, hipStream_t s);
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,

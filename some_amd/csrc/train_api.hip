@@ -395,6 +395,15 @@ int some_train_bce_with_logits(SomeHandle* h, const float* logits_dev, const flo
     return SOME_OK;
 }
 
+int some_train_cross_entropy(SomeHandle* h, const float* logits_dev, const int64_t* target_dev, int32_t M, int32_t N, int64_t ignore_index,
+                             float* dlogits_dev, float* loss_dev, void* scratch_dev, size_t scratch_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M > 0 && N > 0 && logits_dev && target_dev && loss_dev, "some_train_cross_entropy: bad argument");
+    T_CHECK(h, scratch_dev && scratch_bytes >= 1025 * sizeof(double), "some_train_cross_entropy: scratch too small");
+    T_TRY(h, launch_cross_entropy(logits_dev, target_dev, M, N, ignore_index, dlogits_dev, loss_dev, static_cast<double*>(scratch_dev), st(stream)));
+    return SOME_OK;
+}
+
 int some_train_binary_emd(SomeHandle* h, const float* pred_dev, const float* gt_dev, int32_t B, int32_t T,
                           float* dpred_dev, float* loss_dev, void* scratch_dev, size_t scratch_bytes, void* stream) {
     if (!h) return SOME_EINVAL;

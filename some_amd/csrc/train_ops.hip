@@ -531,6 +531,60 @@ __global__ void sum_partials_kernel(const double* __restrict__ partial, int P, d
     }
 }
 
+// nn.CrossEntropyLoss(ignore_index) over rows of logits [M, N] (training/me_quant_task.py:42,77: 129 classes, target -1 = padding):
+//   loss = mean over the rows with target != ignore of (logsumexp(x) - x[target]);  d loss / dx = (softmax(x) - onehot) / count on those rows, 0 elsewhere.
+// ce_count_kernel: one workgroup counts the valid rows (device scalar: the mean's denominator is needed by every gradient element);
+// ce_kernel: a wavefront per row (max, sum of exp, gradient), the workgroup's four row losses -> one partial.
+__global__ __launch_bounds__(256) void ce_count_kernel(const int64_t* __restrict__ target, int M, int64_t ignore, float* __restrict__ count) {
+    __shared__ int red[4];
+    int c = 0;
+    for (int i = threadIdx.x; i < M; i += 256) c += target[i] != ignore;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) count[0] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ x, const int64_t* __restrict__ target, int M, int N, int64_t ignore,
+                                                  const float* __restrict__ count, float* __restrict__ dx, double* __restrict__ partial) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv = 1.0f / count[0];                   // count = 0: inf, and the mean over no rows is NaN as in torch
+    double acc = 0.0;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float* xr = x + (size_t)row * N;
+        const int64_t t = target[row];
+        if (t == ignore) {
+            if (dx) for (int j = lane; j < N; j += 64) dx[(size_t)row * N + j] = 0.f;
+            continue;
+        }
+        float mx = -INFINITY;
+        for (int j = lane; j < N; j += 64) mx = fmaxf(mx, xr[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float se = 0.f;
+        for (int j = lane; j < N; j += 64) se += __expf(xr[j] - mx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+        const float lse = mx + __logf(se);
+        if (lane == 0) acc += (double)(lse - xr[t]);
+        if (dx) {
+            const float rs = inv / se;
+            for (int j = lane; j < N; j += 64) dx[(size_t)row * N + j] = __expf(xr[j] - mx) * rs - (j == (int)t ? inv : 0.f);
+        }
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void ce_finish_kernel(const double* __restrict__ partial, int P, const float* __restrict__ count, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int p = 0; p < P; ++p) s += partial[p];
+        out[0] = (float)(s / (double)count[0]);
+    }
+}
+
 // sum of squares of a flat array (global gradient norm for clip_grad_norm); NaN / inf propagate into the result
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ partial) {
     __shared__ double red[4];
@@ -827,6 +881,16 @@ hipError_t launch_bce(const float* x, const float* t, int64_t n, float* dx, floa
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(bce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, t, n, 1.0f / (float)n, dx, scratch);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, scratch, blocks, 1.0 / (double)n, loss);
+    return hipGetLastError();
+}
+
+hipError_t launch_cross_entropy(const float* x, const int64_t* target, int M, int N, int64_t ignore, float* dx, float* loss, double* scratch, hipStream_t s) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const int blocks = (M + 3) / 4 < 1024 ? (M + 3) / 4 : 1024;
+    float* count = reinterpret_cast<float*>(scratch + 1024);              // scratch: 1024 partial doubles, then the row count
+    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, target, M, ignore, count);
+    hipLaunchKernelGGL(ce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, target, M, N, ignore, count, dx, scratch);
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, s, scratch, blocks, count, loss);
     return hipGetLastError();
 }
 

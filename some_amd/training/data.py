@@ -99,6 +99,29 @@ def collater(samples: List[Dict[str, torch.Tensor]], config: dict) -> Dict[str, 
     return batch
 
 
+def quant_collater(samples: List[Dict[str, torch.Tensor]], config: dict) -> Dict[str, torch.Tensor]:
+    """QuantizedMIDIExtractionDataset.collater (training/me_quant_task.py:14-27): ``note_midi`` holds integer classes (0 - 127, 128 = rest,
+    preprocessing/me_quant_binarizer.py:16,32), padded with -1; the per-frame class ``midi_idx`` is gathered through unit2note with -1
+    in front (frames of the padding, unit2note 0) - the ignore_index of the cross-entropy loss."""
+    batch = {'size': len(samples)}
+    batch['units'] = _collate_nd([s['units'] for s in samples])
+    batch['pitch'] = _collate_nd([s['pitch'] for s in samples])
+    batch['note_midi'] = _collate_nd([s['note_midi'] for s in samples], pad_value=-1)
+    batch['note_dur'] = _collate_nd([s['note_dur'] for s in samples])
+    unit2note = _collate_nd([s['unit2note'] for s in samples])
+    batch['unit2note'] = unit2note
+    batch['midi_idx'] = torch.gather(torch.nn.functional.pad(batch['note_midi'], [1, 0], value=-1), 1, unit2note)
+    batch['bounds'] = (torch.diff(unit2note, dim=1, prepend=unit2note.new_zeros((len(samples), 1))) > 0).float()
+    return batch
+
+
+def quantize_item(item: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """A continuous item -> the quantised binarizer's fields (preprocessing/me_quant_binarizer.py:25-32): round_midi, rests -> class 128."""
+    midi = torch.round(item['note_midi'].float()).long()
+    midi[item['note_rest'].bool()] = 128
+    return {k: v for k, v in {**item, 'note_midi': midi}.items() if k != 'note_rest'}
+
+
 class MIDIExtractionDataset:
     """training/base_task.py:31-76 + training/me_task.py:13-52.  ``sizes`` are the frame counts the binarizer saved
     (preprocessing/base_binarizer.py:196-199); the samplers read ``_sizes`` / ``num_frames``.  Items are moved to
@@ -133,14 +156,31 @@ class MIDIExtractionDataset:
         return collater(samples, self.config)
 
 
-class SyntheticNoteDataset(MIDIExtractionDataset):
-    """The same interface over synthetic sung clips (``synth_note_clip``) held in device memory."""
+class QuantizedMIDIExtractionDataset(MIDIExtractionDataset):
+    """training/me_quant_task.py:13-27 over the quantised binarizer's items."""
+    quantized = True
 
-    def __init__(self, config: dict, engine, indices, seconds, allow_aug: bool = False):
+    def collater(self, samples: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
+        if self.device is not None:
+            samples = [{k: v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v for k, v in s.items()} for s in samples]
+        return quant_collater(samples, self.config)
+
+
+class SyntheticNoteDataset(MIDIExtractionDataset):
+    """The same interface over synthetic sung clips (``synth_note_clip``) held in device memory.  ``quantized``: items and batches of
+    QuantizedMIDIExtractionDataset (integer note classes, rest = 128)."""
+
+    def __init__(self, config: dict, engine, indices, seconds, allow_aug: bool = False, quantized: bool = False):
         self.config, self.prefix, self.allow_aug, self.device = config, 'synthetic', allow_aug, None
+        self.quantized = quantized
         timestep = config['hop_size'] / config['audio_sample_rate']
         self.items = [make_sample(engine, synth_note_clip(i, sec), timestep) for i, sec in zip(indices, seconds)]
+        if quantized:
+            self.items = [quantize_item(it) for it in self.items]
         self.sizes = np.asarray([int(s['units'].shape[0]) for s in self.items], dtype=np.int64)
 
     def __getitem__(self, index):
         return self.items[index]
+
+    def collater(self, samples):
+        return quant_collater(samples, self.config) if self.quantized else collater(samples, self.config)

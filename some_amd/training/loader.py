@@ -67,7 +67,8 @@ class PrefetchLoader:
         self.dataset, self.config, self.device = dataset, config, torch.device(device) if device is not None else None
         self.workers = max(0, int(workers))
         self.depth = max(1, self.workers) * max(1, int(prefetch_factor))
-        self.on_device = isinstance(dataset, data.SyntheticNoteDataset) or self.device is None       # items are device tensors already
+        # (quantised datasets - other item fields, no gaussian targets to build - are collated by the dataset itself, which moves the items)
+        self.on_device = isinstance(dataset, data.SyntheticNoteDataset) or self.device is None or getattr(dataset, 'quantized', False)
         self.cuda = not self.on_device and self.device.type == 'cuda'        # (a CPU device runs the same pipeline without pinning / streams: tests)
         # worker threads pin memory (torch.full(..., pin_memory=True)): a new host thread defaults to device 0, so under one process per GPU
         # every rank's workers would create a context on GPU 0 and pin there - bind them to this rank's device first (what torch's

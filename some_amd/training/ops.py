@@ -568,6 +568,10 @@ class TrainOps:
     def bce_with_logits(self, logits, target):
         return self._apply(_Bce, logits, target)
 
+    def cross_entropy(self, logits, target, ignore_index: int = -1):
+        """nn.CrossEntropyLoss(ignore_index) of logits [M, N] against int64 classes [M] (training/me_quant_task.py:42,77)."""
+        return self._apply(_Ce, logits, target, ignore_index)
+
     def binary_emd(self, pred, gt, B: int, T: int):
         return self._apply(_Emd, pred, gt, B, T)
 
@@ -1301,6 +1305,24 @@ class _Bce(torch.autograd.Function):
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
         return None, dl * g, None
+
+
+class _Ce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, logits, target, ignore_index):
+        logits, target = logits.contiguous(), target.contiguous().long()
+        M, N = logits.shape
+        assert target.numel() == M
+        dl, loss = torch.empty_like(logits), ops.new(1)
+        sc = ops.scratch(1, 1)
+        ops.check(ops.lib.some_train_cross_entropy(ops.h, _p(logits), _p(target), M, N, int(ignore_index), _p(dl), _p(loss), _p(sc), sc.numel(), ops.stream()))
+        ctx.save_for_backward(dl)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return None, dl * g, None, None
 
 
 class _Emd(torch.autograd.Function):

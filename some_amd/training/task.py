@@ -319,3 +319,54 @@ class MIDIExtractionTrainer:
         out['midi_acc_correct'], out['midi_acc_total'] = overall.sum(), masks.sum()
         out['notes'] = dec['n_notes']
         return out
+
+
+class QuantizedMIDIExtractionTrainer(MIDIExtractionTrainer):
+    """``QuantizedMIDIExtractionTask`` (training/me_quant_task.py:30-78; configs/quant_two_head_model.yaml): the same model with 129 output
+    classes (128 = rest), raw logits out of the midi head in training (``softmax=infer``, me_quant_task.py:61), nn.CrossEntropyLoss with
+    ignore_index -1 over the frames (me_quant_task.py:42,77) instead of the blurred-target BCE; the bound stream and everything around
+    the step (AdamW, WarmupLR, clipping, data parallelism) are the base trainer's."""
+
+    def run_model(self, sample: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        units = sample['units']
+        B, T = units.shape[0], units.shape[1]
+        batch = ClipBatch([T] * B, self.ops.device)
+        mask = sample['unit2note'] > 0
+        logits, bounds = self.model(units.reshape(B * T, -1), batch, mask=mask)
+        losses = {}
+        if self.config.get('use_bound_loss', True):
+            losses['bound_loss'] = self.ops.binary_emd(bounds, sample['bounds'].reshape(-1).float(), B, T)
+        if self.config.get('use_midi_loss', True):
+            losses['midi_loss'] = self.ops.cross_entropy(logits, sample['midi_idx'].reshape(-1), ignore_index=-1)
+        return losses
+
+    @torch.no_grad()
+    def validation_step(self, sample: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """_validation_step (me_quant_task.py:81-130): eval-mode losses, then argmax classes -> rest = class 128 -> frame-level
+        MIDIAccuracy counts against the per-frame ground truth (tolerance 0.5)."""
+        from .. import _lib
+        units = sample['units']
+        B, T = units.shape[0], units.shape[1]
+        batch = ClipBatch([T] * B, self.ops.device)
+        masks = sample['unit2note'] > 0
+        logits, bounds = self.engine.forward(units.reshape(B * T, -1).contiguous(), batch, mask=masks, head_mode=_lib.HEAD_LOGITS)
+        out: Dict[str, torch.Tensor] = {}
+        if self.config.get('use_bound_loss', True):
+            out['bound_loss'] = self.ops.binary_emd(bounds, sample['bounds'].reshape(-1).float(), B, T)
+        if self.config.get('use_midi_loss', True):
+            out['midi_loss'] = self.ops.cross_entropy(logits, sample['midi_idx'].reshape(-1), ignore_index=-1)
+        cls = logits.reshape(B, T, -1).argmax(dim=-1)
+        rest_pred = cls == 128
+        midi_pred = cls.float()
+        midi_pred[rest_pred] = -torch.inf
+        note_midi_gt = sample['note_midi'].float().clone()
+        note_midi_gt[sample['note_midi'] == 128] = -torch.inf
+        midi_gt = torch.gather(torch.nn.functional.pad(note_midi_gt, [1, 0], value=-torch.inf), 1, sample['unit2note'])
+        rest_gt = midi_gt < 0
+        close = ~rest_pred & ~rest_gt & (torch.abs(midi_pred - midi_gt) <= 0.5)
+        overall = close & (rest_pred == rest_gt) & masks                  # modules/metrics/midi_acc.py:28-32 (a rest frame is never 'close')
+        out['midi_acc_correct'], out['midi_acc_total'] = overall.sum(), masks.sum()
+        return out
+
+
+TRAINERS = {'training.MIDIExtractionTask': MIDIExtractionTrainer, 'training.QuantizedMIDIExtractionTask': QuantizedMIDIExtractionTrainer}

@@ -607,3 +607,90 @@ def test_update_without_host_sync_equals_the_synchronous_one(precision):
     with pytest.raises(FloatingPointError, match='non-finite gradient'):
         tr.flush()
     assert torch.equal(tr.model.params.flat, before)
+
+
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+def test_quantized_task_step_matches_reference(golden_dir, precision):
+    """QuantizedMIDIExtractionTask (training/me_quant_task.py:30-78): one step of the reference model with 129 classes + nn.CrossEntropyLoss(
+    ignore_index=-1) + BinaryEMDLoss + AdamW (tests/golden/train_step_quant.npz, oracle/make_golden.py:gen_train_quant) against
+    QuantizedMIDIExtractionTrainer: losses 2e-5, every gradient tensor 2e-4 (relative L2, count sketch), parameters after the update."""
+    from some_amd.training import data
+    from some_amd.training.task import TRAINERS
+    g = np.load(golden_dir / 'train_step_quant.npz')
+    cfg = get_config('quant_two_head_model', lay=1)
+    for k in ('conv_drop', 'ffn_latent_drop', 'ffn_out_drop', 'attention_drop'):
+        cfg['midi_extractor_args'][k] = 0.0
+    tr = TRAINERS[cfg['task_cls']](dict(cfg, some_amd_precision=precision), device='cuda')
+    tr.model.params.load_state_dict(synth.synth_state_dict(cfg, int(g['weights_seed'])))
+    items = []
+    while f'item{len(items)}.units' in g.files:
+        i = len(items)
+        items.append({k: torch.from_numpy(g[f'item{i}.{k}']).cuda() for k in ('units', 'pitch', 'note_midi', 'note_dur', 'unit2note')})
+    out = tr.training_step(data.quant_collater(items, cfg))
+    assert not out['skipped'] and out['lr'] == pytest.approx(1e-4 / 10000)
+    assert abs(out['bound_loss'].item() - float(g['bound_loss'])) < 2e-5 * abs(float(g['bound_loss']))
+    assert abs(out['midi_loss'].item() - float(g['midi_loss'])) < 2e-5 * abs(float(g['midi_loss']))
+    assert out['grad_norm'] == pytest.approx(float(g['grad_norm']), rel=2e-5)
+    P = tr.model.params
+    worst = 0.0
+    for name in g['names']:
+        key = str(name)
+        norm = g['grad.' + key][10]
+        mine = P.views[key].grad.detach().double().cpu().numpy().reshape(-1) / out['grad_scale']
+        if norm < 1e-6:
+            assert np.sqrt((mine * mine).sum()) < 1e-5, key
+            continue
+        err = np.linalg.norm(_sketch(key, mine) - g['sk.' + key]) / norm
+        worst = max(worst, err)
+        assert err < 2e-4, (key, err)
+        v = P.views[key].detach().double().cpu().numpy().reshape(-1)
+        ref = g['after.' + key]
+        np.testing.assert_allclose(v[:min(8, v.size)], ref[:min(8, v.size)], rtol=0, atol=2e-9 + 1e-6 * np.abs(ref[:8]).max())
+    print(f'quantised task, {precision}: worst gradient tensor error (relative L2):', worst)
+
+
+def test_cross_entropy_kernel_matches_torch():
+    """some_train_cross_entropy against torch.nn.functional.cross_entropy(ignore_index=-1): loss and gradient, ragged validity, one
+    extreme row (no overflow: the row maximum is subtracted), and the all-ignored case (NaN, as torch)."""
+    from some_amd.engine import Engine
+    from some_amd.training.ops import TrainOps
+    ops = TrainOps(Engine(get_config('quant_two_head_model', lay=1), device='cuda'))
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    x = (torch.randn(301, 129, device='cuda', generator=gen) * 4).requires_grad_()
+    with torch.no_grad():
+        x[7] *= 40.0
+    t = torch.randint(0, 129, (301,), device='cuda', generator=gen)
+    t[::5] = -1
+    loss = ops.cross_entropy(x, t, ignore_index=-1)
+    (loss * 3.0).backward()
+    xr = x.detach().double().requires_grad_()
+    want = torch.nn.functional.cross_entropy(xr, t, ignore_index=-1)
+    (want * 3.0).backward()
+    assert abs(loss.item() - want.item()) < 1e-6 * abs(want.item())
+    assert float((x.grad.double() - xr.grad).abs().max()) < 1e-6 * float(xr.grad.abs().max())
+    assert float(x.grad[::5].abs().max()) == 0.0
+    none = ops.cross_entropy(x.detach(), torch.full_like(t, -1), ignore_index=-1)
+    assert torch.isnan(none)
+
+
+def test_cli_train_quantized_task_then_infer(tmp_path):
+    """train.py on configs/quant_two_head_model.yaml's task (synthetic clips with integer note classes) and the checkpoint through
+    QuantizedMIDIExtractionInference (inference/me_quant_infer.py)."""
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / 'train.py'), '--config', 'quant_two_head_model', '--exp_name', 'q', '--work_dir', str(tmp_path),
+                        '--synthetic', '12', '--max_updates', '8', '--log_interval', '2'], capture_output=True, text=True, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'step 8:' in r.stdout and 'midi_loss=' in r.stdout and 'validation @ 8' in r.stdout
+    ckpt = tmp_path / 'q' / 'model_ckpt_steps_8.ckpt'
+    assert ckpt.exists()
+    sys.path.insert(0, str(root))
+    from infer import load_inference
+    ins, cfg = load_inference(ckpt)
+    assert type(ins).__name__ == 'QuantizedMIDIExtractionInference'
+    from some_amd.training import data
+    wave, _, _, _ = data.synth_note_clip(99, 6.0)
+    res = ins.infer([wave])[0]
+    assert set(res) == {'note_midi', 'note_dur', 'note_rest'} and len(res['note_midi']) >= 1

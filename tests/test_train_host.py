@@ -428,3 +428,30 @@ def test_ffn_dropout_generator_statistics():
         assert abs(a.mean(1) - q).max() < 6 * (q * (1 - q) / N) ** 0.5
     assert ffn_keep_mask(1, 64, 64, 0.0).all()
     assert key_words(1) != key_words(2)
+
+
+def test_quant_collater_equals_the_reference_collater(golden_dir):
+    """some_amd.training.data.quant_collater against the batch the REFERENCE's own collater text produced from the same items
+    (tests/golden/train_step_quant.npz, oracle/make_golden.py:_ref_quant_collater; training/me_quant_task.py:14-27): padding values,
+    midi_idx (-1 on padding frames and behind padded notes), boundaries - exactly."""
+    import numpy as np
+    import torch
+    from some_amd.configs import get_config
+    from some_amd.training import data
+    g = np.load(golden_dir / 'train_step_quant.npz')
+    items = []
+    i = 0
+    while f'item{i}.units' in g.files:
+        items.append({k: torch.from_numpy(g[f'item{i}.{k}']) for k in ('units', 'pitch', 'note_midi', 'note_dur', 'unit2note')})
+        i += 1
+    assert len(items) == 2
+    batch = data.quant_collater(items, get_config('quant_two_head_model', lay=1))
+    assert batch['size'] == 2
+    for k in ('units', 'note_midi', 'note_dur', 'unit2note', 'midi_idx', 'bounds'):
+        want = g['batch.' + k]
+        assert batch[k].dtype == torch.from_numpy(want).dtype and np.array_equal(batch[k].numpy(), want), k
+    assert (batch['midi_idx'][1, -26:] == -1).all() and (batch['midi_idx'] == 128).any()       # padding frames ignored, a rest class present
+    # a continuous item -> quantised fields (me_quant_binarizer.py:25-32)
+    q = data.quantize_item({'units': torch.zeros(4, 80), 'pitch': torch.zeros(4), 'note_midi': torch.tensor([60.4, 61.5, 62.5]),
+                            'note_rest': torch.tensor([False, True, False]), 'note_dur': torch.tensor([1, 1, 2]), 'unit2note': torch.tensor([1, 2, 3, 3])})
+    assert q['note_midi'].tolist() == [60, 128, 62] and 'note_rest' not in q                   # torch.round: half to even

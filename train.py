@@ -56,11 +56,11 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
     from some_amd.training.loader import PrefetchLoader
     from some_amd.training.run_log import CheckpointKeeper, ScalarLog
     from some_amd.training.samplers import DsBatchSampler, DsEvalBatchSampler
-    from some_amd.training.task import MIDIExtractionTrainer
+    from some_amd.training.task import TRAINERS
     cfg = _load_config(config)
-    if cfg['task_cls'] != 'training.MIDIExtractionTask':
-        # training/me_quant_task.py (129-way cross-entropy head) has no HIP training step here; its INFERENCE class is built
-        raise click.UsageError(f"task_cls {cfg['task_cls']!r}: only training.MIDIExtractionTask can be trained by this command")
+    if cfg['task_cls'] not in TRAINERS:           # training/__init__.py of the reference: MIDIExtractionTask, QuantizedMIDIExtractionTask
+        raise click.UsageError(f"task_cls {cfg['task_cls']!r}: this command trains {sorted(TRAINERS)}")
+    quantized = cfg['task_cls'] == 'training.QuantizedMIDIExtractionTask'
     work = (pathlib.Path(work_dir) if work_dir else pathlib.Path(__file__).parent / 'experiments') / exp_name
     assert not work.exists() or work.is_dir(), f'Path \'{work}\' is not a directory.'
     world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
@@ -73,19 +73,20 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
         work.mkdir(parents=True, exist_ok=True)
         with open(work / 'config.yaml', 'w', encoding='utf8') as f:
             yaml.safe_dump(cfg, f)
-    trainer = MIDIExtractionTrainer(cfg, device=f'cuda:{local}', seed=cfg.get('seed', 114514))
+    trainer = TRAINERS[cfg['task_cls']](cfg, device=f'cuda:{local}', seed=cfg.get('seed', 114514))
     if synthetic > 0:
         rng_len = torch.Generator().manual_seed(1)
         seconds = [4.0 + 8.0 * torch.rand((), generator=rng_len).item() for _ in range(synthetic)]
-        train_set = data.SyntheticNoteDataset(cfg, trainer.engine, range(synthetic), seconds, allow_aug=True)
-        valid_set = data.SyntheticNoteDataset(cfg, trainer.engine, range(10 ** 6, 10 ** 6 + val_clips), [6.0] * val_clips) if val_clips else None
+        train_set = data.SyntheticNoteDataset(cfg, trainer.engine, range(synthetic), seconds, allow_aug=True, quantized=quantized)
+        valid_set = data.SyntheticNoteDataset(cfg, trainer.engine, range(10 ** 6, 10 ** 6 + val_clips), [6.0] * val_clips, quantized=quantized) if val_clips else None
         max_val_batch_size = max(val_clips, 1)
     else:
         if not cfg.get('binary_data_dir'):
             raise click.UsageError('the config has no binary_data_dir: set it, or pass --synthetic N')
         # training/base_task.py:135-142
-        train_set = data.MIDIExtractionDataset(cfg, cfg['binary_data_dir'], cfg['train_set_name'], allow_aug=True, device=trainer.ops.device)
-        valid_set = data.MIDIExtractionDataset(cfg, cfg['binary_data_dir'], cfg['valid_set_name'], device=trainer.ops.device)
+        ds_cls = data.QuantizedMIDIExtractionDataset if quantized else data.MIDIExtractionDataset           # task.dataset_cls
+        train_set = ds_cls(cfg, cfg['binary_data_dir'], cfg['train_set_name'], allow_aug=True, device=trainer.ops.device)
+        valid_set = ds_cls(cfg, cfg['binary_data_dir'], cfg['valid_set_name'], device=trainer.ops.device)
         max_val_batch_size = cfg['max_val_batch_size']
     accumulate = int(cfg.get('accumulate_grad_batches', 1))
     # training/base_task.py:360-395
