@@ -20,6 +20,9 @@
 
 namespace {
 
+#ifndef SOME_GEMM_FLIP
+#define SOME_GEMM_FLIP 0      // sign flip of the accumulation's last 3/8 (see hgemm3_kernel); 0: the round-1..4 arithmetic
+#endif
 constexpr int LDT = 36;      // LDS row in dwords: 16 (32 hi halves) + 16 (32 lo halves) + 4 pad
 
 // 1 / (1 + e^-x) with the hardware reciprocal (v_rcp_f32, 1 ulp): the IEEE divide costs ~10 VALU per element
@@ -468,6 +471,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
         return *reinterpret_cast<const half8*>(base + tile * 32 * LDT + lo * 16 + s * 8);
     };
     // mode 0: steady state (store k-block kt + 1, load kt + 2); 1: second-to-last block (store only); 2: last block (neither)
+    // neg: the A fragments enter with their sign flipped (second phase of the accumulation, see the k-loop below)
+    // sgn: 0, or 0x80008000 = the A fragments enter with their sign flipped (second phase of the accumulation, see the k-loop below);
+    // always applied (a scalar operand: one v_xor per fragment dword, 32 per k-block beside 48 MFMAs) so that the loop stays one body
+    uint32_t sgn = 0;
+    auto flip = [&](half8 v) {
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        const u32x4_ m = {sgn, sgn, sgn, sgn};
+        return __builtin_bit_cast(half8, __builtin_bit_cast(u32x4_, v) ^ m);
+    };
+    constexpr bool kFlip = TERMS == 3 && SOME_GEMM_FLIP;
     auto compute_staged = [&](int buf, int kt_load, int mode) {
         const float* As = lds + buf * STAGE + a_off;
         const float* Ws = lds + buf * STAGE + w_off;
@@ -482,6 +495,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
         for (int i = 0; i < TM; ++i) ah[i] = frag(As, i, 0, 0);
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) bl[jn] = frag(Ws, jn, 0, 1);
+        if constexpr (kFlip) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { al[i] = flip(al[i]); ah[i] = flip(ah[i]); }
+        }
         __builtin_amdgcn_sched_barrier(0);
         constexpr int SLOTS = 2 * TM * TN;                       // products 1 and 2 of the first slab carry the staging
         constexpr int OPS = (NLD + SLOTS - 1) / SLOTS;
@@ -521,6 +538,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
         for (int i = 0; i < TM; ++i) al1[i] = frag(As, i, 1, 1);
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) bh1[jn] = frag(Ws, jn, 1, 0);
+        if constexpr (kFlip) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) al1[i] = flip(al1[i]);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -531,6 +552,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
         for (int i = 0; i < TM; ++i) ah1[i] = frag(As, i, 1, 0);
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) bl1[jn] = frag(Ws, jn, 1, 1);
+        if constexpr (kFlip) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ah1[i] = flip(ah1[i]);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -549,29 +574,52 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 #ifdef GEMM_ABLATE_NO_LOOP
     nk = 1;                                              // one k-block: the epilogue alone (plus the prologue loads)
 #endif
-    for (; kt + 2 < nk; ++kt) {
-        if constexpr (TERMS == 3) {
+    // Sign flip of the accumulation (round 5, profiles/r05_experiments.md "the f16 matrix pipe rounds toward minus infinity"): the fp32
+    // accumulate of v_mfma_f32_32x32x16_f16 truncates toward -inf (a fraction of an ulp per instruction, but ALWAYS downward: a GEMM
+    // result carries a bias of -0.03 .. -0.05 of its rms error where the f32 MFMA carries 0.000), and over the network those biases
+    // add up to +1e-7 on every bound probability - 2.5e-4 on the fp64 cumsum the note boundaries are rounded from, 16 of 50 724
+    // boundaries moved at 32 x 30 s.  Accumulating the LAST part of the contraction NEGATED turns its truncation the other way:
+    //   k-blocks [0, kflip): acc = S1 - b1;   acc = -acc;   k-blocks [kflip, nk) with -A: acc = -S1 - S2 + b1 - b2;   result = -acc
+    // |partial sums| grow like sqrt(k), so the two biases balance at kflip ~ 0.63 nk.  Cost: 2 x 128 v_xor per workgroup tile and two
+    // v_xor per A fragment in the second phase; same products, same order - only the rounding direction of the later sums changes.
+    const int kflip = (kFlip && nk >= 8) ? (nk * 5 + 4) / 8 : nk;          // 0.625 nk (K = 512: 10 of 16; K = 2048: 40 of 64)
+    auto negate_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jn][r] = -acc[i][jn][r];
+    };
+    if constexpr (TERMS == 3) {
+        for (; kt + 2 < nk; ++kt) {
+            if (kFlip && kt == kflip) { negate_acc(); sgn = 0x80008000u; }      // once per tile (kflip <= nk - 3 whenever nk >= 8)
             compute_staged(kt & 1, kt + 2, 0);
-        } else {
+            __syncthreads();
+        }
+        if (kt + 1 < nk) {
+            compute_staged(kt & 1, 0, 1);
+            __syncthreads();
+            ++kt;
+        }
+        compute_staged(kt & 1, 0, 2);
+        if (kFlip && sgn != 0) negate_acc();
+    } else {
+        for (; kt + 2 < nk; ++kt) {
             lstore((kt & 1) ^ 1);
             gload(kt + 2);
             __builtin_amdgcn_sched_barrier(0);
             compute(kt & 1);
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    if (kt + 1 < nk) {
-        if constexpr (TERMS == 3) {
-            compute_staged(kt & 1, 0, 1);
-        } else {
+        if (kt + 1 < nk) {
             lstore((kt & 1) ^ 1);
             compute(kt & 1);
+            __syncthreads();
+            ++kt;
         }
-        __syncthreads();
-        ++kt;
+        compute(kt & 1);
     }
-    if constexpr (TERMS == 3) compute_staged(kt & 1, 0, 2);
-    else compute(kt & 1);
 
     // ---- epilogue (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
     // Interior workgroups take the unguarded path (no per-element exec masking).  Residual values are fetched one
