@@ -225,12 +225,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a, int nqb) 
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.max_frames <= 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.mark();
     }
     const int nqb = (a.max_frames + QB - 1) / QB;
     const int units = a.B * kHeads * a.groups;

@@ -899,10 +899,10 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
 
 hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
     if (a.B <= 0 || a.max_frames <= 0) return hipSuccess;
-    static bool attr_set = false;
+    static DeviceOnce attr_once;
     static const bool placed = !(getenv("SOME_AMD_ATTN_V1") && getenv("SOME_AMD_ATTN_V1")[0] == '1');       // A/B switch: the round-1..4 kernel
     static const bool dma = !(getenv("SOME_AMD_ATTN_DMA") && getenv("SOME_AMD_ATTN_DMA")[0] == '0');        // A/B switch: register-staged rings
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -916,7 +916,7 @@ hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.mark();
     }
     const bool inference = a.out32[0] == nullptr;
     if (inference && a.pad_offsets == nullptr) return hipErrorInvalidValue;

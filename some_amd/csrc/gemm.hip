@@ -209,12 +209,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
 
 template <int EPI>
 hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.mark();
     }
     int n_max = 0;
     for (int g = 0; g < a.groups; ++g) n_max = a.g[g].N > n_max ? a.g[g].N : n_max;

@@ -783,12 +783,12 @@ template <int EPI, bool OUT_SPLIT>
 hipError_t launch_ring(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 128, BN = 256;
     constexpr size_t LDS_BYTES = 3 * (size_t)(BM + BN) * 64;
-    static bool attr_set = false;
+    static DeviceOnce attr_once;
     auto kern = &hgemm3_ring_kernel<EPI, OUT_SPLIT>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.mark();
     }
     int n_max = 0;
     for (int g = 0; g < a.groups; ++g) n_max = a.g[g].N > n_max ? a.g[g].N : n_max;
@@ -804,12 +804,12 @@ template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int
 hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LDT * sizeof(float);
-    static bool attr_set = false;
+    static DeviceOnce attr_once;
     auto kern = &hgemm3_kernel<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, TERMS, TR, BF16>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.mark();
     }
     int n_max = 0;
     for (int g = 0; g < a.groups; ++g) n_max = a.g[g].N > n_max ? a.g[g].N : n_max;
@@ -1137,12 +1137,12 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args a) {
 template <bool TA, bool TB, int MODE, bool S16 = false>
 hipError_t launch_gemm16_cfg(const Gemm16Args& a_in, hipStream_t s) {
     using Cfg = Gemm16Cfg<MODE>;
-    static bool attr_set = false;
+    static DeviceOnce attr_once;
     auto kern = &gemm16_kernel<TA, TB, MODE, S16>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.mark();
     }
     Gemm16Args a = a_in;
     a.m_tiles = (a.M + Cfg::BM - 1) / Cfg::BM;

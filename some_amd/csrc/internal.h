@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libsome_amd.so (not part of the C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <mutex>
 #include <string>
@@ -10,6 +11,16 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// hipFuncSetAttribute is PER DEVICE: a process-wide `static bool` latch is wrong the day one process drives two GPUs (a server with two
+// handles) and racy between threads.  One bit per device, set after the attributes are in place; two threads that race both set the
+// (idempotent) attributes.
+struct DeviceOnce {
+    std::atomic<uint64_t> done{0};
+    static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+    bool need() const { return !((done.load(std::memory_order_acquire) >> dev()) & 1ull); }
+    void mark() { done.fetch_or(1ull << dev(), std::memory_order_release); }
+};
 
 // Compiled shapes (validated in some_create): the reference's configs all use them
 // (configs/midi_conformer.yaml:22-33, configs/base.yaml:11-15).

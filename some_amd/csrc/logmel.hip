@@ -185,11 +185,11 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelTables t, const float
 hipError_t launch_logmel(const LogmelTables& t, const float* audio, const int64_t* sample_offsets,
                          const int32_t* frame_offsets, int B, int max_frames, int pad_reflect, float* units, hipStream_t s) {
     if (B <= 0 || max_frames <= 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.mark();
     }
     dim3 grid((unsigned)((max_frames + kFramesPerWg - 1) / kFramesPerWg), (unsigned)B);
     hipLaunchKernelGGL(logmel_kernel, grid, dim3(256), kLdsBytes, s, t, audio, sample_offsets, frame_offsets, units, t.kmax, pad_reflect);

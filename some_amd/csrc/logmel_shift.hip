@@ -83,12 +83,12 @@ hipError_t launch_logmel_shift(const LogmelTables& t, const float* window, const
     if (B <= 0 || max_frames <= 0) return hipSuccess;
     if (N < 2 || N > kMaxShiftFft) return hipErrorInvalidValue;
     const size_t lds = logmel_shift_lds_bytes(N, t.kmax);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_shift_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)logmel_shift_lds_bytes(kMaxShiftFft, 1024));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.mark();
     }
     const int nbins = (t.kmax < N / 2 ? t.kmax : N / 2) + 1;
     hipLaunchKernelGGL(logmel_shift_kernel, dim3((unsigned)max_frames, (unsigned)B), dim3(256), lds, s, t, window,

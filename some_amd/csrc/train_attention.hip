@@ -338,14 +338,14 @@ hipError_t launch_attention_dsum(const float* out, const float* dout, float* dsu
 
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.max_frames <= 0 || a.M <= 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)DQ_LDS_BYTES);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKV_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.mark();
     }
     hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, s, a.out, a.dout, a.dsum, a.M);
     const int units = a.B * kHeads, slots = (units + 7) / 8;

@@ -416,13 +416,13 @@ __global__ __launch_bounds__(256, 2) void attn3_bwd_dq_kernel(Bwd3Args a, int nq
 
 template <int TERMS>
 static hipError_t launch_bwd(const Bwd3Args& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_bwd_dkv_kernel<TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKV_LDS);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_bwd_dq_kernel<TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DQ_LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.mark();
     }
     const int units = a.B * kHeads, slots = (units + 7) / 8;
     const int nb = (a.max_frames + 127) / 128;

@@ -331,12 +331,12 @@ template <int EPI, bool BF16, int WM = 2, int TN = 4, int NSTAGE = 3, int MINB =
 hipError_t launch16s(const G16sArgs& a_in, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * TN;
     constexpr size_t LDS_BYTES = NSTAGE * (size_t)(BM + BN) * 64;
-    static bool attr_set = false;
+    static DeviceOnce attr_once;
     auto kern = &gemm16s_kernel<EPI, BF16, WM, TN, NSTAGE, MINB>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_once.mark();
     }
     G16sArgs a = a_in;
     const int m_tiles = (a.M + BM - 1) / BM;

@@ -90,6 +90,34 @@ def test_midi_file_messages_and_bytes(golden_dir):
         assert raw[22:29] == bytes([0x00, 0xFF, 0x51, 0x03]) + int(round(60e6 / c['tempo'])).to_bytes(3, 'big')
 
 
+def test_smf_whole_file_known_answer():
+    """A two-note file assembled BY HAND from the SMF 1.0 specification (header chunk, track chunk length, variable-length deltas,
+    status bytes, set_tempo and end_of_track meta events) - every byte of what ``build_midi_file(...).to_bytes()`` writes, not only the
+    header and the tail: note 60 for 0.5 s, a 0.25 s rest (emits nothing, shows up as the next delta), note 64 for 1.0 s at tempo 120
+    (480 ticks per beat -> 960 ticks per second).  mido's exact bytes are unpinned by the reference; this pins the format itself."""
+    from some_amd.utils import smf
+    from some_amd.utils.infer_utils import build_midi_file
+    seg = {'note_midi': np.array([60.2, 0.0, 63.7], np.float32), 'note_dur': np.array([0.5, 0.25, 1.0], np.float64), 'note_rest': np.array([False, True, False])}
+    want = bytes([
+        0x4D, 0x54, 0x68, 0x64, 0, 0, 0, 6, 0, 1, 0, 1, 0x01, 0xE0,        # MThd, length 6, format 1, one track, 480 ticks per quarter
+        0x4D, 0x54, 0x72, 0x6B, 0, 0, 0, 30,                              # MTrk, 30 bytes follow
+        0x00, 0xFF, 0x51, 0x03, 0x07, 0xA1, 0x20,                         # delta 0, set_tempo 500 000 us per quarter (120 bpm)
+        0x00, 0x90, 0x3C, 0x40,                                           # delta 0, note_on ch 0, note 60 (round(60.2)), velocity 64
+        0x83, 0x60, 0x80, 0x3C, 0x40,                                     # delta 480 (VLQ 83 60), note_off 60
+        0x81, 0x70, 0x90, 0x40, 0x40,                                     # delta 240 (the rest), note_on 64 (round(63.7))
+        0x87, 0x40, 0x80, 0x40, 0x40,                                     # delta 960 (VLQ 87 40), note_off 64
+        0x00, 0xFF, 0x2F, 0x00])                                          # delta 0, end_of_track
+    assert build_midi_file([0.0], [seg], tempo=120).to_bytes() == want
+    # running status: consecutive channel messages with the same status byte drop it (what mido's writer does); a meta event resets it
+    tr = smf.MidiTrack([smf.Message('note_on', note=60, time=0), smf.Message('note_on', note=64, time=0), smf.MetaMessage('set_tempo', tempo=500000, time=0),
+                        smf.Message('note_on', note=67, time=1), smf.Message('note_off', note=60, time=0x4000)])
+    mf = smf.MidiFile()
+    mf.tracks.append(tr)
+    body = mf.to_bytes()[22:]
+    assert body == bytes([0x00, 0x90, 0x3C, 0x40, 0x00, 0x40, 0x40, 0x00, 0xFF, 0x51, 0x03, 0x07, 0xA1, 0x20, 0x01, 0x90, 0x43, 0x40,
+                          0x81, 0x80, 0x00, 0x80, 0x3C, 0x40, 0x00, 0xFF, 0x2F, 0x00])
+
+
 def test_smf_variable_length_quantity():
     from some_amd.utils.smf import _vlq
     assert _vlq(0) == [0] and _vlq(0x7F) == [0x7F] and _vlq(0x80) == [0x81, 0x00]
