@@ -43,11 +43,12 @@ def _offline_evidence(kernel_name: str) -> dict:
     FETCH_SIZE x 2 (the gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE; MFMA-busy
     at the power-limited clock the kernel actually ran at."""
     prof = ROOT / 'profiles'
-    key = {'attention': 'attention3_kernel'}.get(kernel_name)
+    key = {'attention': 'attention3'}.get(kernel_name)            # attention3i_kernel<DMA> (round 5) / attention3_kernel<...>
     out = {}
     if key is None:
         return out
-    for hbm_file, busy_file in (('r04n_pmc_hbm_traffic.json', 'r04n_pmc_mfma_busy.json'),        # newest committed passes first
+    for hbm_file, busy_file in (('r05z_pmc_hbm_traffic.json', 'r05z_pmc_mfma_busy.json'),        # newest committed passes first
+                                ('r04n_pmc_hbm_traffic.json', 'r04n_pmc_mfma_busy.json'),
                                 ('r03f_pmc_hbm_traffic.json', 'r03f_pmc_mfma_busy.json'),
                                 ('r02f_pmc_hbm_traffic.json', 'r02f_pmc_mfma_busy.json'),
                                 ('r02_pmc_hbm_traffic.json', 'r02_pmc_mfma_busy.json'),
@@ -85,7 +86,7 @@ def _live_pmc(kernel_name: str, config_args) -> dict:
     import shutil
     import subprocess
     import tempfile
-    key = {'attention': 'attention3_kernel'}.get(kernel_name)
+    key = {'attention': 'attention3'}.get(kernel_name)            # attention3i_kernel<DMA> (round 5) / attention3_kernel<...>
     exe = shutil.which('rocprofv3')
     if key is None or exe is None or os.environ.get('SOME_AMD_BENCH_CHILD'):
         return {}
