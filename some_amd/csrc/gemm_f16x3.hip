@@ -20,6 +20,9 @@
 
 namespace {
 
+#ifndef SOME_GEMM_DMA
+#define SOME_GEMM_DMA 0
+#endif
 #ifndef SOME_GEMM_FLIP
 #define SOME_GEMM_FLIP 0      // sign flip of the accumulation's last 3/8 (see hgemm3_kernel); 0: the round-1..4 arithmetic
 #endif
@@ -313,7 +316,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     static_assert(!BF16 || (TERMS == 1 && !TR), "bf16 hi halves: one-product kernels only (split.h)");
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    constexpr int STAGE = (BM + BN) * LDT;               // dwords
+    // kDma (round 5, -DSOME_GEMM_DMA=1): the k-blocks go L2 -> LDS by DMA (buffer_load_dwordx4 ... lds) instead of through registers and
+    // ds_write_b128; LDS rows are then 128 unpadded bytes with an XOR swizzle - chunk c (16 B) of row r at position c ^ ((r >> 1) & 7),
+    // conflict-free for the ds_read_b128 lane groups in both the identity and the pi32 row order - applied to the per-lane SOURCE address
+    // (the DMA destination is lane-linear: a wavefront's 64 lanes fill 8 consecutive rows) and again on the fragment reads.
+    constexpr bool kDma = TERMS == 3 && SOME_GEMM_DMA;
+    constexpr int LDW = kDma ? 32 : LDT;                 // LDS row in dwords
+    constexpr int STAGE = (BM + BN) * LDW;               // dwords
     constexpr int NLD = (BM + BN) * 8 / NT;              // 16-byte chunks per thread per k-block
     static_assert((BM + BN) * 8 % NT == 0, "staging must divide evenly");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -359,7 +368,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     static_assert(BM % RPP == 0, "a pass must not straddle A and W");
     const __amdgpu_buffer_rsrc_t rsa = make_rsrc(g.A, (size_t)a.a_rows * a.lda * 4);
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(g.W, (size_t)g.N * a.K * 4);
-    const int srow = tid >> 3, scol = tid & 7;
+    const int srow = tid >> 3;
+    const int scol = kDma ? ((tid & 7) ^ ((srow >> 1) & 7)) : (tid & 7);      // (RPP is a multiple of 16: the swizzle of row srow + p RPP is srow's)
     uint32_t voff[NLD];
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
@@ -378,6 +388,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
         }
     }
     const int dst0 = srow * LDT + scol * 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);       // DMA destinations only (the epilogues keep the lane-derived index, see above)
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto dma_piece = [&](int buf, int kt, int p) {                     // rows p RPP + 8 wave .. + 7 of k-block kt -> LDS buffer `buf`
+        float* dst = lds + buf * STAGE + (p * RPP + 8 * wave_u) * 32;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(p * RPP < BM ? rsa : rsw, (lds_ptr_t)dst, 16, voff[p], (uint32_t)(kt0 + kt) * 128u, 0, 0);
+    };
     f32x4 stage[NLD];
     auto gload = [&](int kt) {
         const uint32_t koff = (uint32_t)(kt0 + kt) * 128u;
@@ -403,13 +419,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     // registers hold k-block kt + 1 (loaded during iteration kt - 1, so its latency is already paid); they are
     // written to the other LDS buffer, immediately re-issued for k-block kt + 2, and the MFMAs of block kt run
     // while those loads fly.  One barrier per k-block; nothing waits on a just-issued load.
-    gload(0);
-    lstore(0);
-    if (nk > 1) gload(1);
+    if constexpr (kDma) {
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) dma_piece(0, 0, p);
+    } else {
+        gload(0);
+        lstore(0);
+        if (nk > 1) gload(1);
+    }
     __syncthreads();
 
-    const int a_off = (wm * TM * 32 + l31) * LDT + kg * 4;
-    const int w_off = (BM + wn * TN * 32 + (TR ? pi32(l31) : l31)) * LDT + kg * 4;
+    const int w_row = BM + wn * TN * 32 + (TR ? pi32(l31) : l31);
+    const int a_off = kDma ? (wm * TM * 32 + l31) * 32 : (wm * TM * 32 + l31) * LDT + kg * 4;
+    const int w_off = kDma ? w_row * 32 : w_row * LDT + kg * 4;
+    // kDma: dword offset of logical chunk (kg | 4 lo + 2 s) inside the lane's row, by operand (the W rows of the TR layout are permuted)
+    int xa[4], xw[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        xa[c] = ((kg | (2 * c)) ^ ((l31 >> 1) & 7)) * 4;
+        xw[c] = ((kg | (2 * c)) ^ ((w_row >> 1) & 7)) * 4;
+    }
     // TR: the W fragment is the first MFMA operand (accumulator rows <- n, lane <- m), see epilogue_tr
     // GEMM_ABLATE_* (tools/build_variant.py builds only, wrong results): what each part of the k-loop costs
     auto mma = [](half8 x, half8 w, f32x16 c) {
@@ -467,8 +496,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     //     product runs, ah / bl under the second slab's first product - into the registers the first slab has just
     //     retired (al dies after product 1, bl after product 2), so the fragment set stays at 48 VGPRs.
     // sched_barrier(0) pins that order; no condition inside the iteration, the last two k-blocks are peeled.
-    auto frag = [&](const float* base, int tile, int s, int lo) {
-        return *reinterpret_cast<const half8*>(base + tile * 32 * LDT + lo * 16 + s * 8);
+    auto frag = [&](const float* base, int tile, int s, int lo, bool is_w = false) {
+        if constexpr (kDma) return *reinterpret_cast<const half8*>(base + tile * 32 * 32 + (is_w ? xw[2 * lo + s] : xa[2 * lo + s]));
+        else return *reinterpret_cast<const half8*>(base + tile * 32 * LDT + lo * 16 + s * 8);
     };
     // mode 0: steady state (store k-block kt + 1, load kt + 2); 1: second-to-last block (store only); 2: last block (neither)
     // neg: the A fragments enter with their sign flipped (second phase of the accumulation, see the k-loop below)
@@ -490,11 +520,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 #pragma unroll
         for (int i = 0; i < TM; ++i) al[i] = frag(As, i, 0, 1);
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn) bh[jn] = frag(Ws, jn, 0, 0);
+        for (int jn = 0; jn < TN; ++jn) bh[jn] = frag(Ws, jn, 0, 0, true);
 #pragma unroll
         for (int i = 0; i < TM; ++i) ah[i] = frag(As, i, 0, 0);
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn) bl[jn] = frag(Ws, jn, 0, 1);
+        for (int jn = 0; jn < TN; ++jn) bl[jn] = frag(Ws, jn, 0, 1, true);
         if constexpr (kFlip) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) { al[i] = flip(al[i]); ah[i] = flip(ah[i]); }
@@ -506,7 +536,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 #pragma unroll
             for (int o = 0; o < OPS; ++o) {
                 const int q = slot * OPS + o;
-                if (q < NLD && mode < 2) {
+                if constexpr (kDma) {
+                    if (q < NLD && mode < 2) dma_piece(buf ^ 1, kt_load, q);          // (kt_load = the NEXT k-block in this mode)
+                } else if (q < NLD && mode < 2) {
 #ifndef GEMM_ABLATE_NO_LDSW
                     *reinterpret_cast<f32x4*>(wbase + q * RPP * LDT) = stage[q];
 #endif
@@ -537,7 +569,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 #pragma unroll
         for (int i = 0; i < TM; ++i) al1[i] = frag(As, i, 1, 1);
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn) bh1[jn] = frag(Ws, jn, 1, 0);
+        for (int jn = 0; jn < TN; ++jn) bh1[jn] = frag(Ws, jn, 1, 0, true);
         if constexpr (kFlip) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) al1[i] = flip(al1[i]);
@@ -551,7 +583,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 #pragma unroll
         for (int i = 0; i < TM; ++i) ah1[i] = frag(As, i, 1, 0);
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn) bl1[jn] = frag(Ws, jn, 1, 1);
+        for (int jn = 0; jn < TN; ++jn) bl1[jn] = frag(Ws, jn, 1, 1, true);
         if constexpr (kFlip) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) ah1[i] = flip(ah1[i]);
@@ -594,11 +626,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     if constexpr (TERMS == 3) {
         for (; kt + 2 < nk; ++kt) {
             if (kFlip && kt == kflip) { negate_acc(); sgn = 0x80008000u; }      // once per tile (kflip <= nk - 3 whenever nk >= 8)
-            compute_staged(kt & 1, kt + 2, 0);
+            compute_staged(kt & 1, kDma ? kt + 1 : kt + 2, 0);
             __syncthreads();
         }
         if (kt + 1 < nk) {
-            compute_staged(kt & 1, 0, 1);
+            if constexpr (kDma) compute_staged(kt & 1, kt + 1, 0); else compute_staged(kt & 1, 0, 1);
             __syncthreads();
             ++kt;
         }
@@ -803,7 +835,7 @@ hipError_t launch_ring(const GemmArgs& a, hipStream_t s) {
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3, bool TR = false, bool BF16 = false>
 hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LDT * sizeof(float);
+    constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * ((TERMS == 3 && SOME_GEMM_DMA) ? 32 : LDT) * sizeof(float);
     static DeviceOnce attr_once;
     auto kern = &hgemm3_kernel<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, TERMS, TR, BF16>;
     if (attr_once.need()) {
