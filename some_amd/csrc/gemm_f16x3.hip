@@ -56,6 +56,14 @@ __device__ __forceinline__ uint32_t pack_split_pair(float v, int lane) {
     return (lane & 1) ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
 }
 
+// 16 bytes per lane, buffer -> LDS (lane t lands at dst + 16 t).  A plain function on purpose: with the builtin written inside the kernel
+// TEMPLATE (dependent context) hipcc (ROCm 7.2) silently drops some instantiations' host stubs and the library fails to load with an
+// undefined kernel symbol (seen first in train_gemm16s.hip).
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t r, float* lds_dst, uint32_t voff, uint32_t soff) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds_dst, 16, voff, soff, 0, 0);
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, bool FULL>
 __device__ __forceinline__ void epilogue(const GemmArgs& a, const GemmGroup& g, f32x16 (&acc)[TM][TN], int m0, int n0,
                                          int wm, int wn, int lane, char* wave_lds = nullptr) {
@@ -389,10 +397,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     }
     const int dst0 = srow * LDT + scol * 4;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);       // DMA destinations only (the epilogues keep the lane-derived index, see above)
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
     auto dma_piece = [&](int buf, int kt, int p) {                     // rows p RPP + 8 wave .. + 7 of k-block kt -> LDS buffer `buf`
-        float* dst = lds + buf * STAGE + (p * RPP + 8 * wave_u) * 32;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(p * RPP < BM ? rsa : rsw, (lds_ptr_t)dst, 16, voff[p], (uint32_t)(kt0 + kt) * 128u, 0, 0);
+        dma16_buf(p * RPP < BM ? rsa : rsw, lds + buf * STAGE + (p * RPP + 8 * wave_u) * 32, voff[p], (uint32_t)(kt0 + kt) * 128u);
     };
     f32x4 stage[NLD];
     auto gload = [&](int kt) {
