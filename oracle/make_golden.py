@@ -548,6 +548,29 @@ def gen_train_trajectory():
             out[f'p{step}.{k}'] = np.array(list(v[:8]) + [v.sum(), np.sqrt((v * v).sum())])
         out[f'bn{step}.mean'] = bufs[bn].detach().numpy().copy()
         out[f'bn{step}.var'] = bufs[bn_var].detach().numpy().copy()
+    # the same 8 updates the way Lightning's precision='bf16' runs them (train.py:65, configs/midi_conformer.yaml:35): forward and losses under
+    # torch.autocast(bfloat16), fp32 master weights and optimiser - the yardstick of the HIP bf16 trajectory (how far the REFERENCE's own bf16
+    # arithmetic drifts from its fp32 run over 8 updates)
+    model16 = RefModel(copy.deepcopy(cfg)).train()
+    model16.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    opt16 = torch.optim.AdamW(model16.parameters(), lr=oa['lr'], betas=(oa['beta1'], oa['beta2']), weight_decay=oa['weight_decay'])
+    sched16 = sched_mod.WarmupLR(opt16, warmup_steps=4, min_lr=cfg['lr_scheduler_args']['min_lr'])
+    rows16 = {k: [] for k in ('bound_loss', 'midi_loss', 'grad_norm')}
+    for step in range(TRAJ_STEPS):
+        t = {k: torch.from_numpy(v) for k, v in synth.synth_train_batch(B=2 + step % 2, T=80 + 16 * (step % 3), seed=100 + step).items()}
+        opt16.zero_grad(set_to_none=True)
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            probs, bounds = model16(x=t['units'], f0=None, mask=t['unit2note'] > 0, sig=False)
+            bound_loss = ref_losses.BinaryEMDLoss()(bounds, t['bounds'])
+            midi_loss = torch.nn.BCEWithLogitsLoss()(probs, t['probs'])
+        (bound_loss + midi_loss).backward()
+        rows16['bound_loss'].append(float(bound_loss))
+        rows16['midi_loss'].append(float(midi_loss))
+        rows16['grad_norm'].append(float(torch.nn.utils.clip_grad_norm_(model16.parameters(), cfg.get('clip_grad_norm', 1.0))))
+        opt16.step()
+        sched16.step()
+    for k, v in rows16.items():
+        out['bf16.' + k] = np.array(v)
     for k, v in rows.items():
         out[k] = np.array(v)
     names = []
@@ -559,6 +582,7 @@ def gen_train_trajectory():
     out['names'] = np.array(names)
     np.savez_compressed(OUT / 'train_trajectory.npz', **out)
     print('train_trajectory.npz', len(out), 'losses', rows['bound_loss'], rows['midi_loss'], 'lr', rows['lr'], 'norm', rows['grad_norm'])
+    print('   autocast bf16 arm:', rows16['bound_loss'], rows16['midi_loss'])
 
 
 def synth_quant_batch(B=2, T=96, seed=33):

@@ -609,6 +609,36 @@ def test_update_without_host_sync_equals_the_synchronous_one(precision):
     assert torch.equal(tr.model.params.flat, before)
 
 
+def test_bf16_trajectory_stays_within_the_references_own_bf16_drift(golden_dir):
+    """BASELINE configs[4] in its own arithmetic over several updates: the eight updates of test_training_trajectory_matches_reference with
+    ``pl_trainer_precision: bf16``.  The yardstick is the reference itself: the same eight updates under torch.autocast(bfloat16) (fixture
+    keys ``bf16.*``, oracle/make_golden.py:gen_train_trajectory) drift up to 1.5 % (bound loss), 1.2e-4 (midi loss) and 2.5 % (gradient norm)
+    from its fp32 run; the HIP bf16 trainer must stay within 1.5 x that drift (+ 1e-3), update by update in the running maximum."""
+    from some_amd.training.task import MIDIExtractionTrainer
+    g = np.load(golden_dir / 'train_trajectory.npz')
+    cfg = get_config('two_head_model')
+    for k in ('conv_drop', 'ffn_latent_drop', 'ffn_out_drop', 'attention_drop'):
+        cfg['midi_extractor_args'][k] = 0.0
+    cfg['lr_scheduler_args'] = dict(cfg['lr_scheduler_args'], warmup_steps=int(g['warmup_steps']))
+    tr = MIDIExtractionTrainer(dict(cfg, pl_trainer_precision='bf16'), device='cuda')
+    assert tr.mixed and tr.mixed_operand == 'bf16'
+    tr.model.params.load_state_dict(synth.synth_state_dict(cfg, int(g['weights_seed'])))
+    worst_hip = dict(bound_loss=0.0, midi_loss=0.0, grad_norm=0.0)
+    worst_ref = dict(worst_hip)
+    for step in range(int(g['steps'])):
+        sample = {k: torch.from_numpy(v).cuda() for k, v in synth.synth_train_batch(B=2 + step % 2, T=80 + 16 * (step % 3), seed=100 + step).items()}
+        out = tr.training_step(sample)
+        assert not out['skipped'] and out['lr'] == pytest.approx(float(g['lr'][step]), rel=1e-12)
+        for k in worst_hip:
+            ref32 = float(g[k][step])
+            mine = out[k].item() if k != 'grad_norm' else out[k]
+            worst_hip[k] = max(worst_hip[k], abs(mine - ref32) / abs(ref32))
+            worst_ref[k] = max(worst_ref[k], abs(float(g['bf16.' + k][step]) - ref32) / abs(ref32))
+            assert worst_hip[k] <= 1.5 * worst_ref[k] + 1e-3, (step, k, mine, ref32, float(g['bf16.' + k][step]))
+    print('bf16 trajectory, worst relative distance from the reference fp32 run over 8 updates: HIP', {k: float(f'{v:.3g}') for k, v in worst_hip.items()},
+          '| reference autocast', {k: float(f'{v:.3g}') for k, v in worst_ref.items()})
+
+
 @pytest.mark.parametrize('precision', ['f32', 'f16x3'])
 def test_quantized_task_step_matches_reference(golden_dir, precision):
     """QuantizedMIDIExtractionTask (training/me_quant_task.py:30-78): one step of the reference model with 129 classes + nn.CrossEntropyLoss(
