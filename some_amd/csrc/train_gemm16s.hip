@@ -475,7 +475,8 @@ hipError_t launch_gemm16s(int epi, const void* A16, int lda, const void* B16, in
     // configs/base.yaml:55-56) 33 x 2 = 66 workgroups on 256 CUs - a quarter of the chip, 25 - 35 us of which 4 us are arithmetic.  Below
     // ~3/4 of a round of big tiles the 64 x 128 tile (2 wavefronts, 36 KB of LDS, up to 4 workgroups per CU) takes over: 4 x the
     // workgroups, the same k order per element - results bit-identical (tests/test_gpu_train_ffn16.py).
-    static const int force = getenv("SOME_AMD_G16S_TILE") ? atoi(getenv("SOME_AMD_G16S_TILE")) : -1;     // A/B: 0 big, 1 small
+    const char* force_env = getenv("SOME_AMD_G16S_TILE");                                          // A/B and the bit-identity test: 0 big, 1 small
+    const int force = force_env ? atoi(force_env) : -1;
     const long big_wgs = (long)((M + 127) / 128) * ((N + 255) / 256);
     const bool small = force >= 0 ? force == 1 : big_wgs < 192;
 #define G16S_CASE(E) case E: return small ? (bf16 ? launch16s<E, true, 1, 2, 3, 4>(a, s) : launch16s<E, false, 1, 2, 3, 4>(a, s)) \

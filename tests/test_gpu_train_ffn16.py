@@ -356,3 +356,27 @@ def test_weight_images_of_many_weights_in_one_launch(ops, operand):
         assert torch.equal(ops.shadow16(ws[3])[0], ws[3].to(ops.dtype16))
     finally:
         ops.set_mixed_precision(False)
+
+
+@pytest.mark.parametrize('epi', [0, 3])
+def test_gemm16s_tiles_are_bit_identical(ops, epi, monkeypatch):
+    """The 64 x 128 tile (small grids, round 5) against the 128 x 256 tile on the same operands: every output element accumulates its
+    k-steps in the same order, so the results must be the same BITS (SOME_AMD_G16S_TILE forces the tile per call)."""
+    ops.set_mixed_precision(True, 'bf16')
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    M, N, K = 1000, 512, 2048
+    a = torch.randn(M, K, device='cuda', generator=gen).to(ops.dtype16)
+    w = torch.randn(N, K, device='cuda', generator=gen).to(ops.dtype16) / 30
+    b = torch.randn(N, device='cuda', generator=gen)
+    res = torch.randn(M, N, device='cuda', generator=gen)
+    outs = []
+    for tile in ('0', '1'):
+        monkeypatch.setenv('SOME_AMD_G16S_TILE', tile)
+        out = torch.full((M, N), float('nan'), device='cuda')
+        if epi == 0:
+            ops.gemm16s(0, a, w, b, out, N, M, N, K)
+        else:
+            ops.gemm16s(3, a, w, b, out, N, M, N, K, h16=res, p=0.1, seed=77, alpha=0.5)
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
