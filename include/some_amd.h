@@ -304,6 +304,25 @@ int some_train_layernorm_bwd(SomeHandle* h, const float* dy_dev, const float* x_
                              const float* mean_dev, const float* rstd_dev, float* dx_dev, float* dgamma_dev,
                              float* dbeta_dev, int32_t accumulate, int32_t M, void* scratch_dev, size_t scratch_bytes,
                              void* stream);
+/* Block-level operators (round 5): the trainer's FFN sub-block `x + alpha * dropout(ffn(LayerNorm(x)))` (modules/conform/Gconform.py:29-34,
+ * 57, 60) forward and backward as ONE call each - the same launches, in the same order, as some_train_layernorm_fwd16 + 2 x some_train_gemm16s
+ * (forward) and some_train_dropcast16 + 2 x some_train_gemm16s + 2 x some_train_gemm16_wgrad16 + some_train_layernorm_bwd_add (backward):
+ * bit-identical results, a third of the host time.  save_dev: caller-owned block the forward fills for the backward (n16 | mean | rstd | h16 |
+ * a16); scratch_dev: temporaries of the backward (dy16 | dh16 | dn); both 256-byte aligned, sized by the *_bytes functions.  w*_16: the
+ * weights' 16-bit images [N, K] (forward) / their transposes [K, N] (backward) from some_train_transpose16*.  The weight / bias / LayerNorm
+ * gradients are ACCUMULATED into d*_dev (the flat gradient buffer); dx_dev = LayerNorm'(dn) (+ d when add_residual). */
+size_t some_train_ffn_block_save_bytes(const SomeHandle* h, int32_t M, int32_t K, int32_t H);
+size_t some_train_ffn_block_scratch_bytes(const SomeHandle* h, int32_t M, int32_t K, int32_t H, int32_t N);
+int some_train_ffn_block_fwd(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev, const void* w1_16_dev,
+                             const float* b1_dev, const void* w2_16_dev, const float* b2_dev, int32_t M, int32_t K, int32_t H, int32_t N,
+                             int32_t operand, float alpha, float p_latent, uint64_t seed_latent, float p_out, uint64_t seed_out,
+                             void* save_dev, size_t save_bytes, float* out_dev, void* stream);
+int some_train_ffn_block_bwd(SomeHandle* h, const float* d_dev, const float* x_dev, const float* gamma_dev, const void* save_dev,
+                             const void* w1t_16_dev, const void* w2t_16_dev, int32_t M, int32_t K, int32_t H, int32_t N, int32_t operand,
+                             float alpha, float p_latent, uint64_t seed_latent, float p_out, uint64_t seed_out,
+                             float* dw1_dev, float* db1_dev, float* dw2_dev, float* db2_dev, float* dgamma_dev, float* dbeta_dev,
+                             int32_t add_residual, float* dx_dev, void* scratch_dev, size_t scratch_bytes, void* ln_scratch_dev, size_t ln_scratch_bytes,
+                             void* partial_dev, size_t partial_bytes, void* stream);
 /* LayerNorm forward with the output written in 16 bits (operand 1 = f16, 2 = bf16): the FFN's GEMM operand without a cast pass. */
 int some_train_layernorm_fwd16(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
                                void* y16_dev, float* mean_dev, float* rstd_dev, int32_t M, int32_t operand, void* stream);

@@ -84,6 +84,13 @@ SYMBOLS = {
                                      C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_float, _P]),
     'some_train_dropcast16': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_uint64, C.c_int32, _P]),
     'some_train_layernorm_fwd16': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
+    'some_train_ffn_block_save_bytes': (C.c_size_t, [_P, C.c_int32, C.c_int32, C.c_int32]),
+    'some_train_ffn_block_scratch_bytes': (C.c_size_t, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'some_train_ffn_block_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                           C.c_uint64, C.c_float, C.c_uint64, _P, C.c_size_t, _P, _P]),
+    'some_train_ffn_block_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                           C.c_uint64, C.c_float, C.c_uint64, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_size_t, _P, C.c_size_t,
+                                           _P, C.c_size_t, _P]),
     'some_train_layernorm_bwd_add': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
     'some_train_gemm16_wgrad16': (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
                                             C.c_size_t, _P]),

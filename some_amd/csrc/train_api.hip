@@ -235,6 +235,75 @@ int some_train_gemm16_wgrad16(SomeHandle* h, const void* dY16_dev, int32_t ldy, 
     return SOME_OK;
 }
 
+// ---- block-level operators (round 5): one C call per conformer sub-block and direction ---------------------------------------------
+// The trainer's Python layer drove 3 (forward) + 7 (backward) library calls and 9 tensor allocations per FFN sub-block; at the reference's
+// batch shape (8 x ~520 frames, configs/base.yaml:55-56) the step is bound by that host path (enqueue 7.5 - 8.4 ms of 8.9).  These entry
+// points run the SAME launches in the same order (bit-identical results) behind one call; the caller owns one `save` block (activations kept
+// for the backward) and one scratch block.  Layout of both: consecutive 256-byte aligned segments, sizes from the *_bytes functions.
+static size_t up256(size_t n) { return (n + 255) / 256 * 256; }
+
+size_t some_train_ffn_block_save_bytes(const SomeHandle* h, int32_t M, int32_t K, int32_t H) {
+    (void)h;
+    if (M <= 0 || K <= 0 || H <= 0) return 256;
+    return up256((size_t)M * K * 2) + 2 * up256((size_t)M * 4) + up256(2 * (size_t)M * H * 2);       // n16 | mean | rstd | h16, a16 planes
+}
+size_t some_train_ffn_block_scratch_bytes(const SomeHandle* h, int32_t M, int32_t K, int32_t H, int32_t N) {
+    (void)h;
+    if (M <= 0 || K <= 0 || H <= 0 || N <= 0) return 256;
+    return up256((size_t)M * N * 2) + up256((size_t)M * H * 2) + up256((size_t)M * K * 4);             // dy16 | dh16 | dn
+}
+
+int some_train_ffn_block_fwd(SomeHandle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev, const void* w1_16_dev,
+                             const float* b1_dev, const void* w2_16_dev, const float* b2_dev, int32_t M, int32_t K, int32_t H, int32_t N,
+                             int32_t operand, float alpha, float p_latent, uint64_t seed_latent, float p_out, uint64_t seed_out,
+                             void* save_dev, size_t save_bytes, float* out_dev, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M > 0 && x_dev && save_dev && out_dev, "some_train_ffn_block_fwd: bad argument");
+    T_CHECK(h, N == K, "some_train_ffn_block_fwd: the residual needs N == K");
+    T_CHECK(h, save_bytes >= some_train_ffn_block_save_bytes(h, M, K, H) && (reinterpret_cast<uintptr_t>(save_dev) & 255) == 0,
+            "some_train_ffn_block_fwd: save block too small / not 256-byte aligned (some_train_ffn_block_save_bytes)");
+    char* p = static_cast<char*>(save_dev);
+    void* n16 = p; p += up256((size_t)M * K * 2);
+    float* mean = reinterpret_cast<float*>(p); p += up256((size_t)M * 4);
+    float* rstd = reinterpret_cast<float*>(p); p += up256((size_t)M * 4);
+    char* ha = p;                                                             // h16 plane, then the a16 plane
+    int rc;
+    if ((rc = some_train_layernorm_fwd16(h, x_dev, gamma_dev, beta_dev, n16, mean, rstd, M, operand, stream))) return rc;
+    if ((rc = some_train_gemm16s(h, 1, n16, K, w1_16_dev, K, b1_dev, ha, H, nullptr, 0, (int64_t)M * H, M, H, K, operand, p_latent, seed_latent, 1.0f, stream)))
+        return rc;
+    return some_train_gemm16s(h, 3, ha + (size_t)M * H * 2, H, w2_16_dev, H, b2_dev, out_dev, N, x_dev, K, 0, M, N, H, operand, p_out, seed_out, alpha, stream);
+}
+
+int some_train_ffn_block_bwd(SomeHandle* h, const float* d_dev, const float* x_dev, const float* gamma_dev, const void* save_dev,
+                             const void* w1t_16_dev, const void* w2t_16_dev, int32_t M, int32_t K, int32_t H, int32_t N, int32_t operand,
+                             float alpha, float p_latent, uint64_t seed_latent, float p_out, uint64_t seed_out,
+                             float* dw1_dev, float* db1_dev, float* dw2_dev, float* db2_dev, float* dgamma_dev, float* dbeta_dev,
+                             int32_t add_residual, float* dx_dev, void* scratch_dev, size_t scratch_bytes, void* ln_scratch_dev, size_t ln_scratch_bytes,
+                             void* partial_dev, size_t partial_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M > 0 && d_dev && x_dev && save_dev && dx_dev && dw1_dev && dw2_dev && dgamma_dev && dbeta_dev, "some_train_ffn_block_bwd: bad argument");
+    T_CHECK(h, scratch_dev && scratch_bytes >= some_train_ffn_block_scratch_bytes(h, M, K, H, N) && (reinterpret_cast<uintptr_t>(scratch_dev) & 255) == 0,
+            "some_train_ffn_block_bwd: scratch block too small / not 256-byte aligned (some_train_ffn_block_scratch_bytes)");
+    const char* s = static_cast<const char*>(save_dev);
+    const void* n16 = s; s += up256((size_t)M * K * 2);
+    const float* mean = reinterpret_cast<const float*>(s); s += up256((size_t)M * 4);
+    const float* rstd = reinterpret_cast<const float*>(s); s += up256((size_t)M * 4);
+    const char* ha = s;
+    char* q = static_cast<char*>(scratch_dev);
+    void* dy16 = q; q += up256((size_t)M * N * 2);
+    void* dh16 = q; q += up256((size_t)M * H * 2);
+    float* dn = reinterpret_cast<float*>(q);
+    int rc;
+    // the order of _FfnBlock16.backward (some_amd/training/ops.py): dy16, dh16, dn, weight gradients (first linear, then second), LayerNorm
+    if ((rc = some_train_dropcast16(h, d_dev, dy16, M, N, alpha, p_out, seed_out, operand, stream))) return rc;
+    if ((rc = some_train_gemm16s(h, 2, dy16, N, w2t_16_dev, N, nullptr, dh16, H, ha, H, 0, M, H, N, operand, p_latent, seed_latent, 1.0f, stream))) return rc;
+    if ((rc = some_train_gemm16s(h, 0, dh16, H, w1t_16_dev, H, nullptr, dn, K, nullptr, 0, 0, M, K, H, operand, 0.f, 0, 1.0f, stream))) return rc;
+    if ((rc = some_train_gemm16_wgrad16(h, dh16, H, n16, K, dw1_dev, db1_dev, H, K, M, operand, 1, partial_dev, partial_bytes, stream))) return rc;
+    if ((rc = some_train_gemm16_wgrad16(h, dy16, N, ha + (size_t)M * H * 2, H, dw2_dev, db2_dev, N, H, M, operand, 1, partial_dev, partial_bytes, stream))) return rc;
+    return some_train_layernorm_bwd_add(h, dn, x_dev, gamma_dev, mean, rstd, add_residual ? d_dev : nullptr, dx_dev, dgamma_dev, dbeta_dev, 1, M,
+                                        ln_scratch_dev, ln_scratch_bytes, stream);
+}
+
 int some_train_transpose(SomeHandle* h, const float* in_dev, int32_t M, int32_t N, int32_t ld_in, float* out_dev,
                          int32_t ld_out, int32_t split_out, void* stream) {
     if (!h) return SOME_EINVAL;

@@ -30,7 +30,12 @@ class TrainOps:
         self._pinned_stream = None
         self.tape: Optional['Tape'] = None        # set by the trainer for the duration of a forward + backward pass
         self._partials: Dict[int, torch.Tensor] = {}
+        self._block_scratch: Dict[int, torch.Tensor] = {}
         self._size_cache: Dict[tuple, int] = {}
+        # Block-level library calls (round 5): one call per FFN sub-block and direction (some_train_ffn_block_fwd / _bwd: the same launches in
+        # the same order as the call-by-call path, bit-identical) - the step is bound by the host's enqueue path at the reference's batch
+        # shape.  SOME_AMD_TRAIN_BLOCK_CALLS=0: the call-by-call path (A/B runs, and the reference for the bit-identity test).
+        self.block_calls = os.environ.get('SOME_AMD_TRAIN_BLOCK_CALLS', '1') != '0'
         # Two LANES (trainer's tape only): the midi and the bound stream of a Gcf layer are independent between the cross gates
         # (Gconform.py:82-87), forward and backward, so the model issues the bound stream's block on lane 1 = a second HIP stream.
         # At the reference's batch shape (8 phrases, ~4 100 frames) a step is ~860 launches of 5 - 35 us, most of them far from filling
@@ -313,6 +318,13 @@ class TrainOps:
         buf = self._scratch.get(self._lane)
         if buf is None or buf.numel() < need:
             buf = self._scratch[self._lane] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return buf
+
+    def block_scratch(self, need: int) -> torch.Tensor:
+        """Temporaries of a block-level backward call (dy16 | dh16 | dn ...), one buffer per lane, grown on demand."""
+        buf = self._block_scratch.get(self._lane)
+        if buf is None or buf.numel() < need:
+            buf = self._block_scratch[self._lane] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return buf
 
     def partial(self, need: int) -> torch.Tensor:
@@ -822,6 +834,20 @@ class _FfnBlock16(torch.autograd.Function):
         x = x.contiguous()
         M, K = x.shape
         H, N = w1.shape[0], w2.shape[0]
+        ctx.ops = ops
+        ctx.drop = (alpha, p_latent, seed_latent, p_out, seed_out)
+        ctx.params = (gamma, beta, w1, b1, w2, b2)                                   # identities: shadows and gradient sinks
+        if ops.block_calls and b1 is not None and b2 is not None:
+            # one library call for the sub-block (some_train_ffn_block_fwd: the same three launches); ONE allocation holds what the backward needs
+            save = torch.empty(ops._bytes('some_train_ffn_block_save_bytes', M, K, H), dtype=torch.uint8, device=ops.device)
+            out = ops.new(M, N)
+            ops.check(ops.lib.some_train_ffn_block_fwd(ops.h, _p(x), _p(gamma), _p(beta), _p(ops.shadow16(w1)[0]), _p(b1), _p(ops.shadow16(w2)[0]), _p(b2),
+                                                       M, K, H, N, ops._hi_mode, float(alpha), float(p_latent), seed_latent, float(p_out), seed_out,
+                                                       _p(save), save.numel(), _p(out), ops.stream()))
+            ctx.block = True
+            ctx.save_for_backward(x, gamma, save)
+            return out
+        ctx.block = False
         n16 = torch.empty((M, K), dtype=ops.dtype16, device=ops.device)
         mean, rstd = ops.new(M), ops.new(M)
         ops.check(ops.lib.some_train_layernorm_fwd16(ops.h, _p(x), _p(gamma), _p(beta), _p(n16), _p(mean), _p(rstd), M, ops._hi_mode, ops.stream()))
@@ -829,19 +855,43 @@ class _FfnBlock16(torch.autograd.Function):
         ops.gemm16s(1, n16, ops.shadow16(w1)[0], b1, ha, H, M, H, K, plane=M * H, p=p_latent, seed=seed_latent)
         out = ops.new(M, N)
         ops.gemm16s(3, ha[1], ops.shadow16(w2)[0], b2, out, N, M, N, H, h16=x, p=p_out, seed=seed_out, alpha=alpha)
-        ctx.ops = ops
-        ctx.drop = (alpha, p_latent, seed_latent, p_out, seed_out)
         ctx.save_for_backward(x, gamma, mean, rstd, n16, ha)
-        ctx.params = (gamma, beta, w1, b1, w2, b2)                                   # identities: shadows and gradient sinks
         return out
 
     @staticmethod
     def backward(ctx, d):
         ops: TrainOps = ctx.ops
-        x, gamma_t, mean, rstd, n16, ha = ctx.saved_tensors
         gamma, beta, w1, b1, w2, b2 = ctx.params
         alpha, p_latent, seed_latent, p_out, seed_out = ctx.drop
         d = d.contiguous()
+        if ctx.block:
+            x, gamma_t, save = ctx.saved_tensors
+            M, K = x.shape
+            H, N = w1.shape[0], w2.shape[0]
+            sinks = [ops.sink(t) for t in (w1, b1, w2, b2, gamma, beta)]
+            if all(t is not None for t in sinks) and all(ctx.needs_input_grad[i] for i in (2, 3, 4, 5, 6, 7)):
+                # one library call (some_train_ffn_block_bwd): every gradient lands in the flat gradient buffer, dx = d + LayerNorm'(dn)
+                dx = torch.empty_like(x)
+                scr = ops.block_scratch(ops._bytes('some_train_ffn_block_scratch_bytes', M, K, H, N))
+                sc = ops.scratch(M, 512)
+                part = ops.partial(max(ops._bytes('some_train_gemm16_bytes', H, K, M, K + 4), ops._bytes('some_train_gemm16_bytes', N, H, M, H + 4)))
+                ops.check(ops.lib.some_train_ffn_block_bwd(ops.h, _p(d), _p(x), _p(gamma_t), _p(save), _p(ops.shadow16(w1)[1]), _p(ops.shadow16(w2)[1]),
+                                                           M, K, H, N, ops._hi_mode, float(alpha), float(p_latent), seed_latent, float(p_out), seed_out,
+                                                           _p(sinks[0]), _p(sinks[1]), _p(sinks[2]), _p(sinks[3]), _p(sinks[4]), _p(sinks[5]),
+                                                           1 if ctx.needs_input_grad[1] else 0, _p(dx), _p(scr), scr.numel(), _p(sc), sc.numel(),
+                                                           _p(part), part.numel(), ops.stream()))
+                for t in (w1, b1, w2, b2, gamma, beta):
+                    ops.deposited(t)
+                return None, dx, None, None, None, None, None, None, None, None, None, None, None
+            # (a parameter without a gradient sink: unpack the save block into the tensors of the call-by-call path below)
+            o0 = (M * K * 2 + 255) // 256 * 256
+            o1 = o0 + (M * 4 + 255) // 256 * 256
+            o2 = o1 + (M * 4 + 255) // 256 * 256
+            n16 = save[:M * K * 2].view(ops.dtype16).view(M, K)
+            mean, rstd = save[o0:o0 + M * 4].view(torch.float32), save[o1:o1 + M * 4].view(torch.float32)
+            ha = save[o2:o2 + 2 * M * H * 2].view(ops.dtype16).view(2, M, H)
+        else:
+            x, gamma_t, mean, rstd, n16, ha = ctx.saved_tensors
         M, K = x.shape
         H, N = w1.shape[0], w2.shape[0]
         dy16 = torch.empty((M, N), dtype=ops.dtype16, device=ops.device)
