@@ -426,18 +426,7 @@ constexpr int kAbl = SOME_ATTN_ABL;
 #ifndef SOME_ATTN_DBG_WG
 #define SOME_ATTN_DBG_WG 2048      // (timeline builds, tools/attn_probe.hip) a workgroup of the second round
 #endif
-#ifndef SOME_ATTN_FLIP
-#define SOME_ATTN_FLIP 0      // measured (round 5): removes nothing that matters (the bound bias was the head's dropped lo * lo term), costs 2 %
-#endif
-#ifndef SOME_ATTN_LO_RTN
-#define SOME_ATTN_LO_RTN 0
-#endif
-#ifndef SOME_ATTN_PRIO
-#define SOME_ATTN_PRIO 2      // s_setprio 1 over phase B (1) or phase A (2); measured 2.338 (0) / 2.333 (1) / 2.310 ms (2), profiles/r05_experiments.md
-#endif
-#ifndef SOME_ATTN_STAGE_SLOT
-#define SOME_ATTN_STAGE_SLOT 8
-#endif
+constexpr int kStageSlot = 8;      // slots 8 - 15 of phase A carry the tile DMA (0 / 4 / 8 / 16 measured the same: profiles/r05m_attn_env.txt)
 constexpr float kPShiftI = 11.f;
 constexpr float kLazy = 4.5f;
 
@@ -610,10 +599,8 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
     uint32_t lpk[4][4];            // [slab][pair] packed lo halves
     float lo0_[4][4];              // first half-step's leftover
     auto pel = [&](const f32x16& c0, const f32x16& c1, int e) -> float { return e < 16 ? c0[e] : c1[e - 16]; };
-    auto split_half = [&](f32x16& c0, f32x16& c1, int q, int j, int half, bool neg) {
-        // neg: the split of -p (source modifiers of v_cvt_pkrtz / v_fma_mix: no extra instruction) - see the sign flip of O below
-        const float p0 = neg ? -pel(c0, c1, 8 * q + 2 * j) : pel(c0, c1, 8 * q + 2 * j);
-        const float p1 = neg ? -pel(c0, c1, 8 * q + 2 * j + 1) : pel(c0, c1, 8 * q + 2 * j + 1);
+    auto split_half = [&](f32x16& c0, f32x16& c1, int q, int j, int half) {
+        const float p0 = pel(c0, c1, 8 * q + 2 * j), p1 = pel(c0, c1, 8 * q + 2 * j + 1);
         if (half == 0) {
             const half2_t hh = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(p0, p1));
             hpk[q][j] = __builtin_bit_cast(uint32_t, hh);
@@ -621,13 +608,7 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
         } else {
             const half2_t hh = __builtin_bit_cast(half2_t, hpk[q][j]);
             const float l1 = mix_sub_(hh[1], mone, p1);
-#if SOME_ATTN_LO_RTN
-            typedef float f32x2_ __attribute__((ext_vector_type(2)));
-            const f32x2_ lv = {lo0_[q][j], l1};
-            lpk[q][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(lv, half2_t));          // v_cvt_pk_f16_f32: round to nearest even
-#else
             lpk[q][j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo0_[q][j], l1));
-#endif
         }
     };
     auto frag_of = [&](const uint32_t (&w)[4]) {
@@ -640,10 +621,10 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
 
     // One tile step.  c0 / c1: raw scores of tile i on entry, its probabilities afterwards.  n0 / n1: receive S(i+1).
     //   FULL: tiles i + 1 .. i + 3 all exist and tile i + 1 needs no masking (interior of the clip).  QK = false: last tile (no S(i+1)).
-    auto step = [&](int i, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1, auto full_, auto qk_, auto neg_) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full_)::value, QK = decltype(qk_)::value, NEG = decltype(neg_)::value;
+    auto step = [&](int i, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1, auto full_, auto qk_) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_)::value, QK = decltype(qk_)::value;
         // ---- phase A: S(i+1) = K(i+1) Q^T  |  P(i) = exp2(S(i) c + nm), split of slabs 0 and 1, staging
-        if (SOME_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);                 // raised priority over the QK phase: 2.338 -> 2.310 ms (over the PV phase: 2.333; profiles/r05j_attn_variants.txt)
         if constexpr (QK) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) read_k1(i + 1, 0, j);
@@ -668,12 +649,12 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
             // staging, EARLY in the step (slots 8 - 15): K tile i + 2 and V^T tile i + 1 out of the registers into the rings, the next loads
             // behind them.  The ring stores then have 32 slots to drain before the barrier's lgkmcnt(0); at the END of the step they cost
             // 0.6 ms per launch (profiles/r05_experiments.md: ablations 16 / 32 / 8 - it is the store -> barrier wait, not the loads)
-            if (t >= SOME_ATTN_STAGE_SLOT && t < SOME_ATTN_STAGE_SLOT + 8 && !(kAbl & 4)) {
-                const int p = (t - SOME_ATTN_STAGE_SLOT) & 3;
+            if (t >= kStageSlot && t < kStageSlot + 8 && !(kAbl & 4)) {
+                const int p = (t - kStageSlot) & 3;
                 if constexpr (DMA) {
-                    if (t < SOME_ATTN_STAGE_SLOT + 4) { if (FULL || i + 2 < n) dma_k(i + 2, p); }
+                    if (t < kStageSlot + 4) { if (FULL || i + 2 < n) dma_k(i + 2, p); }
                     else { if (FULL || i + 1 < n) dma_v(i + 1, p); }
-                } else if (t < SOME_ATTN_STAGE_SLOT + 4) {
+                } else if (t < kStageSlot + 4) {
                     if (!(kAbl & 32)) { if (FULL || i + 2 < n) lstore_k1(i + 2, p); } else asm volatile("" :: "v"(rk[p]));
                     if (!(kAbl & 16)) { if (FULL || i + 3 < n) gload_k1(i + 3, p); }
                 } else {
@@ -689,15 +670,14 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
             } else {
                 const int j = t - 8;                              // 0 .. 15
                 c1[j] = exp2_(fmaf(c1[j], c, nm));
-                split_half(c0, c1, j >> 3, (j >> 1) & 3, j & 1, NEG);  // slab 0 in slots 8 - 15, slab 1 in 16 - 23
+                split_half(c0, c1, j >> 3, (j >> 1) & 3, j & 1);  // slab 0 in slots 8 - 15, slab 1 in 16 - 23
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (SOME_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         if constexpr (QK && !FULL) mask_tile(i + 1, n0, n1);
         // ---- phase B: O += V(i)^T P(i)^T  |  split of slabs 2 and 3, row sums, row maximum of S(i+1)
         float mxa = 0.f, mxb = 0.f;
-        if (SOME_ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int t = 0; t < 24; ++t) {
             const int q = t / 6, u = t % 6;
@@ -716,8 +696,8 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
             }
             // split: slab 2 in slots 2 - 9, slab 3 in slots 8 - 15 (half a pair per slot)
             if (!((kAbl & 1) && i > 0)) {
-            if (t >= 2 && t < 10) split_half(c0, c1, 2, (t - 2) >> 1, (t - 2) & 1, NEG);
-            if (t >= 8 && t < 16) split_half(c0, c1, 3, (t - 8) >> 1, (t - 8) & 1, NEG);
+            if (t >= 2 && t < 10) split_half(c0, c1, 2, (t - 2) >> 1, (t - 2) & 1);
+            if (t >= 8 && t < 16) split_half(c0, c1, 3, (t - 8) >> 1, (t - 8) & 1);
             // row sums: 32 probabilities over slots 0 - 15
             if (t < 16) { ps0 += pel(c0, c1, 2 * t); ps1 += pel(c0, c1, 2 * t + 1); }
             }
@@ -733,7 +713,6 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (SOME_ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         l_run += ps0 + ps1;
         ps0 = 0.f; ps1 = 0.f;
         if constexpr (QK && !(kAbl & 1)) {
@@ -799,43 +778,22 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
     }
     // S(0) read K ring slot 0 and the first step stores K(2) into it (the round-1 race, see attention3_kernel)
     __syncthreads();
-    // Sign flip of the O accumulation (round 5 experiment, OFF: profiles/r05_experiments.md "the f16 matrix pipe rounds toward minus
-    // infinity").  The fp32 accumulate of v_mfma_f32_32x32x16_f16 truncates toward -inf; from key tile nflip ~ 5/8 n on, P can enter
-    // NEGATED (free: source modifiers in the split) into a negated O so that the later partial sums are truncated the other way.
-    // Measured: the attention op's bias (-0.29 of its rms error) is the QKV projection's, carried through the softmax average of V -
-    // not this accumulation's (-0.29 -> -0.24) - and the bound stream's end-to-end bias came from the head's dropped lo * lo term
-    // (api.hip, "heads"); the flip costs 2 % of the kernel.  Kept compilable for the record (-DSOME_ATTN_FLIP=1).
-    const int nflip = (SOME_ATTN_FLIP && n >= 8) ? ((5 * n + 4) / 8) & ~1 : n;
-    bool flipped = false;
     int i = 0;
     if (active) {
-        for (; i + 4 < n && i < nflip; i += 2) {
-            step(i, sa0, sa1, sb0, sb1, Flag<true>{}, Flag<true>{}, Flag<false>{});
-            step(i + 1, sb0, sb1, sa0, sa1, Flag<true>{}, Flag<true>{}, Flag<false>{});
+        for (; i + 4 < n; i += 2) {
+            step(i, sa0, sa1, sb0, sb1, Flag<true>{}, Flag<true>{});
+            step(i + 1, sb0, sb1, sa0, sa1, Flag<true>{}, Flag<true>{});
         }
-        if (SOME_ATTN_FLIP && i >= nflip) {
-            flipped = true;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] = -o0[r]; o1[r] = -o1[r]; }
-            for (; i + 4 < n; i += 2) {
-                step(i, sa0, sa1, sb0, sb1, Flag<true>{}, Flag<true>{}, Flag<true>{});
-                step(i + 1, sb0, sb1, sa0, sa1, Flag<true>{}, Flag<true>{}, Flag<true>{});
-            }
+        for (; i + 2 < n; i += 2) {
+            step(i, sa0, sa1, sb0, sb1, Flag<false>{}, Flag<true>{});
+            step(i + 1, sb0, sb1, sa0, sa1, Flag<false>{}, Flag<true>{});
         }
-        auto tail = [&](auto neg_) __attribute__((always_inline)) {
-            for (; i + 2 < n; i += 2) {
-                step(i, sa0, sa1, sb0, sb1, Flag<false>{}, Flag<true>{}, neg_);
-                step(i + 1, sb0, sb1, sa0, sa1, Flag<false>{}, Flag<true>{}, neg_);
-            }
-            if (i + 1 < n) {
-                step(i, sa0, sa1, sb0, sb1, Flag<false>{}, Flag<true>{}, neg_);
-                step(i + 1, sb0, sb1, sa0, sa1, Flag<false>{}, Flag<false>{}, neg_);
-            } else {
-                step(i, sa0, sa1, sb0, sb1, Flag<false>{}, Flag<false>{}, neg_);
-            }
-        };
-        if constexpr (SOME_ATTN_FLIP) { if (flipped) tail(Flag<true>{}); else tail(Flag<false>{}); }
-        else tail(Flag<false>{});
+        if (i + 1 < n) {
+            step(i, sa0, sa1, sb0, sb1, Flag<false>{}, Flag<true>{});
+            step(i + 1, sb0, sb1, sa0, sa1, Flag<false>{}, Flag<false>{});
+        } else {
+            step(i, sa0, sa1, sb0, sb1, Flag<false>{}, Flag<false>{});
+        }
     } else {
         for (; i < n; ++i) {                       // the same ring traffic and barriers as step(i), nothing else
 #pragma unroll
@@ -869,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
     float* patch = lds + wave * (32 * LDR);
     {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = (flipped ? -1.0f : 1.0f) / l_tot;
+        const float inv = 1.0f / l_tot;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = (r & 3) + 8 * (r >> 2) + 4 * kg;

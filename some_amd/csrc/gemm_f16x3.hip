@@ -20,12 +20,6 @@
 
 namespace {
 
-#ifndef SOME_GEMM_DMA
-#define SOME_GEMM_DMA 0
-#endif
-#ifndef SOME_GEMM_FLIP
-#define SOME_GEMM_FLIP 0      // sign flip of the accumulation's last 3/8 (see hgemm3_kernel); 0: the round-1..4 arithmetic
-#endif
 constexpr int LDT = 36;      // LDS row in dwords: 16 (32 hi halves) + 16 (32 lo halves) + 4 pad
 
 // 1 / (1 + e^-x) with the hardware reciprocal (v_rcp_f32, 1 ulp): the IEEE divide costs ~10 VALU per element
@@ -54,14 +48,6 @@ __device__ __forceinline__ uint32_t pack_split_pair(float v, int lane) {
     // lane ^ 1 exchange as a DPP quad permute [1,0,3,2] (no LDS round trip, unlike __shfl_xor's ds_bpermute)
     const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);
     return (lane & 1) ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
-}
-
-// 16 bytes per lane, buffer -> LDS (lane t lands at dst + 16 t).  A plain function on purpose: with the builtin written inside the kernel
-// TEMPLATE (dependent context) hipcc (ROCm 7.2) silently drops some instantiations' host stubs and the library fails to load with an
-// undefined kernel symbol (seen first in train_gemm16s.hip).
-__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t r, float* lds_dst, uint32_t voff, uint32_t soff) {
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds_dst, 16, voff, soff, 0, 0);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, bool FULL>
@@ -324,13 +310,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     static_assert(!BF16 || (TERMS == 1 && !TR), "bf16 hi halves: one-product kernels only (split.h)");
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    // kDma (round 5, -DSOME_GEMM_DMA=1): the k-blocks go L2 -> LDS by DMA (buffer_load_dwordx4 ... lds) instead of through registers and
-    // ds_write_b128; LDS rows are then 128 unpadded bytes with an XOR swizzle - chunk c (16 B) of row r at position c ^ ((r >> 1) & 7),
-    // conflict-free for the ds_read_b128 lane groups in both the identity and the pi32 row order - applied to the per-lane SOURCE address
-    // (the DMA destination is lane-linear: a wavefront's 64 lanes fill 8 consecutive rows) and again on the fragment reads.
-    constexpr bool kDma = TERMS == 3 && SOME_GEMM_DMA;
-    constexpr int LDW = kDma ? 32 : LDT;                 // LDS row in dwords
-    constexpr int STAGE = (BM + BN) * LDW;               // dwords
+    constexpr int STAGE = (BM + BN) * LDT;               // dwords
     constexpr int NLD = (BM + BN) * 8 / NT;              // 16-byte chunks per thread per k-block
     static_assert((BM + BN) * 8 % NT == 0, "staging must divide evenly");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -376,8 +356,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     static_assert(BM % RPP == 0, "a pass must not straddle A and W");
     const __amdgpu_buffer_rsrc_t rsa = make_rsrc(g.A, (size_t)a.a_rows * a.lda * 4);
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(g.W, (size_t)g.N * a.K * 4);
-    const int srow = tid >> 3;
-    const int scol = kDma ? ((tid & 7) ^ ((srow >> 1) & 7)) : (tid & 7);      // (RPP is a multiple of 16: the swizzle of row srow + p RPP is srow's)
+    const int srow = tid >> 3, scol = tid & 7;
     uint32_t voff[NLD];
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
@@ -396,10 +375,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
         }
     }
     const int dst0 = srow * LDT + scol * 4;
-    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);       // DMA destinations only (the epilogues keep the lane-derived index, see above)
-    auto dma_piece = [&](int buf, int kt, int p) {                     // rows p RPP + 8 wave .. + 7 of k-block kt -> LDS buffer `buf`
-        dma16_buf(p * RPP < BM ? rsa : rsw, lds + buf * STAGE + (p * RPP + 8 * wave_u) * 32, voff[p], (uint32_t)(kt0 + kt) * 128u);
-    };
     f32x4 stage[NLD];
     auto gload = [&](int kt) {
         const uint32_t koff = (uint32_t)(kt0 + kt) * 128u;
@@ -425,26 +400,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     // registers hold k-block kt + 1 (loaded during iteration kt - 1, so its latency is already paid); they are
     // written to the other LDS buffer, immediately re-issued for k-block kt + 2, and the MFMAs of block kt run
     // while those loads fly.  One barrier per k-block; nothing waits on a just-issued load.
-    if constexpr (kDma) {
-#pragma unroll
-        for (int p = 0; p < NLD; ++p) dma_piece(0, 0, p);
-    } else {
-        gload(0);
-        lstore(0);
-        if (nk > 1) gload(1);
-    }
+    gload(0);
+    lstore(0);
+    if (nk > 1) gload(1);
     __syncthreads();
 
-    const int w_row = BM + wn * TN * 32 + (TR ? pi32(l31) : l31);
-    const int a_off = kDma ? (wm * TM * 32 + l31) * 32 : (wm * TM * 32 + l31) * LDT + kg * 4;
-    const int w_off = kDma ? w_row * 32 : w_row * LDT + kg * 4;
-    // kDma: dword offset of logical chunk (kg | 4 lo + 2 s) inside the lane's row, by operand (the W rows of the TR layout are permuted)
-    int xa[4], xw[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        xa[c] = ((kg | (2 * c)) ^ ((l31 >> 1) & 7)) * 4;
-        xw[c] = ((kg | (2 * c)) ^ ((w_row >> 1) & 7)) * 4;
-    }
+    const int a_off = (wm * TM * 32 + l31) * LDT + kg * 4;
+    const int w_off = (BM + wn * TN * 32 + (TR ? pi32(l31) : l31)) * LDT + kg * 4;
     // TR: the W fragment is the first MFMA operand (accumulator rows <- n, lane <- m), see epilogue_tr
     // GEMM_ABLATE_* (tools/build_variant.py builds only, wrong results): what each part of the k-loop costs
     auto mma = [](half8 x, half8 w, f32x16 c) {
@@ -502,21 +464,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     //     product runs, ah / bl under the second slab's first product - into the registers the first slab has just
     //     retired (al dies after product 1, bl after product 2), so the fragment set stays at 48 VGPRs.
     // sched_barrier(0) pins that order; no condition inside the iteration, the last two k-blocks are peeled.
-    auto frag = [&](const float* base, int tile, int s, int lo, bool is_w = false) {
-        if constexpr (kDma) return *reinterpret_cast<const half8*>(base + tile * 32 * 32 + (is_w ? xw[2 * lo + s] : xa[2 * lo + s]));
-        else return *reinterpret_cast<const half8*>(base + tile * 32 * LDT + lo * 16 + s * 8);
+    auto frag = [&](const float* base, int tile, int s, int lo) {
+        return *reinterpret_cast<const half8*>(base + tile * 32 * LDT + lo * 16 + s * 8);
     };
     // mode 0: steady state (store k-block kt + 1, load kt + 2); 1: second-to-last block (store only); 2: last block (neither)
-    // neg: the A fragments enter with their sign flipped (second phase of the accumulation, see the k-loop below)
-    // sgn: 0, or 0x80008000 = the A fragments enter with their sign flipped (second phase of the accumulation, see the k-loop below);
-    // always applied (a scalar operand: one v_xor per fragment dword, 32 per k-block beside 48 MFMAs) so that the loop stays one body
-    uint32_t sgn = 0;
-    auto flip = [&](half8 v) {
-        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-        const u32x4_ m = {sgn, sgn, sgn, sgn};
-        return __builtin_bit_cast(half8, __builtin_bit_cast(u32x4_, v) ^ m);
-    };
-    constexpr bool kFlip = TERMS == 3 && SOME_GEMM_FLIP;
     auto compute_staged = [&](int buf, int kt_load, int mode) {
         const float* As = lds + buf * STAGE + a_off;
         const float* Ws = lds + buf * STAGE + w_off;
@@ -526,15 +477,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 #pragma unroll
         for (int i = 0; i < TM; ++i) al[i] = frag(As, i, 0, 1);
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn) bh[jn] = frag(Ws, jn, 0, 0, true);
+        for (int jn = 0; jn < TN; ++jn) bh[jn] = frag(Ws, jn, 0, 0);
 #pragma unroll
         for (int i = 0; i < TM; ++i) ah[i] = frag(As, i, 0, 0);
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn) bl[jn] = frag(Ws, jn, 0, 1, true);
-        if constexpr (kFlip) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) { al[i] = flip(al[i]); ah[i] = flip(ah[i]); }
-        }
+        for (int jn = 0; jn < TN; ++jn) bl[jn] = frag(Ws, jn, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
         constexpr int SLOTS = 2 * TM * TN;                       // products 1 and 2 of the first slab carry the staging
         constexpr int OPS = (NLD + SLOTS - 1) / SLOTS;
@@ -542,9 +489,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 #pragma unroll
             for (int o = 0; o < OPS; ++o) {
                 const int q = slot * OPS + o;
-                if constexpr (kDma) {
-                    if (q < NLD && mode < 2) dma_piece(buf ^ 1, kt_load, q);          // (kt_load = the NEXT k-block in this mode)
-                } else if (q < NLD && mode < 2) {
+                if (q < NLD && mode < 2) {
 #ifndef GEMM_ABLATE_NO_LDSW
                     *reinterpret_cast<f32x4*>(wbase + q * RPP * LDT) = stage[q];
 #endif
@@ -575,11 +520,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 #pragma unroll
         for (int i = 0; i < TM; ++i) al1[i] = frag(As, i, 1, 1);
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn) bh1[jn] = frag(Ws, jn, 1, 0, true);
-        if constexpr (kFlip) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) al1[i] = flip(al1[i]);
-        }
+        for (int jn = 0; jn < TN; ++jn) bh1[jn] = frag(Ws, jn, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -589,11 +530,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 #pragma unroll
         for (int i = 0; i < TM; ++i) ah1[i] = frag(As, i, 1, 0);
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn) bl1[jn] = frag(Ws, jn, 1, 1, true);
-        if constexpr (kFlip) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) ah1[i] = flip(ah1[i]);
-        }
+        for (int jn = 0; jn < TN; ++jn) bl1[jn] = frag(Ws, jn, 1, 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -612,52 +549,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 #ifdef GEMM_ABLATE_NO_LOOP
     nk = 1;                                              // one k-block: the epilogue alone (plus the prologue loads)
 #endif
-    // Sign flip of the accumulation (round 5, profiles/r05_experiments.md "the f16 matrix pipe rounds toward minus infinity"): the fp32
-    // accumulate of v_mfma_f32_32x32x16_f16 truncates toward -inf (a fraction of an ulp per instruction, but ALWAYS downward: a GEMM
-    // result carries a bias of -0.03 .. -0.05 of its rms error where the f32 MFMA carries 0.000), and over the network those biases
-    // add up to +1e-7 on every bound probability - 2.5e-4 on the fp64 cumsum the note boundaries are rounded from, 16 of 50 724
-    // boundaries moved at 32 x 30 s.  Accumulating the LAST part of the contraction NEGATED turns its truncation the other way:
-    //   k-blocks [0, kflip): acc = S1 - b1;   acc = -acc;   k-blocks [kflip, nk) with -A: acc = -S1 - S2 + b1 - b2;   result = -acc
-    // |partial sums| grow like sqrt(k), so the two biases balance at kflip ~ 0.63 nk.  Cost: 2 x 128 v_xor per workgroup tile and two
-    // v_xor per A fragment in the second phase; same products, same order - only the rounding direction of the later sums changes.
-    const int kflip = (kFlip && nk >= 8) ? (nk * 5 + 4) / 8 : nk;          // 0.625 nk (K = 512: 10 of 16; K = 2048: 40 of 64)
-    auto negate_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jn][r] = -acc[i][jn][r];
-    };
-    if constexpr (TERMS == 3) {
-        for (; kt + 2 < nk; ++kt) {
-            if (kFlip && kt == kflip) { negate_acc(); sgn = 0x80008000u; }      // once per tile (kflip <= nk - 3 whenever nk >= 8)
-            compute_staged(kt & 1, kDma ? kt + 1 : kt + 2, 0);
-            __syncthreads();
-        }
-        if (kt + 1 < nk) {
-            if constexpr (kDma) compute_staged(kt & 1, kt + 1, 0); else compute_staged(kt & 1, 0, 1);
-            __syncthreads();
-            ++kt;
-        }
-        compute_staged(kt & 1, 0, 2);
-        if (kFlip && sgn != 0) negate_acc();
-    } else {
-        for (; kt + 2 < nk; ++kt) {
+    for (; kt + 2 < nk; ++kt) {
+        if constexpr (TERMS == 3) {
+            compute_staged(kt & 1, kt + 2, 0);
+        } else {
             lstore((kt & 1) ^ 1);
             gload(kt + 2);
             __builtin_amdgcn_sched_barrier(0);
             compute(kt & 1);
-            __syncthreads();
         }
-        if (kt + 1 < nk) {
+        __syncthreads();
+    }
+    if (kt + 1 < nk) {
+        if constexpr (TERMS == 3) {
+            compute_staged(kt & 1, 0, 1);
+        } else {
             lstore((kt & 1) ^ 1);
             compute(kt & 1);
-            __syncthreads();
-            ++kt;
         }
-        compute(kt & 1);
+        __syncthreads();
+        ++kt;
     }
+    if constexpr (TERMS == 3) compute_staged(kt & 1, 0, 2);
+    else compute(kt & 1);
 
     // ---- epilogue (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
     // Interior workgroups take the unguarded path (no per-element exec masking).  Residual values are fetched one
@@ -841,7 +755,7 @@ hipError_t launch_ring(const GemmArgs& a, hipStream_t s) {
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3, bool TR = false, bool BF16 = false>
 hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * ((TERMS == 3 && SOME_GEMM_DMA) ? 32 : LDT) * sizeof(float);
+    constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LDT * sizeof(float);
     static DeviceOnce attr_once;
     auto kern = &hgemm3_kernel<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, TERMS, TR, BF16>;
     if (attr_once.need()) {

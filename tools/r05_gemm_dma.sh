@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 5: split-f16 GEMMs with LDS-DMA staging (-DSOME_GEMM_DMA=1 variant library) - correctness gates, then interleaved A/B
+# round 5: split-f16 GEMMs with LDS-DMA staging (apply tools/patches/r05_gemm_sign_flip_and_lds_dma.patch, then
+#   python tools/build_variant.py gdma gemm_f16x3.hip -DSOME_GEMM_DMA=1) - correctness gates, then interleaved A/B
 O=gpurun_out; mkdir -p $O; TAG=${1:-r05y}
 V=tools/_bin/variants/gdma/libsome_amd.so
 SOME_AMD_LIBRARY=$V timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity.py -x -q -k "gemm or forward or varlen or fullsize or packing" 2>&1 | tail -4
