@@ -723,11 +723,17 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
 #ifdef SOME_ATTN_DBG
         const bool dbg_wg = blockIdx.x == SOME_ATTN_DBG_WG;
         unsigned long long* dbg_l = reinterpret_cast<unsigned long long*>(lds + LDS_BYTES / 4);      // (the probe launches with 4 KiB more LDS)
-        if (dbg_wg && lane == 0) dbg_l[i * 8 + wave * 2] = __builtin_amdgcn_s_memtime();
+        const unsigned long long t_arr = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (timeline builds: how long the tile DMA is waited for)
+        const unsigned long long t_land = __builtin_amdgcn_s_memtime();
 #endif
         if (!(kAbl & 8)) __syncthreads();
 #ifdef SOME_ATTN_DBG
-        if (dbg_wg && lane == 0) dbg_l[i * 8 + wave * 2 + 1] = __builtin_amdgcn_s_memtime();
+        if (dbg_wg && lane == 0) {
+            const unsigned long long t_rel = __builtin_amdgcn_s_memtime();
+            dbg_l[i * 8 + wave * 2] = t_arr;
+            dbg_l[i * 8 + wave * 2 + 1] = ((t_land - t_arr) << 40) | (t_rel & 0xFFFFFFFFFFull);      // DMA wait (cycles) in the top bits
+        }
 #endif
     };
 

@@ -133,15 +133,19 @@ int main(int argc, char** argv) {
     {
         std::vector<unsigned long long> h((size_t)(n_tiles + 2) * 8);
         CK(hipMemcpy(h.data(), dbg_d, h.size() * 8, hipMemcpyDeviceToHost));
-        printf("timeline of one workgroup (cycles since its first record): tile | arrive w0..w3 | release w0..w3 | step length (release to release, w0)\n");
+        printf("timeline of one workgroup (cycles since its first record): tile | arrival at the end of the step w0..w3 | wait for the tile DMA (vmcnt 0) w0..w3 | "
+               "barrier release w0..w3 | step length (release to release, w0)\n");
         unsigned long long t0 = ~0ull;
-        for (size_t i = 0; i < h.size(); ++i) if (h[i] && h[i] < t0) t0 = h[i];
+        for (size_t i = 0; i < h.size(); i += 2) if (h[i] && h[i] < t0) t0 = h[i];
+        const unsigned long long low = 0xFFFFFFFFFFull;
         for (int t = 0; t < n_tiles; ++t) {
             printf("%3d |", t);
             for (int w = 0; w < 4; ++w) printf(" %7llu", h[(size_t)t * 8 + w * 2] ? h[(size_t)t * 8 + w * 2] - t0 : 0ull);
             printf(" |");
-            for (int w = 0; w < 4; ++w) printf(" %7llu", h[(size_t)t * 8 + w * 2 + 1] ? h[(size_t)t * 8 + w * 2 + 1] - t0 : 0ull);
-            if (t > 0) printf(" | %lld", (long long)(h[(size_t)t * 8 + 1] - h[(size_t)(t - 1) * 8 + 1]));
+            for (int w = 0; w < 4; ++w) printf(" %5llu", h[(size_t)t * 8 + w * 2 + 1] >> 40);
+            printf(" |");
+            for (int w = 0; w < 4; ++w) printf(" %7llu", (h[(size_t)t * 8 + w * 2 + 1] & low) ? (h[(size_t)t * 8 + w * 2 + 1] & low) - (t0 & low) : 0ull);
+            if (t > 0) printf(" | %lld", (long long)((h[(size_t)t * 8 + 1] & low) - (h[(size_t)(t - 1) * 8 + 1] & low)));
             printf("\n");
         }
     }
