@@ -434,6 +434,19 @@ int some_train_attention_bwd_f16x3_out16(SomeHandle* h, const float* qkv_split_d
                                          int32_t B, int32_t max_frames, int32_t M, int32_t Mp, int32_t hi_only,
                                          void* dqkv16_dev, const float* out_scale_dev, float* dsum_scratch_dev, void* stream);
 
+/* Both operand layouts of the split attention kernels in one pass over x [M, N] (N % 32 == 0): rows_split = some_op_split_rows_fmt(x),
+ * t_split [N, Mp] = some_train_transpose(x, split_out) - bit for bit. */
+int some_train_split_transpose(SomeHandle* h, const float* x_dev, int32_t M, int32_t N, float* rows_split_dev, float* t_split_dev, int32_t Mp,
+                               int32_t format, void* stream);
+/* some_train_attention_bwd_f16x3_out16 taking dO itself [M, 512] fp32: the power-of-two factor 2^floor(10 - log2 max|dO|) (f16 halves have an
+ * absolute floor of 2^-25), both split layouts of factor * dO, D = rowsum(dO O) and the 1 / factor on the way out are made on the device inside
+ * this call (5 launches, no host synchronisation).  work_dev: >= some_train_attention_bwd16_work_bytes(h, M, Mp) bytes, 256-byte aligned. */
+size_t some_train_attention_bwd16_work_bytes(const SomeHandle* h, int32_t M, int32_t Mp);
+int some_train_attention_bwd_f16x3_auto16(SomeHandle* h, const float* qkv_split_dev, const float* qkv_t_split_dev, const float* out_dev,
+                                          const float* dout_dev, const float* lse_dev, const int32_t* frame_offsets_dev, int32_t B,
+                                          int32_t max_frames, int32_t M, int32_t Mp, int32_t hi_only, void* dqkv16_dev, void* work_dev,
+                                          size_t work_bytes, void* stream);
+
 /* ---- single-operator entry points (kernel-level parity tests and micro-benchmarks) ------------------ */
 
 #define SOME_EPI_NONE 0       /* C = A W^T                                                          */

@@ -116,6 +116,10 @@ SYMBOLS = {
     'some_train_attention_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     'some_train_attention_fwd_f16x3': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     'some_train_attention_bwd_f16x3': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    'some_train_split_transpose': (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P]),
+    'some_train_attention_bwd16_work_bytes': (C.c_size_t, [_P, C.c_int32, C.c_int32]),
+    'some_train_attention_bwd_f16x3_auto16': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_size_t,
+                                                        _P]),
     'some_train_attention_bwd_f16x3_out16': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,
                                                        _P]),
     'some_op_gemm': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32,

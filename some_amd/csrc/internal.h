@@ -128,7 +128,7 @@ struct AttnBwdArgs {
     int B, max_frames, M;
 };
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s);
-hipError_t launch_attention_dsum(const float* out, const float* dout, float* dsum, int M, hipStream_t s);
+hipError_t launch_attention_dsum(const float* out, const float* dout, float* dsum, int M, hipStream_t s, const float* factor = nullptr);
 // split-f16 backward (train_attention_f16x3.hip): R / D row-major SPLIT32, Rt / Dt SPLIT32 over frames ([C, Mp])
 hipError_t launch_attention_bwd_f16x3(const float* R, const float* Rt, const float* D, const float* Dt, const float* lse, const float* dsum,
                                       const int32_t* frame_offsets, int B, int max_frames, int M, int Mp, float* dqkv, int hi_only, hipStream_t s,
@@ -230,6 +230,10 @@ hipError_t launch_reduce_slices(const float* partial, int slices, size_t n, floa
 hipError_t launch_reduce_wgrad(const float* partial, int slices, size_t stride, int M, int N, int ldc, float* dw, float* db, int accumulate,
                                hipStream_t s);
 hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, int split_out, hipStream_t s);
+// row-major SPLIT32 and transposed SPLIT32 copies of in [M, N] in one pass; prescale: both multiplied by 2^floor(10 - log2 max|in|), computed on
+// the device through absmax[256] and left as factor_out = {factor, 1 / factor}
+hipError_t launch_split_transpose(const float* in, int M, int N, float* out_rows, float* out_t, int ld_t, int bf16, int prescale,
+                                  uint32_t* absmax, float* factor_out, hipStream_t s);
 hipError_t launch_colsum(const float* x, int M, int N, int ld, float* out, int accumulate, float* scratch, hipStream_t s);
 hipError_t launch_weighted_colsum(const float* w, int ldw, const float* x, int M, int N, int ld, float* out, float* wsum, float* scratch, hipStream_t s);
 hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, void* y, float* mean, float* rstd, int M, int out16, hipStream_t s);

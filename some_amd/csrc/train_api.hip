@@ -592,4 +592,64 @@ int some_train_attention_bwd_f16x3_out16(SomeHandle* h, const float* qkv_split_d
     return SOME_OK;
 }
 
+int some_train_split_transpose(SomeHandle* h, const float* x_dev, int32_t M, int32_t N, float* rows_split_dev, float* t_split_dev, int32_t Mp,
+                               int32_t format, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M >= 0 && N >= 0 && (N % 32) == 0 && Mp >= M && (Mp % 32) == 0, "some_train_split_transpose: bad shape (N % 32, Mp % 32, Mp >= M)");
+    T_CHECK(h, format == SOME_OPERAND_F16X2 || format == SOME_OPERAND_BF16, "some_train_split_transpose: unknown operand format");
+    if (M == 0 || N == 0) return SOME_OK;
+    T_CHECK(h, x_dev && rows_split_dev && t_split_dev, "some_train_split_transpose: null pointer");
+    T_TRY(h, launch_split_transpose(x_dev, M, N, rows_split_dev, t_split_dev, Mp, format == SOME_OPERAND_BF16, 0, nullptr, nullptr, st(stream)));
+    return SOME_OK;
+}
+
+namespace {
+struct Bwd16Work { size_t d, dt, dsum, absmax, factor, total; };
+Bwd16Work bwd16_work(int M, int Mp) {
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    Bwd16Work w{};
+    w.d = 0;
+    w.dt = w.d + up((size_t)M * kDim * sizeof(float));
+    w.dsum = w.dt + up((size_t)kDim * Mp * sizeof(float));
+    w.absmax = w.dsum + up((size_t)8 * M * sizeof(float));
+    w.factor = w.absmax + up(256 * sizeof(uint32_t));
+    w.total = w.factor + 256;
+    return w;
+}
+}  // namespace
+
+size_t some_train_attention_bwd16_work_bytes(const SomeHandle* h, int32_t M, int32_t Mp) {
+    (void)h;
+    if (M <= 0 || Mp < M) return 0;
+    return bwd16_work(M, Mp).total;
+}
+
+int some_train_attention_bwd_f16x3_auto16(SomeHandle* h, const float* qkv_split_dev, const float* qkv_t_split_dev, const float* out_dev,
+                                          const float* dout_dev, const float* lse_dev, const int32_t* frame_offsets_dev, int32_t B,
+                                          int32_t max_frames, int32_t M, int32_t Mp, int32_t hi_only, void* dqkv16_dev, void* work_dev,
+                                          size_t work_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, B >= 0 && max_frames >= 0 && M >= 0, "some_train_attention_bwd_f16x3_auto16: negative size");
+    if (B == 0 || M == 0) return SOME_OK;
+    T_CHECK(h, hi_only == 1 || hi_only == 2, "some_train_attention_bwd_f16x3_auto16: mixed precision only (hi_only 1 = f16, 2 = bf16: also the output format)");
+    T_CHECK(h, Mp >= M && (Mp % 32) == 0, "some_train_attention_bwd_f16x3_auto16: Mp must be M rounded up to a multiple of 32");
+    T_CHECK(h, qkv_split_dev && qkv_t_split_dev && out_dev && dout_dev && lse_dev && frame_offsets_dev && dqkv16_dev && work_dev,
+            "some_train_attention_bwd_f16x3_auto16: null pointer");
+    T_CHECK(h, (reinterpret_cast<uintptr_t>(dqkv16_dev) & 7) == 0 && (reinterpret_cast<uintptr_t>(work_dev) & 255) == 0,
+            "some_train_attention_bwd_f16x3_auto16: dqkv16 must be 8-byte, the work area 256-byte aligned");
+    const Bwd16Work w = bwd16_work(M, Mp);
+    T_CHECK(h, work_bytes >= w.total, "some_train_attention_bwd_f16x3_auto16: work area smaller than some_train_attention_bwd16_work_bytes");
+    char* base = static_cast<char*>(work_dev);
+    float* D = reinterpret_cast<float*>(base + w.d);
+    float* Dt = reinterpret_cast<float*>(base + w.dt);
+    float* dsum = reinterpret_cast<float*>(base + w.dsum);
+    uint32_t* absmax = reinterpret_cast<uint32_t*>(base + w.absmax);
+    float* factor = reinterpret_cast<float*>(base + w.factor);
+    T_TRY(h, launch_split_transpose(dout_dev, M, kDim, D, Dt, Mp, hi_only == 2, 1, absmax, factor, st(stream)));
+    T_TRY(h, launch_attention_dsum(out_dev, dout_dev, dsum, M, st(stream), factor));
+    T_TRY(h, launch_attention_bwd_f16x3(qkv_split_dev, qkv_t_split_dev, D, Dt, lse_dev, dsum, frame_offsets_dev, B, max_frames, M, Mp, nullptr, hi_only,
+                                        st(stream), dqkv16_dev, factor + 1, hi_only));
+    return SOME_OK;
+}
+
 }  // extern "C"

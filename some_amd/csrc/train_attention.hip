@@ -22,8 +22,10 @@ constexpr float kScale2 = 0.125f * 1.4426950408889634f;
 __device__ __forceinline__ float exp2_(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ int krow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }   // C/D row of register r
 
-// D[h][m] = sum_d dO[m, 64 h + d] O[m, 64 h + d]: one wave per row, 8 lanes per head
-__global__ __launch_bounds__(256) void attn_dsum_kernel(const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ dsum, int M) {
+// D[h][m] = sum_d dO[m, 64 h + d] O[m, 64 h + d]: one wave per row, 8 lanes per head.  factor (optional, a power of two on the device: the
+// one the split dO operands were multiplied by, train_ops.hip split_transpose_kernel) scales the sums - exactly what summing factor * dO gives.
+__global__ __launch_bounds__(256) void attn_dsum_kernel(const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ dsum, int M,
+                                                        const float* __restrict__ factor) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(out + (size_t)row * kDim + lane * 8);
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(256) void attn_dsum_kernel(const float* __restrict_
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 4, 64);
+    if (factor) s *= factor[0];
     if ((lane & 7) == 0) dsum[(size_t)(lane >> 3) * M + row] = s;
 }
 
@@ -330,9 +333,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs a, int 
 
 }  // namespace
 
-hipError_t launch_attention_dsum(const float* out, const float* dout, float* dsum, int M, hipStream_t s) {
+hipError_t launch_attention_dsum(const float* out, const float* dout, float* dsum, int M, hipStream_t s, const float* factor) {
     if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, out, dout, dsum, M);
+    hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, out, dout, dsum, M, factor);
     return hipGetLastError();
 }
 
@@ -347,7 +350,7 @@ hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_once.mark();
     }
-    hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, s, a.out, a.dout, a.dsum, a.M);
+    hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, s, a.out, a.dout, a.dsum, a.M, nullptr);
     const int units = a.B * kHeads, slots = (units + 7) / 8;
     const int nkb = (a.max_frames + 127) / 128, nqb = (a.max_frames + QB - 1) / QB;
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(slots * nkb * 8)), dim3(256), DKV_LDS_BYTES, s, a, nkb);

@@ -59,6 +59,87 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// ---- attention operand preparation: row-split AND transposed-split copies of one fp32 matrix in one pass -------------------------
+// The split-f16 attention kernels read every operand twice - row-major SPLIT32 (split.h) and transposed SPLIT32 - and, in the
+// backward pass, dO first multiplied by the power of two that brings its largest element to [2^9, 2^10] (f16 halves have an absolute
+// floor of 2^-25).  absmax_partial_kernel leaves 256 per-workgroup maxima of |x| (as bit patterns: order-independent, deterministic);
+// split_transpose_kernel derives the factor from them in every workgroup (256 values, one per thread), writes both layouts from
+// one 32 x 32 LDS tile and leaves {factor, 1 / factor} for the kernels behind it.
+constexpr int kAbsmaxBlocks = 256;
+
+__global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __restrict__ x, int64_t n4, uint32_t* __restrict__ partial) {
+    __shared__ uint32_t red[4];
+    uint32_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)kAbsmaxBlocks * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = max(m, __float_as_uint(v[j]) & 0x7fffffffu);      // NaN / inf order above every finite value
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
+// 2^floor(10 - log2(max(a, 1e-30))) for a = |x|max given as its bit pattern, in integer arithmetic (exact); NaN when x held inf / NaN
+__device__ __forceinline__ float pow2_factor(uint32_t bits, float& inv) {
+    if (bits >= 0x7f800000u) { inv = __uint_as_float(0x7fc00000u); return inv; }
+    if (__uint_as_float(bits) < 1e-30f) bits = __float_as_uint(1e-30f);
+    const int e = (int)(bits >> 23) - 127;
+    const int k = (bits & 0x7fffffu) ? 9 - e : 10 - e;                 // e in [-100, 127]: 2^k and 2^-k are normal numbers
+    inv = __uint_as_float((uint32_t)(127 - k) << 23);
+    return __uint_as_float((uint32_t)(127 + k) << 23);
+}
+
+template <int SPLIT>      // 1: f16 hi + lo, 2: bf16 hi, zero lo (as transpose_kernel)
+__global__ __launch_bounds__(256) void split_transpose_kernel(const float* __restrict__ in, int M, int N, float* __restrict__ out_rows,
+                                                               float* __restrict__ out_t, int ld_t, const uint32_t* __restrict__ absmax,
+                                                               float* __restrict__ factor_out) {
+    __shared__ float tile[32][33];
+    __shared__ uint32_t red[4];
+    float factor = 1.f;
+    if (absmax) {
+        uint32_t m = absmax[threadIdx.x];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        float inv;
+        factor = pow2_factor(max(max(red[0], red[1]), max(red[2], red[3])), inv);
+        if (factor_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { factor_out[0] = factor; factor_out[1] = inv; }
+    }
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty + 8 * i, n = n0 + tx;                  // N % 32 == 0: n < N
+        float v = 0.f;
+        if (m < M) {
+            v = in[(size_t)m * N + n] * factor;
+            half_t h, l;
+            if (SPLIT == 2) { h = bf16_as_half(v); l = (half_t)0.f; }
+            else split_f16(v, h, l);
+            half_t* blk = reinterpret_cast<half_t*>(out_rows + (size_t)m * N + n0);      // k-block n0 / 32 of row m: [32 hi | 32 lo]
+            blk[tx] = h;
+            blk[32 + tx] = l;
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i;
+        const float v = tile[tx][ty + 8 * i];                        // zeros beyond M
+        half_t h, l;
+        if (SPLIT == 2) { h = bf16_as_half(v); l = (half_t)0.f; }
+        else split_f16(v, h, l);
+        half_t* blk = reinterpret_cast<half_t*>(out_t + (size_t)n * ld_t + m0);
+        blk[tx] = h;
+        blk[32 + tx] = l;
+    }
+}
+
 // ---- column reductions: partial[p][2][N] over row chunk p, then an ordered final sum -----------------------------
 constexpr int kChunkRows = 128;      // 162 row chunks x N / 64 column groups at 8 x 2584 frames: enough workgroups to keep HBM busy (512: 1.9 TB/s)
 
@@ -767,6 +848,18 @@ hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out
     if (split_out == 2) hipLaunchKernelGGL(transpose_kernel<2>, grid, dim3(256), 0, s, in, M, N, ld_in, out, ld_out);
     else if (split_out) hipLaunchKernelGGL(transpose_kernel<1>, grid, dim3(256), 0, s, in, M, N, ld_in, out, ld_out);
     else hipLaunchKernelGGL(transpose_kernel<0>, grid, dim3(256), 0, s, in, M, N, ld_in, out, ld_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_transpose(const float* in, int M, int N, float* out_rows, float* out_t, int ld_t, int bf16, int prescale,
+                                  uint32_t* absmax, float* factor_out, hipStream_t s) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    if ((N & 31) || (ld_t & 31) || ld_t < M || (prescale && !absmax)) return hipErrorInvalidValue;
+    if (prescale) hipLaunchKernelGGL(absmax_partial_kernel, dim3(kAbsmaxBlocks), dim3(256), 0, s, in, (int64_t)M * N / 4, absmax);
+    const uint32_t* am = prescale ? absmax : nullptr;
+    dim3 grid((unsigned)(ld_t / 32), (unsigned)(N / 32));
+    if (bf16) hipLaunchKernelGGL(split_transpose_kernel<2>, grid, dim3(256), 0, s, in, M, N, out_rows, out_t, ld_t, am, factor_out);
+    else hipLaunchKernelGGL(split_transpose_kernel<1>, grid, dim3(256), 0, s, in, M, N, out_rows, out_t, ld_t, am, factor_out);
     return hipGetLastError();
 }
 

@@ -105,6 +105,7 @@ class TrainableMidiConforms:
         self._calls = 0
         self._shadow_list = None
         self._block_cache = {}
+        self._tracked = []                          # num_batches_tracked buffers of the blocks run in this pass
 
     # ---- dropout: one independent (seed, counter) stream per call site and step; fused into the neighbouring pass --------
     def _drop(self, kind: str):
@@ -163,8 +164,7 @@ class TrainableMidiConforms:
         x = self._ffn_block(x, bp['ffn1'])
         x = o.attention_block(x, *bp['att'], batch, *self._drop('attention'))
         x = o.conv_block(x, *bp['conv'], batch, *self._drop('conv'))
-        with torch.no_grad():
-            bp['tracked'].add_(1)
+        self._tracked.append(bp['tracked'])
         x = self._ffn_block(x, bp['ffn2'])
         return o.layernorm(x, *bp['ln5'])
 
@@ -194,6 +194,9 @@ class TrainableMidiConforms:
         x = self._block(x, 'model.att1', batch)
         with o.lane(1, after=fork):
             x1 = self._block(x1, 'model.att2', batch)
+        with torch.no_grad():
+            torch._foreach_add_(self._tracked, 1)          # BatchNorm's num_batches_tracked of every block: one launch
+        self._tracked.clear()
         midi = o.linear(x, P['model.outln.weight'], P['model.outln.bias'])
         bound = o.reshape(o.sigmoid(o.linear(x1, P['model.cutheard.weight'], P['model.cutheard.bias'])), -1)
         return midi, bound

@@ -36,6 +36,7 @@ class TrainOps:
         # the same order as the call-by-call path, bit-identical) - the step is bound by the host's enqueue path at the reference's batch
         # shape.  SOME_AMD_TRAIN_BLOCK_CALLS=0: the call-by-call path (A/B runs, and the reference for the bit-identity test).
         self.block_calls = os.environ.get('SOME_AMD_TRAIN_BLOCK_CALLS', '1') != '0'
+        self.device_prep = os.environ.get('SOME_AMD_TRAIN_DEVICE_PREP', '1') != '0'    # 0: round 4's torch-side operand preparation (A / B runs)
         # Two LANES (trainer's tape only): the midi and the bound stream of a Gcf layer are independent between the cross gates
         # (Gconform.py:82-87), forward and backward, so the model issues the bound stream's block on lane 1 = a second HIP stream.
         # At the reference's batch shape (8 phrases, ~4 100 frames) a step is ~860 launches of 5 - 35 us, most of them far from filling
@@ -348,6 +349,15 @@ class TrainOps:
         fmt = _lib.OPERAND_BF16 if self._hi_mode == 2 else _lib.OPERAND_F16X2          # bf16 mode: hi slot = bf16(x), lo = 0
         self.check(self.lib.some_op_split_rows_fmt(self.h, _p(x), _p(out), x.shape[0], x.shape[1], fmt, self.stream()))
         return out
+
+    def split_transpose(self, x: torch.Tensor, pad_to: int = 64):
+        """(split_rows(x), transpose(x, pad_to, split=True)) from one pass over x [M, N] - the two operand layouts of the split attention kernels."""
+        M, N = x.shape
+        Mp = (M + pad_to - 1) // pad_to * pad_to
+        rows, t = torch.empty_like(x), self.new(N, Mp)
+        fmt = _lib.OPERAND_BF16 if self._hi_mode == 2 else _lib.OPERAND_F16X2
+        self.check(self.lib.some_train_split_transpose(self.h, _p(x), M, N, _p(rows), _p(t), Mp, fmt, self.stream()))
+        return rows, t
 
     @staticmethod
     def _tile(M: int, N: int) -> int:
@@ -1288,7 +1298,7 @@ class _Attention(torch.autograd.Function):
         out, lse = ops.new(M, 512), ops.new(8, M)
         ctx.ops, ctx.batch, ctx.prec = ops, batch, ops.attention_precision
         if ctx.prec == 'f16x3':
-            R, Rt = ops.split_rows(qkv), ops.transpose(qkv, pad_to=64, split=True)
+            R, Rt = ops.split_transpose(qkv, pad_to=64) if ops.device_prep else (ops.split_rows(qkv), ops.transpose(qkv, pad_to=64, split=True))
             ops.check(ops.lib.some_train_attention_fwd_f16x3(ops.h, _p(R), _p(Rt), _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M,
                                                              Rt.shape[1], ops._hi_mode, _p(out), _p(lse), ops.stream()))
             ctx.save_for_backward(R, Rt, out, lse)
@@ -1329,14 +1339,21 @@ def _attention_bwd16(ctx, dout):
     dout = dout.contiguous()
     M = dout.shape[0]
     R, Rt, out, lse = ctx.saved_tensors
-    dqkv16, dsum = torch.empty((M, 1536), dtype=ops.dtype16, device=ops.device), ops.new(8, M)
-    scale = torch.exp2(torch.floor(10.0 - torch.log2(dout.abs().amax().clamp_min(1e-30))))     # as in _Attention.backward
-    dout = dout * scale
-    inv = torch.reciprocal(scale).reshape(1)
-    D, Dt = ops.split_rows(dout), ops.transpose(dout, pad_to=64, split=True)
-    ops.check(ops.lib.some_train_attention_bwd_f16x3_out16(ops.h, _p(R), _p(Rt), _p(D), _p(Dt), _p(out), _p(dout), _p(lse), _p(batch.frame_offsets_dev),
-                                                           batch.B, batch.max_frames, M, Rt.shape[1], ops._hi_mode, _p(dqkv16), _p(inv), _p(dsum),
-                                                           ops.stream()))
+    dqkv16 = torch.empty((M, 1536), dtype=ops.dtype16, device=ops.device)
+    # dO is carried as 16-bit halves: its power-of-two factor (as in _Attention.backward), both split layouts, rowsum(dO O) and the 1 / factor
+    # on the way out are made on the device inside the one call
+    Mp = Rt.shape[1]
+    if not ops.device_prep:
+        scale = torch.exp2(torch.floor(10.0 - torch.log2(dout.abs().amax().clamp_min(1e-30))))
+        dout = dout * scale
+        inv, dsum = torch.reciprocal(scale).reshape(1), ops.new(8, M)
+        D, Dt = ops.split_rows(dout), ops.transpose(dout, pad_to=64, split=True)
+        ops.check(ops.lib.some_train_attention_bwd_f16x3_out16(ops.h, _p(R), _p(Rt), _p(D), _p(Dt), _p(out), _p(dout), _p(lse), _p(batch.frame_offsets_dev),
+                                                               batch.B, batch.max_frames, M, Mp, ops._hi_mode, _p(dqkv16), _p(inv), _p(dsum), ops.stream()))
+        return dqkv16
+    work = torch.empty(ops._bytes('some_train_attention_bwd16_work_bytes', M, Mp), dtype=torch.uint8, device=ops.device)
+    ops.check(ops.lib.some_train_attention_bwd_f16x3_auto16(ops.h, _p(R), _p(Rt), _p(out), _p(dout), _p(lse), _p(batch.frame_offsets_dev), batch.B,
+                                                            batch.max_frames, M, Mp, ops._hi_mode, _p(dqkv16), _p(work), work.numel(), ops.stream()))
     return dqkv16
 
 

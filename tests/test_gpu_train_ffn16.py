@@ -380,3 +380,80 @@ def test_gemm16s_tiles_are_bit_identical(ops, epi, monkeypatch):
         torch.cuda.synchronize()
         outs.append(out)
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+@pytest.mark.parametrize('M,N', [(1000, 1536), (4160, 512), (33, 512)])
+def test_split_transpose_equals_split_rows_and_transpose(ops, operand, M, N):
+    """One pass over x writes the bits the two separate passes write (row-major SPLIT32 and transposed SPLIT32 with zero padding)."""
+    ops.set_mixed_precision(True, operand)
+    try:
+        x = _rand(M, N, seed=5)
+        rows, t = ops.split_transpose(x, pad_to=64)
+        assert torch.equal(rows.view(torch.int32), ops.split_rows(x).view(torch.int32))
+        assert torch.equal(t.view(torch.int32), ops.transpose(x, pad_to=64, split=True).view(torch.int32))
+    finally:
+        ops.set_mixed_precision(False)
+
+
+@pytest.mark.parametrize('operand', ['bf16', 'f16'])
+@pytest.mark.parametrize('magnitude', [1.0, 3e-6, 2.0 ** -7, 0.0])
+def test_attention_backward_with_the_device_side_factor_equals_the_host_formula(ops, operand, magnitude):
+    """some_train_attention_bwd_f16x3_auto16 (factor, split layouts, row sums and 1 / factor made inside the call) against the same kernels
+    driven by torch's exp2(floor(10 - log2(max|dO|))): identical 16-bit gradients.  2^-7: max|dO| an exact power of two."""
+    from some_amd.engine import ClipBatch
+    from some_amd.training.ops import _p
+    lens = [300, 257, 64]
+    batch, M = ClipBatch(lens, 'cuda'), sum(lens)
+    ops.set_mixed_precision(True, operand)
+    try:
+        qkv = _rand(M, 1536, seed=11)
+        R, Rt = ops.split_transpose(qkv, pad_to=64)
+        Mp = Rt.shape[1]
+        out, lse = ops.new(M, 512), ops.new(8, M)
+        ops.check(ops.lib.some_train_attention_fwd_f16x3(ops.h, _p(R), _p(Rt), _p(batch.frame_offsets_dev), batch.B, batch.max_frames, M, Mp, ops._hi_mode,
+                                                         _p(out), _p(lse), ops.stream()))
+        dout = _rand(M, 512, seed=12).clamp_(-4, 4) / 4 * magnitude
+        if magnitude:
+            dout[5, 7] = magnitude                                   # the largest element, exactly
+        got = torch.empty((M, 1536), dtype=ops.dtype16, device='cuda')
+        work = torch.empty(int(ops.lib.some_train_attention_bwd16_work_bytes(ops.h, M, Mp)), dtype=torch.uint8, device='cuda')
+        ops.check(ops.lib.some_train_attention_bwd_f16x3_auto16(ops.h, _p(R), _p(Rt), _p(out), _p(dout), _p(lse), _p(batch.frame_offsets_dev), batch.B,
+                                                                batch.max_frames, M, Mp, ops._hi_mode, _p(got), _p(work), work.numel(), ops.stream()))
+        scale = torch.exp2(torch.floor(10.0 - torch.log2(dout.abs().amax().clamp_min(1e-30))))
+        ds = dout * scale
+        inv = torch.reciprocal(scale).reshape(1)
+        D, Dt = ops.split_rows(ds), ops.transpose(ds, pad_to=64, split=True)
+        want, dsum = torch.empty_like(got), ops.new(8, M)
+        ops.check(ops.lib.some_train_attention_bwd_f16x3_out16(ops.h, _p(R), _p(Rt), _p(D), _p(Dt), _p(out), _p(ds), _p(lse), _p(batch.frame_offsets_dev),
+                                                               batch.B, batch.max_frames, M, Mp, ops._hi_mode, _p(want), _p(inv), _p(dsum), ops.stream()))
+        torch.cuda.synchronize()
+        assert torch.isfinite(got.float()).all()
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+        if magnitude:
+            assert float(got.float().abs().max()) > 0
+    finally:
+        ops.set_mixed_precision(False)
+
+
+def test_attention_backward_poisons_the_gradient_when_dO_is_not_finite(ops):
+    from some_amd.engine import ClipBatch
+    from some_amd.training.ops import _p
+    batch, M = ClipBatch([96], 'cuda'), 96
+    ops.set_mixed_precision(True, 'bf16')
+    try:
+        qkv = _rand(M, 1536, seed=11)
+        R, Rt = ops.split_transpose(qkv, pad_to=64)
+        Mp = Rt.shape[1]
+        out, lse = ops.new(M, 512), ops.new(8, M)
+        ops.check(ops.lib.some_train_attention_fwd_f16x3(ops.h, _p(R), _p(Rt), _p(batch.frame_offsets_dev), 1, M, M, Mp, ops._hi_mode, _p(out), _p(lse),
+                                                         ops.stream()))
+        dout = _rand(M, 512, seed=12)
+        dout[3, 3] = float('inf')
+        got = torch.empty((M, 1536), dtype=ops.dtype16, device='cuda')
+        work = torch.empty(int(ops.lib.some_train_attention_bwd16_work_bytes(ops.h, M, Mp)), dtype=torch.uint8, device='cuda')
+        ops.check(ops.lib.some_train_attention_bwd_f16x3_auto16(ops.h, _p(R), _p(Rt), _p(out), _p(dout), _p(lse), _p(batch.frame_offsets_dev), 1, M, M, Mp,
+                                                                ops._hi_mode, _p(got), _p(work), work.numel(), ops.stream()))
+        assert not torch.isfinite(got.float()).all()                  # the trainer's non-finite check sees it (task.py)
+    finally:
+        ops.set_mixed_precision(False)
