@@ -10,8 +10,10 @@ Parity pin: every function below is checked by ``tests/test_oracle_golden.py`` a
 of its own; the only textual known-answer, the commented example at
 ``utils/infer_utils.py:103-113``, is included in the goldens.  Third-party arithmetic the reference imports
 but does not vendor (``librosa.filters.mel``; pinned ``librosa<0.10.0`` in ``requirements.txt:10``) is
-restated from its published algorithm and is "parity unpinned" by the reference itself (no test there
-asserts its values); see ``mel_filterbank``.
+restated from its published algorithm; the reference itself has no test that asserts its values, so it is pinned
+to an independent third-party implementation instead (``transformers.audio_utils.mel_filter_bank``, written to
+reproduce librosa: same support, every weight within one fp32 ulp - ``tests/test_oracle_golden.py``); see
+``mel_filterbank``.
 
 Arithmetic: fp32 torch-CPU ops for the network (same ATen kernels the reference's CPU path runs),
 explicit sequential numpy for the integer/decode logic so results are machine independent.
@@ -43,7 +45,9 @@ def mel_filterbank(sr=44100, n_fft=2048, n_mels=80, fmin=40.0, fmax=8000.0) -> n
     ``fftfreqs = linspace(0, sr/2, 1+n_fft/2)``, each band scaled by ``2/(f[i+2]-f[i])`` (Slaney area
     normalisation).  The two fp32 roundings of librosa's own code (row assignment into a float32 array, then the
     in-place scale) are reproduced, so the basis is librosa's bit for bit as far as its published source goes;
-    librosa itself is absent here, so this stays "parity unpinned".
+    librosa itself is absent here; the independent pin is ``transformers.audio_utils.mel_filter_bank(norm='slaney',
+    mel_scale='htk')`` (an fp64 re-implementation of the same published filters): identical support, 193 of 82 000 weights
+    one fp32 ulp apart (``test_mel_filterbank_equals_an_independent_librosa_compatible_implementation``).
     """
     if fmax is None:
         fmax = sr / 2.0
