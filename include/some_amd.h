@@ -285,6 +285,23 @@ int some_train_dropcast16(SomeHandle* h, const float* d_dev, void* y16_dev, int3
 int some_train_gemm16_wgrad16(SomeHandle* h, const void* dY16_dev, int32_t ldy, const void* X16_dev, int32_t ldx, float* dW_dev, float* db_dev,
                               int32_t N, int32_t K, int32_t frames, int32_t operand, int32_t accumulate, void* partial_dev, size_t partial_bytes,
                               void* stream);
+/* Weight-gradient lanes (round 5).  Nothing downstream in a backward pass reads a weight gradient, yet on one stream every split-K
+ * weight-gradient GEMM + reduction (64 + 73 launches per step at the reference's batch shape, configs/base.yaml:55-56) sits in the
+ * dependent chain of the data gradients.  After some_train_set_wgrad_stream(h, stream, wgrad_stream) the launches of
+ * some_train_gemm16_wgrad / some_train_gemm16_wgrad16 (also those inside some_train_ffn_block_bwd) that are issued on `stream` run on
+ * `wgrad_stream` instead, behind an event recorded on `stream` at the call (their operands were produced there).  Same kernels, same
+ * summation order: the gradients are bit-identical.  The CALLER then owns three orderings: (1) whatever reads the gradient arrays
+ * (gradient norm, optimiser, an all-reduce) must wait for `wgrad_stream`; (2) dY / X, the save / scratch blocks of the block call and
+ * partial_dev must stay untouched until `wgrad_stream` has passed the call - partial_dev may be shared by the calls of ONE wgrad_stream
+ * (they serialise there) but not with calls that stay on `stream`; (3) writers of the same gradient array must use the same pair.
+ * defer_reductions != 0: the reduction behind each weight-gradient GEMM (planes -> dW / db) is not launched with it but waits until
+ * some_train_wgrad_flush(h, stream) - which the caller issues BEFORE it orders a reader behind `wgrad_stream` - and then goes out with
+ * the pair's other waiting reductions in ONE launch (up to 32 per launch; 73 launches per step become 4); every call then needs planes of
+ * its own until the flush (a partial_dev that overlaps waiting planes, or an output that overlaps a waiting output, flushes first: correct,
+ * but nothing is saved).  wgrad_stream = NULL flushes and removes the pairing of `stream`.  Not thread-safe against concurrent training
+ * calls on the same handle. */
+int some_train_set_wgrad_stream(SomeHandle* h, void* stream, void* wgrad_stream, int32_t defer_reductions);
+int some_train_wgrad_flush(SomeHandle* h, void* stream);
 /* out[n, m] = in[m, n] for m < M, 0 for M <= m < ld_out (the zero padding makes ld_out a valid contraction length).
  * split_out = 1: rows are written in SPLIT32 format (ready as a split-f16 GEMM operand; ld_out % 32 == 0);
  * split_out = 2: the same slots with bf16 hi halves (SOME_OPERAND_BF16). */

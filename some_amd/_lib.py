@@ -94,6 +94,8 @@ SYMBOLS = {
     'some_train_layernorm_bwd_add': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
     'some_train_gemm16_wgrad16': (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
                                             C.c_size_t, _P]),
+    'some_train_set_wgrad_stream': (C.c_int, [_P, _P, _P, C.c_int32]),
+    'some_train_wgrad_flush': (C.c_int, [_P, _P]),
     'some_train_weighted_colsum': (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_size_t, _P]),
     'some_train_colsum': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P]),
     'some_train_layernorm_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),

@@ -271,6 +271,7 @@ void some_destroy(SomeHandle* h) {
     for (auto& a : h->aux_sets) { (void)hipStreamDestroy(a.aux); (void)hipEventDestroy(a.fork); (void)hipEventDestroy(a.join); }
     for (auto& r : h->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
+    for (auto& l : h->wgrad_lanes) (void)hipEventDestroy(l.ev);
     delete h;
 }
 

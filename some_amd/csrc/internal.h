@@ -227,6 +227,11 @@ size_t train_col_scratch_bytes(int M, int N);
 size_t train_ln_scratch_bytes(int M);
 size_t train_dwconv_w_scratch_bytes(int M, int C);
 hipError_t launch_reduce_slices(const float* partial, int slices, size_t n, float* out, hipStream_t s);
+// One reduction of weight-gradient planes, as launch_reduce_wgrad's arguments; launch_reduce_wgrad_table runs up to kWgradTable of them
+// in ONE launch (same per-element summation order: bit-identical to one launch_reduce_wgrad each).  The entries must not share outputs.
+struct WgradReduce { const float* partial; float* dw; float* db; size_t stride; int slices, M, N, ldc, accumulate; };
+constexpr int kWgradTable = 32;
+hipError_t launch_reduce_wgrad_table(const WgradReduce* entries, int n, hipStream_t s);
 hipError_t launch_reduce_wgrad(const float* partial, int slices, size_t stride, int M, int N, int ldc, float* dw, float* db, int accumulate,
                                hipStream_t s);
 hipError_t launch_transpose(const float* in, int M, int N, int ld_in, float* out, int ld_out, int split_out, hipStream_t s);
@@ -297,6 +302,12 @@ struct SomeHandle {
     std::mutex fwd_mu;
     std::vector<ProfRecord> prof;
     std::vector<hipEvent_t> event_pool;
+    // training: weight-gradient lanes (some_train_set_wgrad_stream) - the split-K weight-gradient GEMM + its reduction issued on `lane`
+    // run on `side` behind an event of `lane`: they leave the backward pass's dependent chain (nothing downstream reads a weight gradient)
+    // defer: the reductions of the planes wait in `pending` until some_train_wgrad_flush (or a full table / a clash of buffers) and
+    // go out in one launch
+    struct WgradLane { hipStream_t lane; hipStream_t side; hipEvent_t ev; bool defer; std::vector<WgradReduce> pending; };
+    std::vector<WgradLane> wgrad_lanes;
     // window + twiddles of the key-shifted front end, one entry per (n_fft', win') seen
     struct ShiftTables { int n_fft, win; void* blob; float* window; double* twiddle; };
     std::vector<ShiftTables> shift_tables;

@@ -21,7 +21,57 @@ int tfail(SomeHandle* h, int code, const char* msg) {
     do { if (!(cond)) return tfail((h), SOME_EINVAL, msg); } while (0)
 
 inline hipStream_t st(void* s) { return static_cast<hipStream_t>(s); }
-inline size_t chunks(int64_t M) { return (size_t)((M + 511) / 512); }
+
+// Weight-gradient lanes (some_train_set_wgrad_stream).  wgrad_begin: the stream a weight-gradient GEMM issued on `s` runs on - `s` itself,
+// or the side stream paired with it, made to wait for everything enqueued on `s` so far (the operands dY / X were produced there; one
+// event per pair is enough: hipStreamWaitEvent captures the record it follows).  With deferred reductions the GEMM about to be launched
+// must not write planes a waiting reduction still has to read, and no two waiting reductions may share an output: such a clash (a
+// caller that reuses one partial buffer, a weight used twice) flushes what waits first - on the same side stream, so in order.
+SomeHandle::WgradLane* wgrad_lane_of(SomeHandle* h, hipStream_t s) {
+    for (auto& l : h->wgrad_lanes) if (l.lane == s) return &l;
+    return nullptr;
+}
+
+hipError_t wgrad_flush(SomeHandle::WgradLane* l) {
+    if (!l || l->pending.empty()) return hipSuccess;
+    const hipError_t e = launch_reduce_wgrad_table(l->pending.data(), (int)l->pending.size(), l->side);
+    l->pending.clear();
+    return e;
+}
+
+inline bool overlap(const void* a, size_t na, const void* b, size_t nb) {
+    const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
+    return x < y + nb && y < x + na;
+}
+
+hipError_t wgrad_begin(SomeHandle* h, hipStream_t s, const WgradReduce& next, hipStream_t* out, SomeHandle::WgradLane** lane) {
+    *out = s;
+    SomeHandle::WgradLane* l = *lane = wgrad_lane_of(h, s);
+    if (!l) return hipSuccess;
+    hipError_t e = hipEventRecord(l->ev, s);
+    if (e != hipSuccess) return e;
+    e = hipStreamWaitEvent(l->side, l->ev, 0);
+    if (e != hipSuccess) return e;
+    *out = l->side;
+    const size_t plane_bytes = (size_t)next.slices * next.stride * sizeof(float), dw_bytes = (size_t)next.M * next.N * sizeof(float);
+    bool clash = (int)l->pending.size() >= kWgradTable;
+    for (const WgradReduce& r : l->pending) {
+        if (clash) break;
+        clash = overlap(r.partial, (size_t)r.slices * r.stride * sizeof(float), next.partial, plane_bytes) ||
+                overlap(r.dw, (size_t)r.M * r.N * sizeof(float), next.dw, dw_bytes) ||
+                (r.db && next.db && overlap(r.db, (size_t)r.M * sizeof(float), next.db, (size_t)next.M * sizeof(float)));
+    }
+    return clash ? wgrad_flush(l) : hipSuccess;
+}
+
+// behind the GEMM: the reduction of its planes - now, or with the lane's other waiting reductions in one launch later
+hipError_t wgrad_reduce(SomeHandle::WgradLane* l, const WgradReduce& r, hipStream_t ws) {
+    if (l && l->defer) {
+        l->pending.push_back(r);
+        return hipSuccess;
+    }
+    return launch_reduce_wgrad(r.partial, r.slices, r.stride, r.M, r.N, r.ldc, r.dw, r.db, r.accumulate, ws);
+}
 
 }  // namespace
 
@@ -128,8 +178,37 @@ int some_train_gemm16_wgrad(SomeHandle* h, const float* dY_dev, int32_t ldy, con
     const int slices = gemm16_slices(N, K, frames, operand);
     T_CHECK(h, partial_bytes >= (size_t)slices * (size_t)N * ldc * sizeof(float), "some_train_gemm16_wgrad: partial buffer too small (some_train_gemm16_bytes(N, K, frames, K + 4))");
     float* planes = static_cast<float*>(partial_dev);
-    T_TRY(h, launch_gemm16(dY_dev, ldy, 1, X_dev, ldx, 1, nullptr, planes, ldc, N, K, frames, operand, slices, (size_t)N * ldc, db_dev ? K : -1, st(stream)));
-    T_TRY(h, launch_reduce_wgrad(planes, slices, (size_t)N * ldc, N, K, ldc, dW_dev, db_dev, accumulate, st(stream)));
+    const WgradReduce red{planes, dW_dev, db_dev, (size_t)N * ldc, slices, N, K, ldc, accumulate};
+    hipStream_t ws;
+    SomeHandle::WgradLane* wl;
+    T_TRY(h, wgrad_begin(h, st(stream), red, &ws, &wl));
+    T_TRY(h, launch_gemm16(dY_dev, ldy, 1, X_dev, ldx, 1, nullptr, planes, ldc, N, K, frames, operand, slices, (size_t)N * ldc, db_dev ? K : -1, ws));
+    T_TRY(h, wgrad_reduce(wl, red, ws));
+    return SOME_OK;
+}
+
+int some_train_set_wgrad_stream(SomeHandle* h, void* stream, void* wgrad_stream, int32_t defer_reductions) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, stream != wgrad_stream || !wgrad_stream, "some_train_set_wgrad_stream: the weight-gradient stream must differ from the stream it serves");
+    for (size_t i = 0; i < h->wgrad_lanes.size(); ++i) {
+        SomeHandle::WgradLane& l = h->wgrad_lanes[i];
+        if (l.lane != st(stream)) continue;
+        T_TRY(h, wgrad_flush(&l));                    // what waits goes out on the stream it was computed on
+        if (wgrad_stream) { l.side = st(wgrad_stream); l.defer = defer_reductions != 0; return SOME_OK; }
+        (void)hipEventDestroy(l.ev);
+        h->wgrad_lanes.erase(h->wgrad_lanes.begin() + (long)i);
+        return SOME_OK;
+    }
+    if (!wgrad_stream) return SOME_OK;
+    SomeHandle::WgradLane l{st(stream), st(wgrad_stream), nullptr, defer_reductions != 0, {}};
+    T_TRY(h, hipEventCreateWithFlags(&l.ev, hipEventDisableTiming));
+    h->wgrad_lanes.push_back(l);
+    return SOME_OK;
+}
+
+int some_train_wgrad_flush(SomeHandle* h, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_TRY(h, wgrad_flush(wgrad_lane_of(h, st(stream))));
     return SOME_OK;
 }
 
@@ -229,9 +308,13 @@ int some_train_gemm16_wgrad16(SomeHandle* h, const void* dY16_dev, int32_t ldy, 
     const int slices = gemm16_slices(N, K, frames, operand);
     T_CHECK(h, partial_bytes >= (size_t)slices * (size_t)N * ldc * sizeof(float), "some_train_gemm16_wgrad16: partial buffer too small (some_train_gemm16_bytes(N, K, frames, K + 4))");
     float* planes = static_cast<float*>(partial_dev);
+    const WgradReduce red{planes, dW_dev, db_dev, (size_t)N * ldc, slices, N, K, ldc, accumulate};
+    hipStream_t ws;
+    SomeHandle::WgradLane* wl;
+    T_TRY(h, wgrad_begin(h, st(stream), red, &ws, &wl));
     T_TRY(h, launch_gemm16(static_cast<const float*>(dY16_dev), ldy, 1, static_cast<const float*>(X16_dev), ldx, 1, nullptr, planes, ldc, N, K, frames,
-                           operand, slices, (size_t)N * ldc, db_dev ? K : -1, st(stream), 1));
-    T_TRY(h, launch_reduce_wgrad(planes, slices, (size_t)N * ldc, N, K, ldc, dW_dev, db_dev, accumulate, st(stream)));
+                           operand, slices, (size_t)N * ldc, db_dev ? K : -1, ws, 1));
+    T_TRY(h, wgrad_reduce(wl, red, ws));
     return SOME_OK;
 }
 
@@ -299,7 +382,15 @@ int some_train_ffn_block_bwd(SomeHandle* h, const float* d_dev, const float* x_d
     if ((rc = some_train_gemm16s(h, 2, dy16, N, w2t_16_dev, N, nullptr, dh16, H, ha, H, 0, M, H, N, operand, p_latent, seed_latent, 1.0f, stream))) return rc;
     if ((rc = some_train_gemm16s(h, 0, dh16, H, w1t_16_dev, H, nullptr, dn, K, nullptr, 0, 0, M, K, H, operand, 0.f, 0, 1.0f, stream))) return rc;
     if ((rc = some_train_gemm16_wgrad16(h, dh16, H, n16, K, dw1_dev, db1_dev, H, K, M, operand, 1, partial_dev, partial_bytes, stream))) return rc;
-    if ((rc = some_train_gemm16_wgrad16(h, dy16, N, ha + (size_t)M * H * 2, H, dw2_dev, db2_dev, N, H, M, operand, 1, partial_dev, partial_bytes, stream))) return rc;
+    // deferred reductions (weight-gradient lanes): the second product gets planes of its own behind the first's when the caller's buffer
+    // holds both (some_train_gemm16_bytes of each, the first rounded up to 256 bytes) - sharing them would only force a flush in between
+    char* part2 = static_cast<char*>(partial_dev);
+    size_t bytes2 = partial_bytes;
+    if (const SomeHandle::WgradLane* wl = wgrad_lane_of(h, st(stream)); wl && wl->defer) {
+        const size_t first = up256((size_t)gemm16_slices(H, K, M, operand) * (size_t)H * (K + 4) * sizeof(float));
+        if (partial_bytes >= first + (size_t)gemm16_slices(N, H, M, operand) * (size_t)N * (H + 4) * sizeof(float)) { part2 += first; bytes2 -= first; }
+    }
+    if ((rc = some_train_gemm16_wgrad16(h, dy16, N, ha + (size_t)M * H * 2, H, dw2_dev, db2_dev, N, H, M, operand, 1, part2, bytes2, stream))) return rc;
     return some_train_layernorm_bwd_add(h, dn, x_dev, gamma_dev, mean, rstd, add_residual ? d_dev : nullptr, dx_dev, dgamma_dev, dbeta_dev, 1, M,
                                         ln_scratch_dev, ln_scratch_bytes, stream);
 }

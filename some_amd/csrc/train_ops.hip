@@ -797,10 +797,9 @@ hipError_t launch_reduce_slices(const float* partial, int slices, size_t n, floa
 // Weight-gradient planes [slice][M][ldc] (ldc = N + 4: the GEMM's N columns, then the column-sum column) -> the parameter-gradient
 // arrays themselves: dW [M, N] contiguous and db [M], summed in slice order, added to what is there when `accumulate` (the flat
 // gradient buffer across micro-batches) - no intermediate tensor, no separate add.
-static __global__ __launch_bounds__(256) void reduce_wgrad_kernel(const float* __restrict__ partial, int slices, size_t stride, int M, int N, int ldc,
-                                                                  float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+static __device__ __forceinline__ void reduce_wgrad_body(const float* __restrict__ partial, int slices, size_t stride, int M, int N, int ldc,
+                                                         float* __restrict__ dw, float* __restrict__ db, int accumulate, size_t i) {
     const int n4 = N / 4;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)M * n4) return;
     const int row = (int)(i / n4), c = (int)(i % n4) * 4;
     const float* src = partial + (size_t)row * ldc + c;
@@ -822,6 +821,39 @@ static __global__ __launch_bounds__(256) void reduce_wgrad_kernel(const float* _
         for (int s = 1; s < slices; ++s) b += partial[(size_t)s * stride + (size_t)row * ldc + N];
         db[row] = (accumulate ? db[row] : 0.f) + b;
     }
+}
+
+static __global__ __launch_bounds__(256) void reduce_wgrad_kernel(const float* __restrict__ partial, int slices, size_t stride, int M, int N, int ldc,
+                                                                  float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+    reduce_wgrad_body(partial, slices, stride, M, N, ldc, dw, db, accumulate, (size_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// Up to kWgradTable reductions in one launch (the weight-gradient lanes' deferred reductions): workgroup -> entry by the running block
+// counts (a scalar scan of <= 32 integers), then the body of reduce_wgrad_kernel on that entry - the same additions in the same order.
+struct WgradTableArgs { WgradReduce e[kWgradTable]; int begin[kWgradTable + 1]; int n; };
+static __global__ __launch_bounds__(256) void reduce_wgrad_table_kernel(WgradTableArgs t) {
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.begin[k + 1]) ++k;
+    const WgradReduce& r = t.e[k];
+    reduce_wgrad_body(r.partial, r.slices, r.stride, r.M, r.N, r.ldc, r.dw, r.db, r.accumulate, (size_t)((int)blockIdx.x - t.begin[k]) * 256 + threadIdx.x);
+}
+
+hipError_t launch_reduce_wgrad_table(const WgradReduce* entries, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n > kWgradTable) return hipErrorInvalidValue;
+    WgradTableArgs t{};
+    int blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        const WgradReduce& r = entries[k];
+        if (r.M <= 0 || r.N <= 0 || (r.N & 3) || (r.ldc & 3) || (reinterpret_cast<uintptr_t>(r.dw) & 15)) return hipErrorInvalidValue;
+        t.e[k] = r;
+        t.begin[k] = blocks;
+        blocks += (int)(((size_t)r.M * (r.N / 4) + 255) / 256);
+    }
+    t.begin[n] = blocks;
+    t.n = n;
+    hipLaunchKernelGGL(reduce_wgrad_table_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t);
+    return hipGetLastError();
 }
 
 hipError_t launch_reduce_wgrad(const float* partial, int slices, size_t stride, int M, int N, int ldc, float* dw, float* db, int accumulate,

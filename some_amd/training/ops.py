@@ -44,6 +44,27 @@ class TrainOps:
         # Tensors carry the lane that produced them on the tape; a consumer on the other lane waits on an event of the producer's
         # stream and tells the caching allocator (record_stream).  SOME_AMD_TRAIN_LANES=1: everything on one stream (A/B runs).
         self.lanes = 2 if os.environ.get('SOME_AMD_TRAIN_LANES', '2') != '1' else 1
+        # Weight-gradient LANES (round 5, trainer's tape only): nothing downstream in a backward pass reads a weight gradient, so the
+        # split-K weight-gradient GEMMs and their reductions (64 + 73 launches of the ~830 per step) need not sit in the dependent chain of
+        # the data gradients.  Inside Tape.backward every lane is paired with a side stream (some_train_set_wgrad_stream): the library
+        # issues the weight-gradient launches there behind an event of the lane; the operands stay referenced until the lanes have been
+        # joined (end of the pass, or before a gradient bucket's all-reduce).  Same kernels and summation order: bit-identical gradients.
+        # Measured at 8 x 520 frames (profiles/r05ai_train_ab.txt, two interleaved repetitions): 8.8 / 8.2 -> 7.7 / 8.1 ms per step.
+        # SOME_AMD_TRAIN_WGRAD_LANES=0: weight gradients in the lanes' own order (A/B runs).
+        self.wgrad_lanes = os.environ.get('SOME_AMD_TRAIN_WGRAD_LANES', '1') != '0'
+        # ... =2: the reductions behind those GEMMs (planes -> the gradient arrays) are deferred too and go out in ONE table-driven launch
+        # per side stream and join (some_train_wgrad_flush; 73 launches per step become 3): every weight gradient of a pass then gets
+        # planes of its own out of one arena per side stream instead of one reused buffer.  Bit-identical as well, 694 launches per step
+        # instead of 764 - and no faster (8.1 / 8.0 ms): the table launches read ~0.8 GB of planes back from HBM long after they were
+        # written (156 us each; reduced one by one behind their GEMM they come out of the MALL), and the last one sits in front of the
+        # gradient norm.  Off by default.
+        self.wgrad_defer = os.environ.get('SOME_AMD_TRAIN_WGRAD_LANES', '1') == '2'
+        self._wg_arena = [None, None]              # planes of the deferred reductions: [tensor, base address, bytes used]
+        self._wg_streams = [None, None]            # side stream of lane i
+        self._wg_active = False                    # inside Tape.backward with the pairs registered
+        self._wg_pending = [False, False]          # lane i's side stream has work nobody has waited for
+        self._wg_keep: list = []                   # operands of the weight-gradient launches in flight on the side streams
+        self._wg_events = [None, None]
         self._lane = 0
         self._lane_streams = [None, None]          # torch streams of the pinned step: [the caller's, the helper]
         self._lane_ptrs = [None, None]
@@ -113,9 +134,10 @@ class TrainOps:
         """dw [N, K] += dy^T x, db [N] += column sums of dy, straight into the gradient arrays (some_train_gemm16_wgrad)."""
         M, N = dy.shape
         K = x.shape[1]
-        part = self.partial(self._bytes('some_train_gemm16_bytes', N, K, M, K + 4))
-        self.check(self.lib.some_train_gemm16_wgrad(self.h, _p(dy), N, _p(x), K, _p(dw), _p(db), N, K, M, self._op16, 1, _p(part),
-                                                    part.numel(), self.stream()))
+        part, part_bytes = self.wgrad_planes(self._bytes('some_train_gemm16_bytes', N, K, M, K + 4))
+        self.check(self.lib.some_train_gemm16_wgrad(self.h, _p(dy), N, _p(x), K, _p(dw), _p(db), N, K, M, self._op16, 1, part,
+                                                    part_bytes, self.stream()))
+        self.wgrad_issued(dy, x)
 
     # ---- 16-bit stored operands (mixed precision) ---------------------------------------------------------------------
     @property
@@ -182,9 +204,12 @@ class TrainOps:
         """dw [N, K] (+)= dy16^T x16, db [N] (+)= column sums of dy16 (some_train_gemm16_wgrad16)."""
         M, N = dy16.shape
         K = x16.shape[1]
-        part = self.partial(self._bytes('some_train_gemm16_bytes', N, K, M, K + 4))
+        part, part_bytes = self.wgrad_planes(self._bytes('some_train_gemm16_bytes', N, K, M, K + 4))
         self.check(self.lib.some_train_gemm16_wgrad16(self.h, _p(dy16), dy16.stride(0), _p(x16), x16.stride(0), _p(dw), _p(db), N, K, M, self._hi_mode, int(accumulate),
-                                                      _p(part), part.numel(), self.stream()))
+                                                      part, part_bytes, self.stream()))
+        self.wgrad_issued(dy16, x16)
+        if not accumulate:
+            self.join_wgrad()                # a fresh array the tape adds on this lane: no run-ahead (not the default path)
 
     def silu16(self, x: torch.Tensor) -> torch.Tensor:
         out = torch.empty(x.shape, dtype=self.dtype16, device=self.device)
@@ -293,6 +318,7 @@ class TrainOps:
         """The current lane waits for the other one (before a collective that reads what both have written)."""
         if self._pinned_stream is not None and self.lanes == 2 and self._lane_streams[1] is not None:
             self.wait_lane(1 - self._lane, force=True)
+        self.join_wgrad()
 
     def join_lanes(self):
         """Lane 0 waits for lane 1 (end of the backward pass: the gradient norm and the optimiser run on the caller's stream)."""
@@ -328,12 +354,88 @@ class TrainOps:
             buf = self._block_scratch[self._lane] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return buf
 
-    def partial(self, need: int) -> torch.Tensor:
-        """Partial-plane buffer of the split-K weight-gradient GEMMs, one per lane."""
-        buf = self._partials.get(self._lane)
+    def partial(self, need: int, wgrad: bool = False) -> torch.Tensor:
+        """Partial-plane buffer of the split-K GEMMs, one per lane; the weight-gradient entry points (which may run on the lane's side
+        stream, see ``wgrad_lanes``) have their own, so that a call that stays on the lane never shares planes with one that left it."""
+        key = (self._lane, wgrad)
+        buf = self._partials.get(key)
         if buf is None or buf.numel() < need:
-            buf = self._partials[self._lane] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            if buf is not None and self._wg_active:
+                self._wg_keep.append(buf)          # the side stream may still be reducing out of the old planes
+            buf = self._partials[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return buf
+
+    # ---- weight-gradient lanes ---------------------------------------------------------------------------------------
+    def wgrad_planes(self, need: int):
+        """(pointer, bytes) of the partial planes of ONE weight-gradient call on the current lane: the lane's reused weight-gradient
+        buffer - or, while reductions are deferred, a slice of the side stream's arena that nothing else touches until the flush.  A full
+        arena is flushed and reused from its start (the side stream runs the flush before the next GEMM writes there)."""
+        if not (self._wg_active and self.wgrad_defer):
+            buf = self.partial(need, wgrad=True)
+            return C.c_void_p(buf.data_ptr()), buf.numel()
+        need = (need + 255) // 256 * 256
+        lane = self._lane
+        arena = self._wg_arena[lane]
+        if arena is None or arena[2] + need > arena[0].numel():
+            if arena is not None and need <= arena[0].numel():
+                self.check(self.lib.some_train_wgrad_flush(self.h, self._lane_ptrs[lane]))
+                arena[2] = 0
+            else:
+                if arena is not None:
+                    self._wg_keep.append(arena[0])     # waiting reductions still read it
+                buf = torch.empty(max(need, 1 << 30), dtype=torch.uint8, device=self.device)     # (~0.8 GB of planes per lane and pass at lay 3)
+                arena = self._wg_arena[lane] = [buf, buf.data_ptr(), 0]
+        off = arena[2]
+        arena[2] = off + need
+        return C.c_void_p(arena[1] + off), need
+
+    def begin_wgrad_lanes(self):
+        """Tape.backward: pair every lane's stream with its side stream for the duration of the pass."""
+        if not self.wgrad_lanes or self._pinned_stream is None or self._wg_active:
+            return
+        for i in range(self.lanes):
+            if self._wg_streams[i] is None:
+                self._wg_streams[i] = torch.cuda.Stream(self.device)
+                self._wg_events[i] = torch.cuda.Event()
+            self.check(self.lib.some_train_set_wgrad_stream(self.h, self._lane_ptrs[i], C.c_void_p(self._wg_streams[i].cuda_stream),
+                                                            1 if self.wgrad_defer else 0))
+            if self._wg_arena[i] is not None:
+                self._wg_arena[i][2] = 0            # the previous pass's planes were reduced on the same side stream: reuse in order
+        self._wg_active = True
+
+    def wgrad_issued(self, *operands):
+        """Bookkeeping behind a weight-gradient call on the current lane: its operands must outlive the side stream's use of them (they
+        were allocated on the lane's stream: freed now, the caching allocator would hand them to the lane's next allocation)."""
+        if self._wg_active:
+            self._wg_pending[self._lane] = True
+            self._wg_keep.append(operands)
+
+    def join_wgrad(self):
+        """The current lane waits for the weight-gradient launches issued so far on every lane's side stream."""
+        if not self._wg_active:
+            return
+        me = self._lane_streams[self._lane]
+        for i in range(self.lanes):
+            if self._wg_pending[i]:
+                if self.wgrad_defer:
+                    self.check(self.lib.some_train_wgrad_flush(self.h, self._lane_ptrs[i]))
+                ev = self._wg_events[i]
+                ev.record(self._wg_streams[i])
+                me.wait_event(ev)
+
+    def end_wgrad_lanes(self):
+        """End of Tape.backward (lane 0 current): lane 0 waits for the side streams - the gradient norm and the optimiser read what they
+        wrote -, the pairs are removed and the operands released (every later use of their memory is enqueued behind lane 0 from here on)."""
+        if not self._wg_active:
+            return
+        try:
+            self.join_wgrad()
+        finally:
+            for i in range(self.lanes):
+                self.lib.some_train_set_wgrad_stream(self.h, self._lane_ptrs[i], None, 0)
+            self._wg_active = False
+            self._wg_pending = [False, False]
+            self._wg_keep.clear()
 
     def check(self, rc):
         if rc:
@@ -652,6 +754,20 @@ class Tape:
             grads[id(t)] = (g, 0) if id(t) not in grads else (grads[id(t)][0] + g, 0)
         records, ops = self.records, self.ops
         two = ops.two_lanes()
+        ops.begin_wgrad_lanes()
+        try:
+            self._walk(records, ops, two, grads)
+        finally:
+            if two:
+                ops._enter_lane(0)
+            ops.end_wgrad_lanes()
+        if two:
+            ops.join_lanes()
+        self.produced.clear()
+        self.lane_of.clear()
+
+    @staticmethod
+    def _walk(records, ops, two, grads):
         while records:
             fn, ctx, args, out, lane = records.pop()            # releases the saved activations as the pass moves on
             entry = grads.pop(id(out), None)
@@ -683,11 +799,6 @@ class Tape:
                             ops.adopt(prev[0], prev[1])
                         grads[id(a)] = (prev[0] + ga, lane)
                         ops._lane_version[lane] += 1
-        if two:
-            ops._enter_lane(0)
-            ops.join_lanes()
-        self.produced.clear()
-        self.lane_of.clear()
 
 
 class _Lane:
@@ -882,14 +993,20 @@ class _FfnBlock16(torch.autograd.Function):
             if all(t is not None for t in sinks) and all(ctx.needs_input_grad[i] for i in (2, 3, 4, 5, 6, 7)):
                 # one library call (some_train_ffn_block_bwd): every gradient lands in the flat gradient buffer, dx = d + LayerNorm'(dn)
                 dx = torch.empty_like(x)
-                scr = ops.block_scratch(ops._bytes('some_train_ffn_block_scratch_bytes', M, K, H, N))
+                need = ops._bytes('some_train_ffn_block_scratch_bytes', M, K, H, N)
+                # (weight-gradient lanes: dy16 / dh16 in the scratch block are read on the side stream after this call has returned -
+                # a block of its own per call, released with the other operands when the lanes are joined)
+                scr = torch.empty(need, dtype=torch.uint8, device=ops.device) if ops._wg_active else ops.block_scratch(need)
                 sc = ops.scratch(M, 512)
-                part = ops.partial(max(ops._bytes('some_train_gemm16_bytes', H, K, M, K + 4), ops._bytes('some_train_gemm16_bytes', N, H, M, H + 4)))
+                n1, n2 = ops._bytes('some_train_gemm16_bytes', H, K, M, K + 4), ops._bytes('some_train_gemm16_bytes', N, H, M, H + 4)
+                # (deferred reductions: planes for both weight gradients, the second behind the first rounded up to 256 bytes)
+                part, part_bytes = ops.wgrad_planes((n1 + 255) // 256 * 256 + n2 if ops._wg_active and ops.wgrad_defer else max(n1, n2))
                 ops.check(ops.lib.some_train_ffn_block_bwd(ops.h, _p(d), _p(x), _p(gamma_t), _p(save), _p(ops.shadow16(w1)[1]), _p(ops.shadow16(w2)[1]),
                                                            M, K, H, N, ops._hi_mode, float(alpha), float(p_latent), seed_latent, float(p_out), seed_out,
                                                            _p(sinks[0]), _p(sinks[1]), _p(sinks[2]), _p(sinks[3]), _p(sinks[4]), _p(sinks[5]),
                                                            1 if ctx.needs_input_grad[1] else 0, _p(dx), _p(scr), scr.numel(), _p(sc), sc.numel(),
-                                                           _p(part), part.numel(), ops.stream()))
+                                                           part, part_bytes, ops.stream()))
+                ops.wgrad_issued(save, scr)
                 for t in (w1, b1, w2, b2, gamma, beta):
                     ops.deposited(t)
                 return None, dx, None, None, None, None, None, None, None, None, None, None, None

@@ -569,6 +569,107 @@ def test_two_lanes_equal_one_lane_bit_for_bit(precision):
     assert all(torch.equal(b2[k], b1[k]) for k in b1)
 
 
+@pytest.mark.parametrize('precision,block_calls,defer', [('bf16', True, False), ('bf16', True, True), ('bf16', False, True), ('16-mixed', True, True),
+                                                        (None, True, False), (None, True, True)])
+def test_weight_gradient_lanes_equal_the_in_order_pass_bit_for_bit(precision, block_calls, defer):
+    """ops.wgrad_lanes: the split-K weight-gradient GEMMs and their reductions leave the lanes' dependent chains for a side stream each
+    (some_train_set_wgrad_stream; the operands stay referenced until the lanes are joined).  Same kernels, same summation order - only
+    their position in time changes: after three updates at lay 3 (the last over two micro-batches, dropout on) losses, gradient norm,
+    gradients, parameters and BatchNorm statistics equal the in-order run's exactly, with the block-level FFN call and call by call, in
+    mixed precision and in the split-f16 fp32-equivalent mode, with the reductions behind the GEMMs launched one by one and deferred into
+    the table-driven launch (``defer``); the side streams were really used and nothing stays registered."""
+    from some_amd.training.task import MIDIExtractionTrainer
+    cfg = get_config('two_head_model', lay=3)
+    if precision:
+        cfg = dict(cfg, pl_trainer_precision=precision)
+    outs = []
+    for wg in (True, False):
+        tr = MIDIExtractionTrainer(cfg, device='cuda', seed=7)
+        tr.ops.wgrad_lanes, tr.ops.wgrad_defer, tr.ops.block_calls = wg, wg and defer, block_calls
+        issued = []
+        if wg:
+            real = tr.ops.wgrad_issued
+            tr.ops.wgrad_issued = lambda *a: (issued.append(tr.ops._lane), real(*a))[1]
+        res = [tr.training_step(_sample()), tr.training_step(_sample()), tr.training_step([_sample(), _sample()])]
+        torch.cuda.synchronize()
+        assert all(not r['skipped'] for r in res)
+        if wg:
+            assert set(issued) == {0, 1} and len(issued) >= 4 * 20          # both lanes' side streams carried weight gradients
+            assert tr.ops._wg_streams[0] is not None and tr.ops._wg_streams[1] is not None
+        assert not tr.ops._wg_active and not tr.ops._wg_keep and tr.ops._wg_pending == [False, False]
+        outs.append((res, tr.model.params.grad.clone(), tr.model.params.flat.clone(),
+                     {k: v.clone() for k, v in tr.model.params.buffers.items()}))
+        assert torch.cuda.current_stream() == torch.cuda.default_stream()
+    (r1, g1, p1, b1), (r0, g0, p0, b0) = outs
+    for a, b in zip(r1, r0):
+        for k in ('bound_loss', 'midi_loss', 'total_loss'):
+            assert float(a[k]) == float(b[k]), k
+        assert a['grad_norm'] == b['grad_norm']
+    assert torch.equal(g1, g0) and torch.equal(p1, p0)
+    assert all(torch.equal(b1[k], b0[k]) for k in b0)
+    assert float(g1.abs().sum()) > 0
+
+
+def test_weight_gradient_stream_pairing_of_the_library():
+    """some_train_set_wgrad_stream through the C ABI: a weight gradient issued on a paired stream is computed on the side stream and equals
+    the unpaired call bit for bit; with deferred reductions nothing reaches the gradient arrays before some_train_wgrad_flush, which
+    reduces every waiting call in one launch; planes that clash with waiting ones (one reused buffer) flush first and stay correct; NULL
+    flushes and removes the pairing."""
+    from some_amd.engine import Engine
+    from some_amd.training.ops import TrainOps, _p
+    import ctypes as C
+    ops = TrainOps(Engine(get_config('two_head_model', lay=1), device='cuda'))
+    ops.set_mixed_precision(True, 'bf16')
+    g = torch.Generator(device='cuda').manual_seed(3)
+    M = 1000
+    shapes = [(512, 2048), (2048, 512), (1536, 512)]
+    ops_in = [(torch.randn(M, N, device='cuda', generator=g).to(torch.bfloat16), torch.randn(M, K, device='cuda', generator=g).to(torch.bfloat16))
+              for N, K in shapes]
+    want = []
+    for (dy16, x16), (N, K) in zip(ops_in, shapes):
+        w, b = torch.ones(N, K, device='cuda'), torch.ones(N, device='cuda')           # accumulate: ones + the product
+        ops.wgrad16(dy16, x16, w, b, accumulate=True)
+        want.append((w, b))
+    torch.cuda.synchronize()
+    lane, side = torch.cuda.Stream(), torch.cuda.Stream()
+    lp, sp = C.c_void_p(lane.cuda_stream), C.c_void_p(side.cuda_stream)
+    need = [ops._bytes('some_train_gemm16_bytes', N, K, M, K + 4) for N, K in shapes]
+    planes = [torch.empty(n, dtype=torch.uint8, device='cuda') for n in need]
+
+    def issue(parts):
+        got = [(torch.ones(N, K, device='cuda'), torch.ones(N, device='cuda')) for N, K in shapes]
+        torch.cuda.synchronize()
+        for (dy16, x16), (N, K), (w, b), part in zip(ops_in, shapes, got, parts):
+            ops.check(ops.lib.some_train_gemm16_wgrad16(ops.h, _p(dy16), N, _p(x16), K, _p(w), _p(b), N, K, M, 2, 1, _p(part), part.numel(), lp))
+        return got
+
+    def same(got):
+        return all(torch.equal(w, ww) and torch.equal(b, bb) for (w, b), (ww, bb) in zip(got, want))
+
+    assert ops.lib.some_train_set_wgrad_stream(ops.h, lp, sp, 0) == 0
+    assert ops.lib.some_train_set_wgrad_stream(ops.h, lp, lp, 0) != 0          # a stream cannot serve itself
+    got = issue(planes)
+    side.synchronize()                                                         # the side stream alone carries the results
+    assert same(got)
+    # deferred: untouched until the flush, then all three in one launch
+    assert ops.lib.some_train_set_wgrad_stream(ops.h, lp, sp, 1) == 0
+    got = issue(planes)
+    torch.cuda.synchronize()
+    assert all(float(w.sum()) == w.numel() and float(b.sum()) == b.numel() for w, b in got)
+    assert ops.lib.some_train_wgrad_flush(ops.h, lp) == 0
+    side.synchronize()
+    assert same(got)
+    # one reused buffer: every call clashes with the waiting planes and flushes them first
+    big = torch.empty(max(need), dtype=torch.uint8, device='cuda')
+    got = issue([big, big, big])
+    assert ops.lib.some_train_set_wgrad_stream(ops.h, lp, None, 0) == 0         # flushes the last one, removes the pairing
+    side.synchronize()
+    assert same(got)
+    got = issue(planes)
+    lane.synchronize()                                                         # unpaired again: the caller's stream
+    assert same(got)
+
+
 @pytest.mark.parametrize('precision', ['bf16', None])
 def test_update_without_host_sync_equals_the_synchronous_one(precision):
     """training_step(sync=False): the clip factor of Lightning's gradient_clip_val is computed on the device from the gradient norm

@@ -17,6 +17,11 @@ from some_amd.configs import get_config  # noqa: E402
 from some_amd.training.task import MIDIExtractionTrainer  # noqa: E402
 
 
+def _crc(t):
+    import zlib
+    return zlib.crc32(t.detach().contiguous().cpu().numpy().tobytes())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=8)
@@ -26,6 +31,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--mixed', action='store_true', help='mixed precision: 16-bit operands on the matrix pipe (pl_trainer_precision 16-bit)')
     ap.add_argument('--operand', choices=['f16', 'bf16'], default='bf16', help="with --mixed: 'bf16' = pl_trainer_precision bf16 (the reference's configs), 'f16' = 16-mixed")
+    ap.add_argument('--digest', action='store_true', help='print CRC-32 digests of the batch, of the gradient after every timed step and of the final parameters (run-to-run determinism probe)')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank, local = int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
@@ -42,7 +48,7 @@ def main():
     sample = {
         'units': torch.from_numpy((rng.standard_normal((B, T, 80)) - 4).astype(np.float32)).cuda(),
         'unit2note': torch.from_numpy(u2n).cuda(),
-        'probs': torch.rand(B, T, 128, device='cuda') * 0.1,
+        'probs': torch.rand(B, T, 128, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1000 + rank)) * 0.1,     # (seeded: the default CUDA generator's seed differs from process to process)
         'bounds': (torch.from_numpy(np.diff(u2n, axis=1, prepend=0)) > 0).float().cuda(),
     }
     for _ in range(args.warmup):
@@ -50,10 +56,16 @@ def main():
     torch.cuda.synchronize()
     host0 = tr.host_enqueue_s
     t0 = time.perf_counter()
+    crcs = []
     for _ in range(args.steps):
         out = tr.training_step(sample)
+        if args.digest:
+            crcs.append(_crc(tr.model.params.grad))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    if args.digest and rank == 0:
+        print('digest: batch', ' '.join(f'{_crc(v):08x}' for v in sample.values()), '| grad per step', ' '.join(f'{c:08x}' for c in crcs),
+              '| parameters', f'{_crc(tr.model.params.flat):08x}', '| loss', repr(float(out['total_loss'])))
     nb = 2 * args.lay + 2
     f_dense = nb * 12090368 + args.lay * 2097152 + 163840 + 1024 * 128 + 1024          # SURVEY.md section 8(d), per frame, forward
     flops = 3.0 * (f_dense + nb * 2048 * T) * B * T                                     # fwd + 2x bwd
