@@ -168,6 +168,35 @@ def load():
     return lib
 
 
+_fast = None
+
+
+def fast():
+    """The library for the call-heavy paths (the training operators): a namespace with every entry point of ``SYMBOLS`` - the generated
+    METH_FASTCALL wrapper (some_amd/_fastcall.so, some_amd/fastcall_gen.py: 0.3 us per call instead of ctypes' ~2 us for 20 arguments)
+    where the signature is plain pointers / integers / floats, the ctypes function otherwise.  Same library, same entry points, same
+    argument order; the wrappers take pointers as None / int / ctypes objects.  SOME_AMD_FASTCALL=0 (A/B runs) or a tree without the
+    built module (it is a binding, not a compute path): the ctypes library itself."""
+    global _fast
+    if _fast is not None:
+        return _fast
+    lib = load()
+    if os.environ.get('SOME_AMD_FASTCALL', '1') == '0' or not (_HERE / '_fastcall.so').exists():
+        _fast = lib
+        return lib
+    import types
+    from . import _fastcall
+    ns = types.SimpleNamespace()
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if _fastcall.bind(name, C.cast(fn, C.c_void_p).value):
+            fn = getattr(_fastcall, name)
+        setattr(ns, name, fn)
+    ns.fastcall = True
+    _fast = ns
+    return ns
+
+
 def check(handle, rc):
     if rc != SOME_OK:
         msg = load().some_last_error(handle)

@@ -72,5 +72,41 @@ def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
     return LIB
 
 
+FASTCALL = HERE / '_fastcall.so'
+
+
+def _load_module(path: pathlib.Path, name: str):
+    """A module of this package by file, without importing the package (some_amd/__init__ pulls in torch)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def build_fastcall(force: bool = False, verbose: bool = True) -> pathlib.Path:
+    """some_amd/_fastcall.so: the generated CPython binding of the C ABI (some_amd/fastcall_gen.py) - plain C, gcc, no link dependency."""
+    import sysconfig
+    header = HERE.parent / 'include' / 'some_amd.h'
+    deps = [HERE / '_lib.py', HERE / 'fastcall_gen.py', header]
+    if not (force or _stale(FASTCALL, deps)):
+        return FASTCALL
+    gcc = shutil.which('gcc') or shutil.which('cc')
+    if gcc is None:
+        raise RuntimeError('gcc not found (needed for some_amd/_fastcall.so)')
+    OBJ.mkdir(parents=True, exist_ok=True)
+    src = OBJ / 'fastcall_gen.c'
+    src.write_text(_load_module(HERE / 'fastcall_gen.py', '_some_amd_fastcall_gen').generate(_load_module(HERE / '_lib.py', '_some_amd_lib_sig').SYMBOLS))
+    cmd = [gcc, '-O2', '-std=gnu11', '-shared', '-fPIC', '-Wall', '-Werror=implicit-function-declaration', f'-I{sysconfig.get_paths()["include"]}',
+           f'-I{header.parent}', str(src), '-o', str(FASTCALL)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'gcc failed for {src.name}:\n{r.stdout}\n{r.stderr}')
+    if verbose:
+        print(f'[some_amd.build] built {FASTCALL}' + (f'\n{r.stderr}' if r.stderr.strip() else ''))
+    return FASTCALL
+
+
 if __name__ == '__main__':
     build(force='--force' in sys.argv)
+    build_fastcall(force='--force' in sys.argv)

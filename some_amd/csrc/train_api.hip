@@ -86,7 +86,7 @@ size_t some_train_scratch_bytes(const SomeHandle* h, int64_t M, int32_t N) {
 }
 
 static int splitk_slices(int M, int N, int K) {
-    const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nk = K / 32;
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nk = K >= 32 ? K / 32 : 1;      // (K < 32 is refused by the GEMM entry point; the sizing call must not divide by zero)
     int want = (512 + tiles - 1) / tiles;                       // ~2 workgroups per CU in flight
     if (want > nk) want = nk;
     if (want < 1) want = 1;

@@ -25,7 +25,12 @@ class TrainOps:
         if engine.host_only or engine.device.type != 'cuda':
             raise RuntimeError('the training operators need an AMD GPU (no CPU fallback)')
         self.engine = engine
-        self.lib, self.h, self.device = engine.lib, engine.handle, engine.device
+        # the library through the generated METH_FASTCALL wrappers (_lib.fast(): ~0.2 us of binding per call instead of ctypes' ~2 us at 20
+        # arguments; ~510 calls per step), the handle and every stream as plain addresses.  Measured (r05al_train_ab.txt): the step does
+        # not move (8.2 vs 8.2 ms in order, 7.7 vs 7.8 with the weight-gradient lanes; host enqueue 6.2 - 6.6 ms either way) - the
+        # enqueue path's time is inside hipLaunchKernel and the allocator, and the step follows the device's dependent chain
+        self.lib, self.device = _lib.fast(), engine.device
+        self.h = getattr(engine.handle, 'value', engine.handle)
         self._scratch: Dict[int, torch.Tensor] = {}         # per lane: two lanes reduce through their scratch at the same time
         self._pinned_stream = None
         self.tape: Optional['Tape'] = None        # set by the trainer for the duration of a forward + backward pass
@@ -49,7 +54,8 @@ class TrainOps:
         # the data gradients.  Inside Tape.backward every lane is paired with a side stream (some_train_set_wgrad_stream): the library
         # issues the weight-gradient launches there behind an event of the lane; the operands stay referenced until the lanes have been
         # joined (end of the pass, or before a gradient bucket's all-reduce).  Same kernels and summation order: bit-identical gradients.
-        # Measured at 8 x 520 frames (profiles/r05ai_train_ab.txt, two interleaved repetitions): 8.8 / 8.2 -> 7.7 / 8.1 ms per step.
+        # Measured at 8 x 520 frames, interleaved repetitions: 8.8 / 8.2 -> 7.7 / 8.1 ms per step (profiles/r05ai_train_ab.txt),
+        # 8.0 / 8.2 / 8.3 -> 7.9 / 7.6 / 7.6 (r05al_train_ab.txt); parameters after 48 updates identical (r05ak_train_ab.txt digests).
         # SOME_AMD_TRAIN_WGRAD_LANES=0: weight gradients in the lanes' own order (A/B runs).
         self.wgrad_lanes = os.environ.get('SOME_AMD_TRAIN_WGRAD_LANES', '1') != '0'
         # ... =2: the reductions behind those GEMMs (planes -> the gradient arrays) are deferred too and go out in ONE table-driven launch
@@ -255,14 +261,14 @@ class TrainOps:
         # step runs on the caller's stream (+ the helper stream of lane 1), so the trainer pins them for the duration of the step
         if self._pinned_stream is not None:
             return self._lane_ptrs[self._lane]
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return torch.cuda.current_stream(self.device).cuda_stream
 
     def pin_stream(self):
         main = torch.cuda.current_stream(self.device)
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(self.device)
         self._lane_streams = [main, self._side_stream]
-        self._lane_ptrs = [C.c_void_p(main.cuda_stream), C.c_void_p(self._side_stream.cuda_stream)]
+        self._lane_ptrs = [main.cuda_stream, self._side_stream.cuda_stream]           # addresses (0: the NULL stream)
         self._pinned_stream = self._lane_ptrs[0]
         self._lane = 0
         self._lane_version = [0, 0]
@@ -372,7 +378,7 @@ class TrainOps:
         arena is flushed and reused from its start (the side stream runs the flush before the next GEMM writes there)."""
         if not (self._wg_active and self.wgrad_defer):
             buf = self.partial(need, wgrad=True)
-            return C.c_void_p(buf.data_ptr()), buf.numel()
+            return buf.data_ptr(), buf.numel()
         need = (need + 255) // 256 * 256
         lane = self._lane
         arena = self._wg_arena[lane]
@@ -387,7 +393,7 @@ class TrainOps:
                 arena = self._wg_arena[lane] = [buf, buf.data_ptr(), 0]
         off = arena[2]
         arena[2] = off + need
-        return C.c_void_p(arena[1] + off), need
+        return arena[1] + off, need
 
     def begin_wgrad_lanes(self):
         """Tape.backward: pair every lane's stream with its side stream for the duration of the pass."""
@@ -397,7 +403,7 @@ class TrainOps:
             if self._wg_streams[i] is None:
                 self._wg_streams[i] = torch.cuda.Stream(self.device)
                 self._wg_events[i] = torch.cuda.Event()
-            self.check(self.lib.some_train_set_wgrad_stream(self.h, self._lane_ptrs[i], C.c_void_p(self._wg_streams[i].cuda_stream),
+            self.check(self.lib.some_train_set_wgrad_stream(self.h, self._lane_ptrs[i], self._wg_streams[i].cuda_stream,
                                                             1 if self.wgrad_defer else 0))
             if self._wg_arena[i] is not None:
                 self._wg_arena[i][2] = 0            # the previous pass's planes were reduced on the same side stream: reuse in order
@@ -596,7 +602,7 @@ class TrainOps:
     def eltwise(self, op: int, a: torch.Tensor, b: Optional[torch.Tensor] = None, alpha: float = 0.0, seed: int = 0,
                 p: float = 0.0) -> torch.Tensor:
         out = torch.empty_like(a)
-        self.check(self.lib.some_train_eltwise(self.h, op, _p(a), _p(b), _p(out), a.numel(), float(alpha), float(p), C.c_uint64(seed),
+        self.check(self.lib.some_train_eltwise(self.h, op, _p(a), _p(b), _p(out), a.numel(), float(alpha), float(p), seed,
                                                self.stream()))
         return out
 

@@ -192,15 +192,15 @@ class MIDIExtractionTrainer:
         # global gradient norm on the device (one double comes back: the step's only host synchronisation); it serves
         # Lightning's gradient_clip_val = clip_grad_norm (configs/base.yaml:49, train.py:88) and the overflow check
         sc = self.ops.scratch(1, 1)
-        self.ops.check(self.ops.lib.some_train_sumsq(self.ops.h, C.c_void_p(P.grad.data_ptr()), P.numel, C.c_void_p(self._sumsq.data_ptr()),
-                                                     C.c_void_p(sc.data_ptr()), sc.numel(), self.ops.stream()))
+        self.ops.check(self.ops.lib.some_train_sumsq(self.ops.h, P.grad.data_ptr(), P.numel, self._sumsq.data_ptr(),
+                                                     sc.data_ptr(), sc.numel(), self.ops.stream()))
         clip = self.config.get('clip_grad_norm', None)
         if not sync and scale == 1.0:
             self._check_pending(block=False)
             self._check_pending(block=True, keep=self._max_in_flight - 1)       # bounded run-ahead
             lr = warmup_lr(self.global_step + 1, self.base_lr, self.warmup_steps, self.min_lr)
             self.global_step += 1
-            p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+            p = lambda t: t.data_ptr()  # noqa: E731
             self.ops.check(self.ops.lib.some_train_adamw_clip(self.ops.h, p(P.flat), p(P.grad), p(self.exp_avg), p(self.exp_avg_sq), P.numel, lr,
                                                               self.betas[0], self.betas[1], self.eps, self.weight_decay, self.global_step,
                                                               p(self._sumsq), float(clip or 0.0), float(self.world * scale), self.ops.stream()))
@@ -236,7 +236,7 @@ class MIDIExtractionTrainer:
         lr = warmup_lr(self.global_step + 1, self.base_lr, self.warmup_steps, self.min_lr)
         if not skipped:
             self.global_step += 1
-            p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+            p = lambda t: t.data_ptr()  # noqa: E731
             self.ops.check(self.ops.lib.some_train_adamw(self.ops.h, p(P.flat), p(P.grad), p(self.exp_avg), p(self.exp_avg_sq), P.numel, lr,
                                                          self.betas[0], self.betas[1], self.eps, self.weight_decay, self.global_step,
                                                          clip_coef / (self.world * scale), self.ops.stream()))

@@ -135,3 +135,69 @@ def test_train_gemm16_validates_arguments_before_any_launch():
         assert call(operand=operand, partial=fake, pbytes=plane, **wg) == _lib.SOME_EINVAL
         assert b'partial buffer too small' in lib.some_last_error(h)
     assert call(bias=fake, partial=fake, pbytes=need, **wg) == _lib.SOME_EINVAL and b'no bias' in lib.some_last_error(h)
+
+
+_SWEEP = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, sys.argv[1])
+from some_amd import _lib, fastcall_gen
+lib, fast = _lib.load(), _lib.fast()
+assert getattr(fast, 'fastcall', False)
+out = {}
+for name, (res, args) in _lib.SYMBOLS.items():
+    if not fastcall_gen.wrappable(res, args):
+        assert getattr(fast, name) is getattr(lib, name) or getattr(fast, name).__name__ == getattr(lib, name).__name__
+        continue
+    assert type(getattr(fast, name)).__name__ == 'builtin_function_or_method', name
+    vals = [None if a is C.c_void_p else (0.5 if a in (C.c_float, C.c_double) else 1) for a in args]
+    out[name] = [int(getattr(lib, name)(*vals)), int(getattr(fast, name)(*vals))]
+print(json.dumps(out))
+"""
+
+
+def test_generated_fast_binding_covers_the_abi_and_agrees_with_ctypes():
+    """some_amd/_fastcall.so (generated from _lib.SYMBOLS against the header, some_amd/fastcall_gen.py): every entry point with a plain
+    pointer / integer / float signature has a wrapper bound to the loaded library, the others fall through to ctypes; each wrapper,
+    called with a NULL handle and dummy arguments (every entry point refuses a NULL handle or is a pure sizing function - no GPU work),
+    returns what the ctypes call returns.  In a subprocess: a wrong wrapper would crash, not fail."""
+    import json
+    import subprocess
+    import sys
+    from some_amd import build
+    build.build_fastcall()
+    r = subprocess.run([sys.executable, '-c', _SWEEP, str(ROOT)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(got) >= 68
+    for name, (a, b) in got.items():
+        assert a == b, (name, a, b)
+    assert got['some_train_gemm16s'] == [_lib.SOME_EINVAL, _lib.SOME_EINVAL] and got['some_train_scratch_bytes'][0] > 0
+
+
+def test_fast_binding_argument_conversions():
+    """Pointers as None / address / ctypes object, 64-bit seeds masked as ctypes masks them, floats from ints, and the errors a wrong call
+    raises (arity, type) - the conversions the training operators rely on."""
+    fast = _lib.fast()
+    if not getattr(fast, 'fastcall', False):
+        pytest.skip('SOME_AMD_FASTCALL=0')
+    p = C.c_void_p(4096)
+    args = [None, 0, p, 512, 4096, 512, None, C.c_void_p(0), 512, None, 0, 0, 4160, 512, 512, 2, 0.1, 2 ** 64 + 5, 1, p]
+    assert fast.some_train_gemm16s(*args) == _lib.SOME_EINVAL                      # reaches the library: a NULL handle is refused
+    assert fast.some_train_scratch_bytes(None, np.int64(4160), True + 511) == _lib.load().some_train_scratch_bytes(None, 4160, 512)
+    with pytest.raises(TypeError, match='takes 3 arguments'):
+        fast.some_train_scratch_bytes(None, 512)
+    with pytest.raises(TypeError):
+        fast.some_train_scratch_bytes(None, 'x', 512)
+    with pytest.raises(TypeError, match='pointer argument'):
+        fast.some_train_scratch_bytes(object(), 1, 512)
+    with pytest.raises(TypeError):
+        fast.some_train_gemm16s(*(args[:16] + ['0.1'] + args[17:]))
+    with pytest.raises(OverflowError):
+        fast.some_train_scratch_bytes(None, 2 ** 70, 512)
+
+
+def test_sizing_calls_do_not_divide_by_zero_on_degenerate_shapes():
+    """some_train_gemm_splitk_bytes(K < 32) raised SIGFPE before round 5 (a slice count of 0 k-blocks); the GEMM itself refuses such a K."""
+    lib = _lib.load()
+    assert lib.some_train_gemm_splitk_bytes(None, 1, 1, 1) >= 256
+    assert lib.some_train_gemm16_bytes(None, 1, 1, 1, 4) >= 256
