@@ -85,6 +85,7 @@ def run(data_dir, precision='bf16', max_batch_frames=80000, max_batch_size=8, wo
                     f'max_batch_size {max_batch_size}; one epoch{" (truncated)" if max_steps else ""}',
         'n_gpus': world, 'updates': len(step_ms), 'skipped_updates': skipped, 'epoch_wall_s': round(wall, 3),
         'host_sync_per_update': bool(sync),
+        'lanes': trainer.ops.lanes, 'weight_gradient_lanes': bool(trainer.ops.wgrad_lanes), 'binding': 'fastcall' if getattr(trainer.ops.lib, 'fastcall', False) else 'ctypes',
         'audio_s_per_s_trained': round(frames_valid * hop_s / wall, 1), 'frames_per_s': round(frames_valid / wall, 1),
         'padding_overhead': round(frames_padded / max(frames_valid, 1), 4),
         'step_ms': {'mean': round(float(ms.mean()), 2), 'p10': round(float(np.percentile(ms, 10)), 2), 'p50': round(float(np.percentile(ms, 50)), 2),
