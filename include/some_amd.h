@@ -385,6 +385,15 @@ int some_train_dwconv(SomeHandle* h, const float* x_dev, const float* taps_dev, 
 int some_train_dwconv_bwd_taps(SomeHandle* h, const float* dy_dev, const float* x_dev, const int32_t* clip_of_row_dev,
                                const int32_t* frame_offsets_dev, int32_t M, int32_t C, float* dtaps_dev,
                                int32_t accumulate, void* scratch_dev, size_t scratch_bytes, void* stream);
+/* The depthwise convolution's PARAMETER gradients written where they belong: dweight_dev [C][31] - the Conv1d weight's own layout, i.e. the
+ * parameter's gradient array - += the tap sums of some_train_dwconv_bwd_taps, dbias_dev [C] (may be NULL) += the column sums of dy.  The
+ * same kernels and sums as some_train_dwconv_bwd_taps(accumulate 0) + a transposed add and some_train_colsum + an add: bit-identical,
+ * four launches (two of them torch's) fewer.  When `stream` is paired with a weight-gradient stream (some_train_set_wgrad_stream) the
+ * launches run there - the caller keeps dy / x and the scratch block (some_train_scratch_bytes(M, C), not shared with calls that stay on
+ * `stream`) untouched until that stream has been joined. */
+int some_train_dwconv_bwd_params(SomeHandle* h, const float* dy_dev, const float* x_dev, const int32_t* clip_of_row_dev,
+                                 const int32_t* frame_offsets_dev, int32_t M, int32_t C, float* dweight_dev, float* dbias_dev,
+                                 void* scratch_dev, size_t scratch_bytes, void* stream);
 /* nn.BCEWithLogitsLoss() (mean over all n elements; training/me_task.py:74,105): loss_dev[0] and, when dlogits_dev is
  * not NULL, d loss / d logits. */
 int some_train_bce_with_logits(SomeHandle* h, const float* logits_dev, const float* target_dev, int64_t n,

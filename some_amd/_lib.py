@@ -107,6 +107,7 @@ SYMBOLS = {
     'some_train_mask_rows': (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P]),
     'some_train_dwconv': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
     'some_train_dwconv_bwd_taps': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P]),
+    'some_train_dwconv_bwd_params': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, C.c_size_t, _P]),
     'some_train_bce_with_logits': (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
     'some_train_cross_entropy': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
     'some_train_binary_emd': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, C.c_size_t, _P]),

@@ -254,7 +254,7 @@ hipError_t launch_mask_rows(const float* x, const uint8_t* mask, float* y, int64
 hipError_t launch_dwconv_train(const float* x, const float* w, const float* bias, const int32_t* frame_offsets, int B, int max_frames, float* y,
                                int C, int flip, hipStream_t s);
 hipError_t launch_dwconv_bwd_w(const float* dy, const float* x, const int32_t* clip_of_row, const int32_t* frame_offsets, int M, int C, float* dw,
-                               int accumulate, float* scratch, hipStream_t s);
+                               int accumulate, float* scratch, hipStream_t s, int weight_layout = 0);
 hipError_t launch_bce(const float* x, const float* t, int64_t n, float* dx, float* loss, double* scratch, hipStream_t s);
 hipError_t launch_cross_entropy(const float* x, const int64_t* target, int M, int N, int64_t ignore, float* dx, float* loss, double* scratch, hipStream_t s);
 hipError_t launch_emd(const float* pred, const float* gt, int B, int T, float* dpred, float* loss, double* scratch, hipStream_t s);

@@ -545,6 +545,28 @@ int some_train_dwconv_bwd_taps(SomeHandle* h, const float* dy_dev, const float* 
     return SOME_OK;
 }
 
+int some_train_dwconv_bwd_params(SomeHandle* h, const float* dy_dev, const float* x_dev, const int32_t* clip_of_row_dev,
+                                 const int32_t* frame_offsets_dev, int32_t M, int32_t C, float* dweight_dev, float* dbias_dev,
+                                 void* scratch_dev, size_t scratch_bytes, void* stream) {
+    if (!h) return SOME_EINVAL;
+    T_CHECK(h, M >= 0 && C > 0 && dweight_dev, "some_train_dwconv_bwd_params: bad argument");
+    if (M == 0) return SOME_OK;
+    T_CHECK(h, dy_dev && x_dev && clip_of_row_dev && frame_offsets_dev, "some_train_dwconv_bwd_params: null pointer");
+    T_CHECK(h, scratch_dev && scratch_bytes >= train_dwconv_w_scratch_bytes(M, C) && scratch_bytes >= train_col_scratch_bytes(M, C),
+            "some_train_dwconv_bwd_params: scratch too small (some_train_scratch_bytes(M, C))");
+    // nothing downstream reads these gradients: they run on the stream's weight-gradient side stream when it has one (the tap sums' two
+    // launches and the bias column sum's two share the scratch block in stream order)
+    hipStream_t ws = st(stream);
+    if (SomeHandle::WgradLane* l = wgrad_lane_of(h, ws)) {
+        T_TRY(h, hipEventRecord(l->ev, ws));
+        T_TRY(h, hipStreamWaitEvent(l->side, l->ev, 0));
+        ws = l->side;
+    }
+    T_TRY(h, launch_dwconv_bwd_w(dy_dev, x_dev, clip_of_row_dev, frame_offsets_dev, M, C, dweight_dev, 1, static_cast<float*>(scratch_dev), ws, 1));
+    if (dbias_dev) T_TRY(h, launch_colsum(dy_dev, M, C, C, dbias_dev, 1, static_cast<float*>(scratch_dev), ws));
+    return SOME_OK;
+}
+
 int some_train_bce_with_logits(SomeHandle* h, const float* logits_dev, const float* target_dev, int64_t n,
                                float* dlogits_dev, float* loss_dev, void* scratch_dev, size_t scratch_bytes,
                                void* stream) {

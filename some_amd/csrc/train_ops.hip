@@ -574,7 +574,10 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_partial_kernel(const float* 
         for (int k = ty; k < kTaps; k += 4)
             partial[((size_t)blockIdx.y * kTaps + k) * C + c] = (red[0][k][l] + red[1][k][l]) + (red[2][k][l] + red[3][k][l]);
 }
-__global__ __launch_bounds__(256) void dwconv_bwd_w_final_kernel(const float* __restrict__ partial, int P, int n, float* __restrict__ dw, int accumulate) {
+// weight_c > 0: dw is the Conv1d weight's own layout [C][taps] (element (tap k, channel c) of the tap-major sums goes to c * taps + k) -
+// the parameter's gradient array itself; 0: tap-major [taps][C] as the sums lie
+__global__ __launch_bounds__(256) void dwconv_bwd_w_final_kernel(const float* __restrict__ partial, int P, int n, float* __restrict__ dw, int accumulate,
+                                                                 int weight_c) {
     // 64 elements per workgroup, wavefront g sums the chunks p = g, g + 4, ... in ascending order, combined as (0 + 1) + (2 + 3)
     __shared__ double red[4][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -584,7 +587,10 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_final_kernel(const float* __
         for (int p = g; p < P; p += 4) a += partial[(size_t)p * n + i];
     red[g][c] = a;
     __syncthreads();
-    if (g == 0 && i < n) dw[i] = (accumulate ? dw[i] : 0.f) + (float)((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    if (g == 0 && i < n) {
+        const int o = weight_c > 0 ? (i % weight_c) * (n / weight_c) + i / weight_c : i;
+        dw[o] = (accumulate ? dw[o] : 0.f) + (float)((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    }
 }
 
 // ---- losses ------------------------------------------------------------------------------------------------------------
@@ -992,12 +998,13 @@ hipError_t launch_dwconv_train(const float* x, const float* w, const float* bias
 }
 
 hipError_t launch_dwconv_bwd_w(const float* dy, const float* x, const int32_t* clip_of_row, const int32_t* frame_offsets, int M, int C, float* dw,
-                               int accumulate, float* scratch, hipStream_t s) {
+                               int accumulate, float* scratch, hipStream_t s, int weight_layout) {
     if (M <= 0) return hipSuccess;
     const int P = (M + kDwChunk - 1) / kDwChunk;
     hipLaunchKernelGGL(dwconv_bwd_w_partial_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)P), dim3(256), 0, s, dy, x, clip_of_row, frame_offsets, M, C,
                        scratch);
-    hipLaunchKernelGGL(dwconv_bwd_w_final_kernel, dim3((unsigned)((kTaps * C + 63) / 64)), dim3(256), 0, s, scratch, P, kTaps * C, dw, accumulate);
+    hipLaunchKernelGGL(dwconv_bwd_w_final_kernel, dim3((unsigned)((kTaps * C + 63) / 64)), dim3(256), 0, s, scratch, P, kTaps * C, dw, accumulate,
+                       weight_layout ? C : 0);
     return hipGetLastError();
 }
 

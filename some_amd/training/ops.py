@@ -66,6 +66,10 @@ class TrainOps:
         # gradient norm.  Off by default.
         self.wgrad_defer = os.environ.get('SOME_AMD_TRAIN_WGRAD_LANES', '1') == '2'
         self._wg_arena = [None, None]              # planes of the deferred reductions: [tensor, base address, bytes used]
+        # The depthwise convolution's weight / bias gradients written by the kernels into the gradient arrays themselves (and with them on the
+        # weight-gradient side stream) instead of tensors the tape adds.  SOME_AMD_TRAIN_DWCONV_SINKS=0: the tape's additions (A/B runs).
+        # Measured at 8 x 520 frames with the lanes on (profiles/r05am_train_ab.txt, interleaved): 7.6 / 7.8 -> 7.4 / 7.3 ms per step.
+        self.dwconv_sinks = os.environ.get('SOME_AMD_TRAIN_DWCONV_SINKS', '1') != '0'
         self._wg_streams = [None, None]            # side stream of lane i
         self._wg_active = False                    # inside Tape.backward with the pairs registered
         self._wg_pending = [False, False]          # lane i's side stream has work nobody has waited for
@@ -368,6 +372,17 @@ class TrainOps:
         if buf is None or buf.numel() < need:
             if buf is not None and self._wg_active:
                 self._wg_keep.append(buf)          # the side stream may still be reducing out of the old planes
+            buf = self._partials[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return buf
+
+    def wgrad_scratch(self, need: int) -> torch.Tensor:
+        """Reduction scratch of a parameter-gradient call that may run on the lane's side stream (the depthwise convolution's tap and bias
+        sums): one block per lane that no lane-resident call touches - the calls that use it serialise on the side stream."""
+        key = (self._lane, 'scratch')
+        buf = self._partials.get(key)
+        if buf is None or buf.numel() < need:
+            if buf is not None and self._wg_active:
+                self._wg_keep.append(buf)
             buf = self._partials[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return buf
 
@@ -1354,6 +1369,7 @@ class _DwConv(torch.autograd.Function):
                                             _p(y), Cn, 0, ops.stream()))
         ctx.save_for_backward(x, taps)
         ctx.wshape, ctx.has_bias = weight.shape, bias is not None
+        ctx.wparam, ctx.bparam = weight, bias                      # identities only: looked up among the gradient sinks in backward
         return y
 
     @staticmethod
@@ -1365,6 +1381,20 @@ class _DwConv(torch.autograd.Function):
         dx = torch.empty_like(x)
         ops.check(ops.lib.some_train_dwconv(ops.h, _p(dy), _p(taps), None, _p(batch.frame_offsets_dev), batch.B, batch.max_frames,
                                             _p(dx), Cn, 1, ops.stream()))
+        sw = ops.sink(ctx.wparam) if ops.dwconv_sinks and ctx.needs_input_grad[2] else None
+        sb = ops.sink(ctx.bparam) if sw is not None and ctx.has_bias and ctx.needs_input_grad[3] else None
+        if sw is not None and (sb is not None or not ctx.has_bias) and sw.is_contiguous():
+            # the parameter gradients straight into the gradient arrays, in the weight's own [C][31] layout (some_train_dwconv_bwd_params:
+            # the same sums, no tap-major temporary, no transposed add, no column-sum tensor - four launches fewer) and, inside
+            # Tape.backward with weight-gradient lanes, on the lane's side stream: 76 us per block that nothing downstream waits for
+            sc = ops.wgrad_scratch(ops._bytes('some_train_scratch_bytes', M, Cn))
+            ops.check(ops.lib.some_train_dwconv_bwd_params(ops.h, _p(dy), _p(x), _p(clip_of_row(batch)), _p(batch.frame_offsets_dev), M, Cn, _p(sw), _p(sb),
+                                                           _p(sc), sc.numel(), ops.stream()))
+            ops.wgrad_issued(dy, x, batch)                          # (the batch descriptor: clip_of_row / frame_offsets are read there too)
+            ops.deposited(ctx.wparam)
+            if sb is not None:
+                ops.deposited(ctx.bparam)
+            return None, dx, None, None, None
         dt = torch.empty_like(taps)
         sc = ops.scratch(M, Cn)
         ops.check(ops.lib.some_train_dwconv_bwd_taps(ops.h, _p(dy), _p(x), _p(clip_of_row(batch)), _p(batch.frame_offsets_dev), M, Cn, _p(dt), 0,

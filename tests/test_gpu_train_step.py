@@ -610,6 +610,36 @@ def test_weight_gradient_lanes_equal_the_in_order_pass_bit_for_bit(precision, bl
     assert float(g1.abs().sum()) > 0
 
 
+@pytest.mark.parametrize('precision,wgrad_lanes,tape', [('bf16', True, True), ('bf16', False, True), (None, True, True), ('bf16', False, False)])
+def test_depthwise_parameter_gradients_into_the_gradient_arrays_equal_the_tape_additions(precision, wgrad_lanes, tape):
+    """ops.dwconv_sinks: the depthwise convolution's weight / bias gradients are accumulated by the kernels into the flat gradient buffer in
+    the weight's own [C][31] layout (some_train_dwconv_bwd_params; on the side stream when weight-gradient lanes are on) instead of a
+    tap-major tensor + a column-sum tensor that the tape (or autograd's AccumulateGrad) adds.  The same sums added to the same values: after
+    three updates (the last over two micro-batches) losses, gradient norm, gradients, parameters and BatchNorm statistics are identical."""
+    from some_amd.training.task import MIDIExtractionTrainer
+    cfg = dict(get_config('two_head_model', lay=2), some_amd_tape=tape)
+    if precision:
+        cfg = dict(cfg, pl_trainer_precision=precision)
+    outs = []
+    for sinks in (True, False):
+        tr = MIDIExtractionTrainer(cfg, device='cuda', seed=11)
+        tr.ops.dwconv_sinks, tr.ops.wgrad_lanes = sinks, wgrad_lanes
+        res = [tr.training_step(_sample()), tr.training_step(_sample()), tr.training_step([_sample(), _sample()])]
+        torch.cuda.synchronize()
+        assert all(not r['skipped'] for r in res)
+        P = tr.model.params
+        dw = [k for k in P.param_names if 'depthwise_conv.weight' in k]
+        assert dw and all(float(P.views[k].grad.abs().sum()) > 0 for k in dw)
+        outs.append((res, P.grad.clone(), P.flat.clone(), {k: v.clone() for k, v in P.buffers.items()}))
+    (r1, g1, p1, b1), (r0, g0, p0, b0) = outs
+    for a, b in zip(r1, r0):
+        for k in ('bound_loss', 'midi_loss', 'total_loss'):
+            assert float(a[k]) == float(b[k]), k
+        assert a['grad_norm'] == b['grad_norm']
+    assert torch.equal(g1, g0) and torch.equal(p1, p0)
+    assert all(torch.equal(b1[k], b0[k]) for k in b0)
+
+
 def test_weight_gradient_stream_pairing_of_the_library():
     """some_train_set_wgrad_stream through the C ABI: a weight gradient issued on a paired stream is computed on the side stream and equals
     the unpaired call bit for bit; with deferred reductions nothing reaches the gradient arrays before some_train_wgrad_flush, which
