@@ -186,7 +186,13 @@ def fast():
         _fast = lib
         return lib
     import types
-    from . import _fastcall
+    try:
+        from . import _fastcall
+    except ImportError as e:                      # built for another interpreter: the binding is optional, the library is not
+        import warnings
+        warnings.warn(f'some_amd/_fastcall.so does not import ({e}); using the ctypes binding (rebuild: python -m some_amd.build)')
+        _fast = lib
+        return lib
     ns = types.SimpleNamespace()
     for name in SYMBOLS:
         fn = getattr(lib, name)
