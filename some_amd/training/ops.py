@@ -414,14 +414,19 @@ class TrainOps:
         """Tape.backward: pair every lane's stream with its side stream for the duration of the pass."""
         if not self.wgrad_lanes or self._pinned_stream is None or self._wg_active:
             return
-        for i in range(self.lanes):
-            if self._wg_streams[i] is None:
-                self._wg_streams[i] = torch.cuda.Stream(self.device)
-                self._wg_events[i] = torch.cuda.Event()
-            self.check(self.lib.some_train_set_wgrad_stream(self.h, self._lane_ptrs[i], self._wg_streams[i].cuda_stream,
-                                                            1 if self.wgrad_defer else 0))
-            if self._wg_arena[i] is not None:
-                self._wg_arena[i][2] = 0            # the previous pass's planes were reduced on the same side stream: reuse in order
+        try:
+            for i in range(self.lanes):
+                if self._wg_streams[i] is None:
+                    self._wg_streams[i] = torch.cuda.Stream(self.device)
+                    self._wg_events[i] = torch.cuda.Event()
+                self.check(self.lib.some_train_set_wgrad_stream(self.h, self._lane_ptrs[i], self._wg_streams[i].cuda_stream,
+                                                                1 if self.wgrad_defer else 0))
+                if self._wg_arena[i] is not None:
+                    self._wg_arena[i][2] = 0        # the previous pass's planes were reduced on the same side stream: reuse in order
+        except Exception:
+            for i in range(self.lanes):             # a pairing without its join would let weight gradients run ahead of their readers
+                self.lib.some_train_set_wgrad_stream(self.h, self._lane_ptrs[i], None, 0)
+            raise
         self._wg_active = True
 
     def wgrad_issued(self, *operands):
