@@ -34,6 +34,7 @@ def init_distributed(backend: str = None):
 
 
 _BOUND = False        # this process has been pinned to its own share of the host's cores (bind_rank_to_cores)
+_SYSFS = '/sys'       # root of the topology files (tests point it at a fixture tree of a two-socket node)
 
 
 def _core_groups(allowed) -> List[List[int]]:
@@ -41,7 +42,7 @@ def _core_groups(allowed) -> List[List[int]]:
     /sys/devices/system/cpu/cpu*/topology; without it every logical CPU is its own group, in numeric order."""
     groups = {}
     for cpu in sorted(allowed):
-        base = f'/sys/devices/system/cpu/cpu{cpu}/topology/'
+        base = f'{_SYSFS}/devices/system/cpu/cpu{cpu}/topology/'
         try:
             with open(base + 'physical_package_id') as f:
                 pkg = int(f.read())
@@ -86,7 +87,7 @@ def gpu_numa_nodes(local_world: int) -> List[int]:
         for i in range(local_world):
             pr = torch.cuda.get_device_properties(i)
             addr = f'{getattr(pr, "pci_domain_id", 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
-            with open(f'/sys/bus/pci/devices/{addr}/numa_node') as f:
+            with open(f'{_SYSFS}/bus/pci/devices/{addr}/numa_node') as f:
                 node = int(f.read())
             if node < 0:
                 return []
@@ -101,7 +102,7 @@ def rank_core_slice_numa(local_rank: int, local_world: int, nodes: Sequence[int]
     if allowed is None:
         allowed = os.sched_getaffinity(0)
     node = nodes[local_rank]
-    with open(f'/sys/devices/system/node/node{node}/cpulist') as f:
+    with open(f'{_SYSFS}/devices/system/node/node{node}/cpulist') as f:
         local = set(_parse_cpulist(f.read())) & set(allowed)
     peers = [r for r in range(local_world) if nodes[r] == node]
     groups = _core_groups(local)

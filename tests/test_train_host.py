@@ -55,7 +55,8 @@ _WORKER = r'''
 import os, sys, torch
 sys.path.insert(0, os.environ['REPO'])
 import torch.distributed as dist
-dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + os.environ['PORT'], rank=int(os.environ['RANK']), world_size=2)
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + os.environ['PORT'], rank=int(os.environ['RANK']), world_size=int(os.environ.get('WORLD', '2')))
+W = dist.get_world_size()
 rank = dist.get_rank()
 # the trainer's synchronisation protocol on plain tensors: broadcast of the flat parameters from rank 0, one summing
 # all-reduce of the flat gradient, averaging folded into the optimiser's grad_scale = 1 / world
@@ -64,8 +65,8 @@ dist.broadcast(flat, src=0)
 assert torch.equal(flat, torch.ones(1000))
 grad = torch.arange(1000, dtype=torch.float32) * (rank + 1)
 dist.all_reduce(grad, op=dist.ReduceOp.SUM)
-mean = grad * (1.0 / 2)
-assert torch.allclose(mean, torch.arange(1000, dtype=torch.float32) * 1.5)
+mean = grad * (1.0 / W)
+assert torch.allclose(mean, torch.arange(1000, dtype=torch.float32) * ((W + 1) / 2))
 # every rank plans the whole epoch itself (no communication) and keeps its own column of the batch grid
 import numpy as np
 from some_amd.training.samplers import DsBatchSampler
@@ -73,20 +74,25 @@ class Lengths:
     _sizes = np.arange(10, 210, 10)
     def __len__(self): return len(self._sizes)
     def num_frames(self, i): return self._sizes[i]
-sm = DsBatchSampler(Lengths(), 400, 4, num_replicas=2, rank=rank, shuffle_sample=True, seed=3)
+sm = DsBatchSampler(Lengths(), 400, 4, num_replicas=W, rank=rank, shuffle_sample=True, seed=3)
 sm.set_epoch(1)
-gathered = [None, None]
+gathered = [None] * W
 dist.all_gather_object(gathered, [list(map(int, b)) for b in sm])
-a, b = gathered
-assert len(a) == len(b) and {i for p in a + b for i in p} == set(range(20))
-assert sum(len(p) for p in a + b) <= 20 + 4          # at most one repeated batch (odd batch count)
+every = [p for g in gathered for p in g]
+assert len({len(g) for g in gathered}) == 1 and {i for p in every for i in p} == set(range(20))      # same update count on every rank
+assert sum(len(p) for p in every) <= 20 + 4 * (W - 1)  # the batch grid is filled up to a multiple of W by repeating at most W - 1 batches
+# the columns of the grid are disjoint batches: no batch is trained twice in one update (utils/training_utils.py:99-124)
+for step in range(len(gathered[0])):
+    row = [tuple(g[step]) for g in gathered]
+    assert len(set(row)) == W or sum(len(p) for p in every) > 20, row
 dist.barrier()
 dist.destroy_process_group()
 print('ok', rank)
 '''
 
 
-def test_two_rank_gloo_gradient_sync(tmp_path):
+@pytest.mark.parametrize('world', [2, 8])
+def test_two_rank_gloo_gradient_sync(tmp_path, world):
     import os
     import pathlib
     import socket
@@ -96,8 +102,8 @@ def test_two_rank_gloo_gradient_sync(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER)
     root = pathlib.Path(__file__).resolve().parents[1]
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), PORT=str(port), REPO=str(root)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), PORT=str(port), REPO=str(root), WORLD=str(world), OMP_NUM_THREADS='1'),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
 
@@ -158,9 +164,18 @@ _SYNC_WORKER = r'''
 import os, sys, torch
 sys.path.insert(0, os.environ['REPO'])
 import torch.distributed as dist
-dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + os.environ['PORT'], rank=int(os.environ['RANK']), world_size=2)
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + os.environ['PORT'], rank=int(os.environ['RANK']), world_size=int(os.environ.get('WORLD', '2')))
+W = dist.get_world_size()
 rank = dist.get_rank()
 from some_amd.training.grad_sync import BucketedGradSync
+def same(got, want):
+    """Two addends sum to the same bits in any order; with more ranks gloo's ring adds a bucket's elements in another rank order than
+    the whole buffer's, so the comparison is to fp32 summation order - and the replicas must still hold IDENTICAL bits."""
+    if W == 2:
+        return torch.equal(got, want)
+    every = [torch.empty_like(got) for _ in range(W)]
+    dist.all_gather(every, got)
+    return all(torch.equal(every[0], q) for q in every) and torch.allclose(got, want, rtol=2e-5, atol=2e-6 * float(want.abs().max()))
 # a flat parameter / gradient buffer cut into views, as FlatParams does; "layers" used in order by the forward pass
 sizes = [4096, 64] * 4
 offs, pos = [], 0
@@ -201,7 +216,7 @@ for skip_last in (False, True):
     local_two = first * 2
     want_two = local_two.clone()
     dist.all_reduce(want_two)
-    assert torch.equal(grad, want_two), (grad - want_two).abs().max()
+    assert same(grad, want_two), (grad - want_two).abs().max()
     # last layers first, in a FIXED descending order (collectives pair up across ranks by issue order): bucket k leaves only after
     # every bucket above it.  The first pass in which the top bucket's parameters get no gradient (skip_last) therefore sends
     # everything from finish(); with static_graph the parameters are then known to be absent and the next pass overlaps again,
@@ -215,7 +230,7 @@ for skip_last in (False, True):
     loss_fn(skip_last).backward()
     in_backward = list(sync.launch_order)
     sync.finish()
-    assert torch.equal(grad, want)
+    assert same(grad, want)
     assert len(in_backward) >= (3 if STATIC or not skip_last else 0) and sync.launch_order == list(reversed(range(len(sync.bounds))))
 # a parameter counted as absent that reports after all (skip_last -> full model): its gradient is in the buffer before its bucket
 # leaves - correct result, and it is no longer absent afterwards
@@ -228,7 +243,7 @@ grad.zero_()
 sync.arm()
 loss_fn(False).backward()
 sync.finish()
-assert torch.equal(grad, want) and sync.absent == set()
+assert same(grad, want) and sync.absent == set()
 if not STATIC:
     # a gradient path that switches on and off from step to step, DIFFERENTLY on the two ranks: never an error, always the sum
     for step in range(6):
@@ -241,7 +256,7 @@ if not STATIC:
         sync.arm()
         loss_fn(skip).backward()
         sync.finish()
-        assert torch.equal(grad, want), step
+        assert same(grad, want), step
         assert sync.launch_order == list(reversed(range(len(sync.bounds))))
 # a parameter that reports twice in one armed pass raises instead of launching its bucket early
 sync.arm()
@@ -263,8 +278,8 @@ print('ok', rank)
 '''
 
 
-@pytest.mark.parametrize('static_graph', [False, True])
-def test_bucketed_gradient_sync_overlaps_backward_and_equals_one_all_reduce(tmp_path, static_graph):
+@pytest.mark.parametrize('static_graph,world', [(False, 2), (True, 2), (False, 8), (True, 8)])
+def test_bucketed_gradient_sync_overlaps_backward_and_equals_one_all_reduce(tmp_path, static_graph, world):
     """grad_sync.BucketedGradSync on gloo, world size 2 (CPU): buckets are launched from inside the backward pass, last
     layers first; the reduced flat gradient equals a single all-reduce bit for bit, with gradient accumulation and with
     parameters that receive no gradient."""
@@ -277,8 +292,8 @@ def test_bucketed_gradient_sync_overlaps_backward_and_equals_one_all_reduce(tmp_
     script = tmp_path / 'sync_worker.py'
     script.write_text(_SYNC_WORKER)
     root = pathlib.Path(__file__).resolve().parents[1]
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), PORT=str(port), REPO=str(root), STATIC=str(int(static_graph))),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), PORT=str(port), REPO=str(root), STATIC=str(int(static_graph)), WORLD=str(world), OMP_NUM_THREADS='1'),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
 
@@ -287,9 +302,18 @@ _MARK_WORKER = r'''
 import os, sys, torch
 sys.path.insert(0, os.environ['REPO'])
 import torch.distributed as dist
-dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + os.environ['PORT'], rank=int(os.environ['RANK']), world_size=2)
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + os.environ['PORT'], rank=int(os.environ['RANK']), world_size=int(os.environ.get('WORLD', '2')))
+W = dist.get_world_size()
 rank = dist.get_rank()
 from some_amd.training.grad_sync import BucketedGradSync
+def same(got, want):
+    """Two addends sum to the same bits in any order; with more ranks gloo's ring adds a bucket's elements in another rank order than
+    the whole buffer's, so the comparison is to fp32 summation order - and the replicas must still hold IDENTICAL bits."""
+    if W == 2:
+        return torch.equal(got, want)
+    every = [torch.empty_like(got) for _ in range(W)]
+    dist.all_gather(every, got)
+    return all(torch.equal(every[0], q) for q in every) and torch.allclose(got, want, rtol=2e-5, atol=2e-6 * float(want.abs().max()))
 sizes = [4096, 64] * 4
 offs, pos = [], 0
 for n in sizes:
@@ -350,7 +374,7 @@ for which in (sync, wide):
         order = list(which.launch_order)
         fired = list(which.fire_order)
         which.finish()
-        assert torch.equal(grad, want), (sink_layers, float((grad - want).abs().max()))
+        assert same(grad, want), (sink_layers, float((grad - want).abs().max()))
         assert order == list(reversed(range(len(which.bounds)))), order              # every bucket launched from inside backward, last layers first
         assert sorted(fired) == list(range(8)) and which.unreported() == []          # every parameter counted exactly once
         assert sum(which.echoed) == 2 * len(sink_layers)                             # the hooks behind the marks were seen and ignored
@@ -359,7 +383,8 @@ print('ok', rank)
 '''
 
 
-def test_gradient_sync_mark_stands_in_for_the_hook(tmp_path):
+@pytest.mark.parametrize('world', [2, 8])
+def test_gradient_sync_mark_stands_in_for_the_hook(tmp_path, world):
     """BucketedGradSync.mark(param): a backward function that writes a parameter's gradient into the flat buffer itself and returns
     None for it (TrainOps' gradient sinks) reports the parameter through mark() instead of autograd's post-accumulate hook.  gloo,
     world size 2, CPU: any mix of marked and autograd-accumulated parameters - also inside one bucket - gives the single all-reduce
@@ -375,8 +400,8 @@ def test_gradient_sync_mark_stands_in_for_the_hook(tmp_path):
     script = tmp_path / 'mark_worker.py'
     script.write_text(_MARK_WORKER)
     root = pathlib.Path(__file__).resolve().parents[1]
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), PORT=str(port), REPO=str(root)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), PORT=str(port), REPO=str(root), WORLD=str(world), OMP_NUM_THREADS='1'),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
 

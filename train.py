@@ -64,7 +64,8 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
     work = (pathlib.Path(work_dir) if work_dir else pathlib.Path(__file__).parent / 'experiments') / exp_name
     assert not work.exists() or work.is_dir(), f'Path \'{work}\' is not a directory.'
     world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local)
+    dev = local % max(1, torch.cuda.device_count())        # one GPU per rank; ranks sharing a GPU only in dry runs (SOME_AMD_DIST_BACKEND=gloo)
+    torch.cuda.set_device(dev)
     if world > 1:
         from some_amd import sharding
         sharding.bind_rank_to_cores(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))       # loader threads stay next to this rank's GPU
@@ -73,7 +74,7 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
         work.mkdir(parents=True, exist_ok=True)
         with open(work / 'config.yaml', 'w', encoding='utf8') as f:
             yaml.safe_dump(cfg, f)
-    trainer = TRAINERS[cfg['task_cls']](cfg, device=f'cuda:{local}', seed=cfg.get('seed', 114514))
+    trainer = TRAINERS[cfg['task_cls']](cfg, device=f'cuda:{dev}', seed=cfg.get('seed', 114514))
     if synthetic > 0:
         rng_len = torch.Generator().manual_seed(1)
         seconds = [4.0 + 8.0 * torch.rand((), generator=rng_len).item() for _ in range(synthetic)]
