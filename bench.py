@@ -92,7 +92,7 @@ def _live_pmc(kernel_name: str, config_args) -> dict:
     if key is None or exe is None or os.environ.get('SOME_AMD_BENCH_CHILD'):
         return {}
     child = [sys.executable, str(ROOT / 'bench.py'), '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--no-kernel-profile', '--no-latency',
-             '--no-f32-leg', '--no-secondary', '--no-live-pmc', '--no-e2e', '--no-train'] + list(config_args)
+             '--no-f32-leg', '--no-secondary', '--no-live-pmc', '--no-e2e', '--no-train', '--no-calibration'] + list(config_args)
     # (a child must not join the parent's process group: drop the torch.distributed.run variables)
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'GROUP_RANK',
                                                               'LOCAL_WORLD_SIZE', 'ROLE_RANK', 'ROLE_WORLD_SIZE') and not k.startswith('TORCHELASTIC')}
@@ -159,7 +159,8 @@ def main():
     ap.add_argument('--no-latency', action='store_true', help='skip the B=1 p50 latency leg')
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the secondary exact-f32 measurement')
     ap.add_argument('--no-secondary', action='store_true', help='skip the quant_two_head_model (BASELINE configs[2]) leg')
-    ap.add_argument('--cpu-clips', type=int, default=4, help='clips in the bounded CPU-baseline sample')
+    ap.add_argument('--cpu-clips', type=int, default=10, help='clips in the bounded CPU-baseline sample (N-thread figure)')
+    ap.add_argument('--cpu-single-thread-seconds', type=float, default=10.0, help='length of the one clip the 1-thread CPU figure runs')
     ap.add_argument('--no-live-pmc', action='store_true', help='skip the rocprofv3 --pmc child passes for roofline.traffic / MFMA-busy')
     ap.add_argument('--no-e2e', action='store_true', help='skip the whole-command leg of BASELINE configs[3]: batch_infer.py over --e2e-rows '
                     'synthetic 30 s WAVs on disk -> CSV (tools/batch_infer_bench.py), both arithmetic modes, rows re-checked one by one')
@@ -170,6 +171,8 @@ def main():
     ap.add_argument('--train-hours', type=float, default=3.0)
     ap.add_argument('--e2e', action='store_true', help=argparse.SUPPRESS)       # round-3 opt-in spellings: the legs are on by default now
     ap.add_argument('--train', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--no-calibration', action='store_true', help='skip the box calibration leg (some_box_calibrate, untimed, before the main loop)')
+    ap.add_argument('--calibration-seconds', type=float, default=0.4)
     ap.add_argument('--scratch', default='/tmp/some_amd_bench', help='directory for the datasets of the --e2e / --train legs')
     args = ap.parse_args()
 
@@ -246,6 +249,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    # ---- box calibration (untimed, before the main loop): what THIS GPU sustains on a pure f16 MFMA stream under its power limit and
+    # on a float4 copy - boxes of this pool have run the same binary at 81.5 - 85.4 ms per step (power-limited clocks differ per package)
+    box = None
+    if not args.no_calibration:
+        import ctypes
+        lib = _lib.load()
+        tf, mhz, gbs = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        rc = lib.some_box_calibrate(args.calibration_seconds, ctypes.addressof(tf), ctypes.addressof(mhz), ctypes.addressof(gbs),
+                                    torch.cuda.current_stream(device).cuda_stream)
+        if rc == 0:
+            box = {'mfma_tf': round(tf.value, 1), 'mfma_effective_mhz': round(mhz.value), 'copy_gbs': round(gbs.value, 1),
+                   'seconds': args.calibration_seconds,
+                   'what': 'pure v_mfma_f32_32x32x16_f16 stream on random operands (issued TFLOP/s under the package power limit; clock = '
+                           'TF / (1024 SIMDs x 1024 FLOP per SIMD-cycle)) and a 1 GiB float4 copy (read + written), some_box_calibrate'}
+        else:
+            box = {'error': f'some_box_calibrate returned {rc}'}
+
     for _ in range(args.warmup):
         out = step()
     sync_all()
@@ -284,6 +304,8 @@ def main():
     }
     if dist is not None:
         result['process_group'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size()}
+    if box is not None:
+        result['box'] = box
 
     if rank == 0:
         # ---- per-kernel leg: HIP events around every launch on the launch stream (some_profile_*) -------
@@ -355,6 +377,21 @@ def main():
                         'unit': 'TFLOP/s', 'frac': round(dom['tflops'] / F32_MATRIX_PEAK_TFLOPS, 4), 'traffic': None,
                         'avg_launch_ms': dom['avg_ms'], 'algorithmic_flops_per_launch': round(flops_per_launch),
                     }
+        # ---- value normalised to the reference box (profiles/box_reference.json: the median calibration of the boxes measured so far) ----
+        # model: the step's matrix-bound share scales with the box's sustained MFMA rate, its HBM-bound share with the copy rate; shares
+        # from this run's own per-kernel leg (kernels with a FLOP count vs kernels with a byte count)
+        if box is not None and 'mfma_tf' in box:
+            try:
+                ref = json.loads((ROOT / 'profiles' / 'box_reference.json').read_text())
+                ks = result.get('kernels') or []
+                w_m = sum(k['share'] for k in ks if 'tflops' in k) if ks else ref['default_matrix_share']
+                w_h = 1.0 - w_m
+                scale = w_m * box['mfma_tf'] / ref['mfma_tf'] + w_h * box['copy_gbs'] / ref['copy_gbs']      # > 1: a faster box than the reference
+                result['box'].update(reference=ref, matrix_share=round(w_m, 4), speed_vs_reference=round(scale, 4))
+                result['value_normalised'] = round(value / scale, 2)
+                result['ms_per_step_normalised'] = round(ms_per_step * scale, 3)
+            except (OSError, KeyError, ValueError, ZeroDivisionError):
+                pass
         # ---- p50 single-clip latency (B = 1, the reference's own granularity) ---------------------------
         one = ClipBatch.from_sample_counts([len(clips[0])], eng.hop, device)
         a1 = torch.from_numpy(clips[0]).to(device)
@@ -419,25 +456,41 @@ def main():
                 'steps': args.steps, 'model_tflops': round((dq + aq) * batch.total_frames / dtq / 1e12, 2)}
             del eng_q
         # ---- CPU baseline: the oracle (port of the reference CPU path), bounded sample, rank 0, N = 1 ---
+        # SURVEY 8(d) protocol: B = 1 per clip exactly as BaseInference.infer (inference/base_infer.py:46-53), an N-thread AND a 1-thread
+        # figure, the stages (mel / forward / decode) timed separately, >= 10 clips for the N-thread figure
         if world == 1 and not args.no_cpu_baseline:
             from oracle import restate
             # B = 1 conformer inference scales poorly past ~32 threads on a 2-socket host (measured on the MI355X
             # box, 2 x EPYC 9575F: 8 -> 8.2, 16 -> 9.2, 32 -> 10.7, 64 -> 6.9, 128 -> 3.0 audio-s/s): use the best
             threads = min(32, torch.get_num_threads())
-            torch.set_num_threads(threads)
             sd_t = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
-            restate.infer_clip(sd_t, cfg, clips[0][: sr * 2], quantized=quant)            # warm-up (2 s)
-            tc = time.perf_counter()
-            for i in range(args.cpu_clips):
-                restate.infer_clip(sd_t, cfg, clips[i % n_distinct], quantized=quant)      # B = 1 per clip, as the reference
-            dt = time.perf_counter() - tc
+
+            def cpu_leg(n_threads, n_clips, seconds):
+                torch.set_num_threads(n_threads)
+                n_samp = int(round(seconds * sr))
+                restate.infer_clip(sd_t, cfg, clips[0][: sr * 2], quantized=quant)            # warm-up (2 s)
+                stages = {'mel': 0.0, 'forward': 0.0, 'decode': 0.0}
+                tc = time.perf_counter()
+                for i in range(n_clips):
+                    r = restate.infer_clip(sd_t, cfg, clips[i % n_distinct][:n_samp], quantized=quant)      # B = 1 per clip, as the reference
+                    for k2, v2 in r['_stage_s'].items():
+                        stages[k2] += v2
+                dt = time.perf_counter() - tc
+                return {'value': round(n_clips * seconds / dt, 2), 'unit': 'audio-s/s', 'threads': n_threads, 'clips': n_clips,
+                        'clip_seconds': seconds, 'wall_s': round(dt, 2), 'stage_s_per_clip': {k2: round(v2 / n_clips, 4) for k2, v2 in stages.items()}}
+            many = cpu_leg(threads, args.cpu_clips, args.seconds)
+            single = cpu_leg(1, 1, min(args.seconds, args.cpu_single_thread_seconds))
+            torch.set_num_threads(threads)
             result['cpu_baseline'] = {
-                'value': round(args.cpu_clips * args.seconds / dt, 2), 'unit': 'audio-s/s', 'cores': threads,
+                'value': many['value'], 'unit': 'audio-s/s', 'cores': threads,
                 'threads': threads, 'host_cores': os.cpu_count(),      # cores = threads used (the bench contract); the box has host_cores
                 'host_cores_available_to_this_process': len(os.sched_getaffinity(0)),
                 'kind': 'port',
                 'sample': f'{args.cpu_clips} x {args.seconds:g} s clips of the same workload, B=1 per clip '
-                          f'(log-mel + forward + decode), torch-CPU fp32 oracle, {threads} threads',
+                          f'(log-mel + forward + decode), torch-CPU fp32 oracle, {threads} threads; one_thread: 1 x '
+                          f'{single["clip_seconds"]:g} s clip on 1 thread',
+                'stage_s_per_clip': many['stage_s_per_clip'], 'wall_s': many['wall_s'],
+                'one_thread': single,
             }
         whole_command_legs = world == 1 and default_workload and not os.environ.get('SOME_AMD_BENCH_CHILD')
         if whole_command_legs and not args.no_e2e:

@@ -534,6 +534,14 @@ int some_profile_enable(SomeHandle* h, int32_t on);
 /* Synchronises the recorded events, accumulates and returns up to max_stats entries; resets the log. */
 int some_profile_collect(SomeHandle* h, SomeKernelStat* stats, int32_t max_stats, int32_t* n_stats);
 
+/* ---- box calibration (measurement only) -------------------------------------------------------------- */
+
+/* What THIS GPU sustains on the two resources the hot path is bound by, for comparing bench lines across boxes (bench.py `box`):
+ * a pure v_mfma_f32_32x32x16_f16 stream on random operands under the package power limit (issued TFLOP/s and the effective clock
+ * it implies: TF / (1024 SIMDs x 1024 FLOP per SIMD-cycle)) and a float4 copy of 1 GiB (GB/s, read + written).  Runs for about
+ * `seconds` (0 < seconds <= 30) on `stream`, allocates ~2 GiB of its own for the duration of the call, synchronises. */
+int some_box_calibrate(double seconds, double* mfma_tflops, double* mfma_mhz, double* copy_gbs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

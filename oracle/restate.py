@@ -324,9 +324,15 @@ def infer_clip(sd, config, waveform: np.ndarray, quantized=None):
     """BaseInference.infer body for one waveform (base_infer.py:46-53): preprocess -> forward -> postprocess."""
     if quantized is None:
         quantized = config['task_cls'].endswith('QuantizedMIDIExtractionTask')
+    import time
+    t0 = time.perf_counter()
     units = logmel(waveform, config)
+    t1 = time.perf_counter()
     probs, bounds = model_forward(sd, config, units, mask=np.ones(units.shape[0], dtype=bool),
                                   softmax=quantized, sig=not quantized)
+    t2 = time.perf_counter()
     res = postprocess(probs.numpy(), bounds.numpy(), config, quantized=quantized)
+    t3 = time.perf_counter()
     res['_units'], res['_probs'], res['_bounds'] = units, probs.numpy(), bounds.numpy()
+    res['_stage_s'] = {'mel': t1 - t0, 'forward': t2 - t1, 'decode': t3 - t2}       # SURVEY 8(d): the CPU path's stages timed separately
     return res

@@ -136,6 +136,7 @@ SYMBOLS = {
     'some_op_dwconv_silu': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     'some_profile_enable': (C.c_int, [_P, C.c_int32]),
     'some_profile_collect': (C.c_int, [_P, C.POINTER(SomeKernelStat), C.c_int32, C.POINTER(C.c_int32)]),
+    'some_box_calibrate': (C.c_int, [C.c_double, _P, _P, _P, _P]),
 }
 
 _lib = None
@@ -191,6 +192,14 @@ def fast():
     except ImportError as e:                      # built for another interpreter: the binding is optional, the library is not
         import warnings
         warnings.warn(f'some_amd/_fastcall.so does not import ({e}); using the ctypes binding (rebuild: python -m some_amd.build)')
+        _fast = lib
+        return lib
+    from .fastcall_gen import table_digest
+    built_from = _fastcall.digest() if hasattr(_fastcall, 'digest') else None
+    if built_from != table_digest(SYMBOLS):       # generated from another SYMBOLS table: an argument of another width would be marshalled wrongly
+        import warnings
+        warnings.warn('some_amd/_fastcall.so was generated from a different _lib.SYMBOLS table; using the ctypes binding '
+                      '(rebuild: python -m some_amd.build)')
         _fast = lib
         return lib
     ns = types.SimpleNamespace()

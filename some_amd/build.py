@@ -16,7 +16,7 @@ HERE = pathlib.Path(__file__).resolve().parent
 CSRC = HERE / 'csrc'
 OBJ = CSRC / 'build'
 LIB = HERE / 'libsome_amd.so'
-SOURCES = ['api.hip', 'gemm.hip', 'gemm_f16x3.hip', 'rowops.hip', 'attention.hip', 'attention_f16x3.hip', 'dwconv.hip', 'logmel.hip', 'logmel_shift.hip', 'decode.hip', 'ingest.hip', 'train_ops.hip', 'train_attention.hip', 'train_attention_f16x3.hip', 'train_gemm16s.hip', 'train_api.hip']
+SOURCES = ['api.hip', 'gemm.hip', 'gemm_f16x3.hip', 'rowops.hip', 'attention.hip', 'attention_f16x3.hip', 'dwconv.hip', 'logmel.hip', 'logmel_shift.hip', 'decode.hip', 'ingest.hip', 'train_ops.hip', 'train_attention.hip', 'train_attention_f16x3.hip', 'train_gemm16s.hip', 'train_api.hip', 'calibrate.hip']
 HEADERS = [CSRC / 'internal.h', CSRC / 'fft_core.h', CSRC / 'split.h', CSRC / 'rms_core.h', HERE.parent / 'include' / 'some_amd.h']
 ARCH = 'gfx950'
 # per-source additions.  attention_f16x3.hip: without SLP vectorisation hipcc keeps the softmax's fp32 adds / multiplies scalar -

@@ -727,6 +727,7 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (timeline builds: how long the tile DMA is waited for)
         const unsigned long long t_land = __builtin_amdgcn_s_memtime();
 #endif
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA completion is tracked by vmcnt: a tile must have LANDED before the barrier publishes it (explicit - not left to what hipcc emits around __syncthreads)
         if (!(kAbl & 8)) __syncthreads();
 #ifdef SOME_ATTN_DBG
         if (dbg_wg && lane == 0) {
@@ -761,6 +762,7 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
             for (int p = 0; p < 4; ++p) gload_k1(2, p);
         }
     }
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA completion is tracked by vmcnt: a tile must have LANDED before the barrier publishes it (explicit - not left to what hipcc emits around __syncthreads)
     __syncthreads();
     f32x16 sa0, sa1, sb0, sb1;
     // A wavefront whose 32 queries all lie behind the clip's end (the last 128-query block of a clip: T = 2584 leaves 24 queries for
@@ -818,6 +820,7 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
                     if (i + 2 < n) gload_v1(i + 2, p);
                 }
             }
+            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA completion is tracked by vmcnt: a tile must have LANDED before the barrier publishes it (explicit - not left to what hipcc emits around __syncthreads)
             __syncthreads();
         }
     }

@@ -645,6 +645,14 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ x, co
             if (dx) for (int j = lane; j < N; j += 64) dx[(size_t)row * N + j] = 0.f;
             continue;
         }
+        if (t < 0 || t >= N) {
+            // a class outside [0, N) that is not ignore_index (torch device-asserts here: nn.CrossEntropyLoss, me_quant_task.py:13-78): never
+            // an out-of-bounds read - the loss AND this row's gradient become NaN, which the trainer's gradient-norm check reports as a
+            // non-finite update (e.g. a quantised dataset with class 128 under a config whose midi_num_bins is not 129)
+            if (lane == 0) acc += (double)NAN;
+            if (dx) for (int j = lane; j < N; j += 64) dx[(size_t)row * N + j] = NAN;
+            continue;
+        }
         float mx = -INFINITY;
         for (int j = lane; j < N; j += 64) mx = fmaxf(mx, xr[j]);
 #pragma unroll

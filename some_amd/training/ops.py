@@ -74,6 +74,13 @@ class TrainOps:
         self._wg_active = False                    # inside Tape.backward with the pairs registered
         self._wg_pending = [False, False]          # lane i's side stream has work nobody has waited for
         self._wg_keep: list = []                   # operands of the weight-gradient launches in flight on the side streams
+        # ... released as the side streams get through them, not at the end of the pass: every _WG_MARK_EVERY calls an event goes onto each
+        # busy side stream, and the operands issued before a mark are dropped once its events have completed (peak backward memory
+        # would otherwise grow with depth: ~1 GB at 8 x 520 frames, > 10 GB at max_batch_frames = 80 000 - ADVICE r05)
+        self._wg_marks: list = []                  # [(entries of _wg_keep covered, [events])] in issue order
+        self._wg_dropped = 0                       # entries of this pass already released (marks count from the start of the pass)
+        self._wg_since_mark = 0
+        self._wg_event_pool: list = []
         self._wg_events = [None, None]
         self._lane = 0
         self._lane_streams = [None, None]          # torch streams of the pinned step: [the caller's, the helper]
@@ -435,6 +442,28 @@ class TrainOps:
         if self._wg_active:
             self._wg_pending[self._lane] = True
             self._wg_keep.append(operands)
+            self._wg_since_mark += 1
+            if self._wg_since_mark >= self._WG_MARK_EVERY:
+                self._wg_mark()
+
+    _WG_MARK_EVERY = 16
+
+    def _wg_mark(self):
+        """An event on every side stream that has work; everything kept so far may go once those events have completed (the side
+        streams run in order, so a completed mark covers every call issued before it).  Completed marks at the head are retired here."""
+        self._wg_since_mark = 0
+        evs = []
+        for i in range(self.lanes):
+            if self._wg_pending[i]:
+                ev = self._wg_event_pool.pop() if self._wg_event_pool else torch.cuda.Event()
+                ev.record(self._wg_streams[i])
+                evs.append(ev)
+        self._wg_marks.append((self._wg_dropped + len(self._wg_keep), evs))
+        while self._wg_marks and all(e.query() for e in self._wg_marks[0][1]):
+            covered, done = self._wg_marks.pop(0)
+            del self._wg_keep[:covered - self._wg_dropped]
+            self._wg_dropped = covered
+            self._wg_event_pool.extend(done)
 
     def join_wgrad(self):
         """The current lane waits for the weight-gradient launches issued so far on every lane's side stream."""
@@ -462,6 +491,10 @@ class TrainOps:
             self._wg_active = False
             self._wg_pending = [False, False]
             self._wg_keep.clear()
+            for _, evs in self._wg_marks:
+                self._wg_event_pool.extend(evs)
+            self._wg_marks.clear()
+            self._wg_dropped = self._wg_since_mark = 0
 
     def check(self, rc):
         if rc:

@@ -832,6 +832,17 @@ def test_cross_entropy_kernel_matches_torch():
     assert float(x.grad[::5].abs().max()) == 0.0
     none = ops.cross_entropy(x.detach(), torch.full_like(t, -1), ignore_index=-1)
     assert torch.isnan(none)
+    # a class outside [0, N) that is not ignore_index (torch device-asserts): no out-of-bounds read - the loss and that row's gradient
+    # turn NaN, every other row keeps its gradient, and the trainer's gradient-norm check reports the update as non-finite
+    bad = t.clone()
+    bad[3], bad[4] = 129, -7
+    xb = x.detach().clone().requires_grad_()
+    lb = ops.cross_entropy(xb, bad, ignore_index=-1)
+    lb.backward()
+    assert torch.isnan(lb) and torch.isnan(xb.grad[3]).all() and torch.isnan(xb.grad[4]).all()
+    rest = torch.ones(301, dtype=torch.bool, device='cuda')
+    rest[3] = rest[4] = False
+    assert torch.isfinite(xb.grad[rest]).all()
 
 
 def test_cli_train_quantized_task_then_infer(tmp_path):
