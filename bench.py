@@ -406,6 +406,20 @@ def main():
             lat.append(time.perf_counter() - t1)
         if lat:
             result['p50_clip_latency_ms'] = round(1e3 * float(np.median(lat[2:])), 3)
+            # the same clip through ONE hipGraph launch (Engine.graph_runner: repeated batch shapes; bit-identical outputs)
+            try:
+                runner = eng.graph_runner(a1, one, head_mode=head, quantized=quant)
+                glat = []
+                for i in range(10):
+                    torch.cuda.synchronize(device)
+                    t1 = time.perf_counter()
+                    runner(a1)
+                    torch.cuda.synchronize(device)
+                    glat.append(time.perf_counter() - t1)
+                result['p50_clip_latency_graph_replay_ms'] = round(1e3 * float(np.median(glat[2:])), 3)
+                del runner
+            except RuntimeError as e:
+                result['p50_clip_latency_graph_replay_ms'] = f'capture failed: {e}'[:200]
 
         # ---- the same workload in the exact-f32 arithmetic mode (bit-conservative option), for reference ---------
         if world == 1 and precision_name != 'f32' and not args.no_f32_leg:

@@ -18,6 +18,11 @@
 #include "internal.h"
 #include "split.h"
 
+#ifdef GEMM_TIMELINE
+__device__ unsigned long long* g_gemm_tl;      // [workgroup][wave][8] (tools/gemm_probe.hip)
+__device__ int g_gemm_tl_cap;
+#endif
+
 namespace {
 
 constexpr int LDT = 36;      // LDS row in dwords: 16 (32 hi halves) + 16 (32 lo halves) + 4 pad
@@ -305,15 +310,25 @@ __device__ __forceinline__ void epilogue_tr(const GemmArgs& a, const GemmGroup& 
 
 // TERMS = 3: x = hi + lo on both operands, three products (fp32-equivalent).  TERMS = 1: hi halves only - plain f16 operands
 // with fp32 accumulation on the same SPLIT32 layout (mixed-precision training, some_train_gemm_f16).
-template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3, bool TR = false, bool BF16 = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs a) {
+// STAGES = 2: the double-buffered kernel described above (one workgroup per CU at 256 x 256).  STAGES = 1 (round 6, two workgroups per CU):
+// ONE LDS stage + the register stage, so that a 128 x 256 tile (4 waves of 64 x 128, 55 KB) fits TWICE on a CU - two INDEPENDENT
+// workgroups whose barriers, LDS-write phases and epilogues fall into each other's matrix phases (a VALU-only wavefront issues
+// beside an MFMA wavefront of the same SIMD at no cost to it: profiles/r05_coissue_probe2.md table C; MI355X_MICROARCH.md
+// "an MFMA wave and a VALU-only wave run concurrently").  Same wave tile, same fragment schedule, same product order per output
+// element as the 256 x 256 kernel: bit-identical results.
+template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, int TERMS = 3, bool TR = false, bool BF16 = false, int STAGES = 2>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 1 ? 2 : 1) void hgemm3_kernel(GemmArgs a) {
     static_assert(!BF16 || (TERMS == 1 && !TR), "bf16 hi halves: one-product kernels only (split.h)");
+    static_assert(STAGES == 2 || TERMS == 3, "the single-stage loop is the hand-scheduled three-product one");
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int STAGE = (BM + BN) * LDT;               // dwords
     constexpr int NLD = (BM + BN) * 8 / NT;              // 16-byte chunks per thread per k-block
     static_assert((BM + BN) * 8 % NT == 0, "staging must divide evenly");
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef GEMM_TIMELINE            // tools/gemm_probe.hip: per-workgroup timestamps (s_memtime) of the prologue / k-loop / epilogue
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
     GemmGroup g = a.g[blockIdx.y];
     const int n_tiles = a.n_tiles;
@@ -404,6 +419,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     lstore(0);
     if (nk > 1) gload(1);
     __syncthreads();
+#ifdef GEMM_TIMELINE
+    const unsigned long long tl_t1 = __builtin_amdgcn_s_memtime();
+#endif
 
     const int a_off = (wm * TM * 32 + l31) * LDT + kg * 4;
     const int w_off = (BM + wn * TN * 32 + (TR ? pi32(l31) : l31)) * LDT + kg * 4;
@@ -549,6 +567,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
 #ifdef GEMM_ABLATE_NO_LOOP
     nk = 1;                                              // one k-block: the epilogue alone (plus the prologue loads)
 #endif
+    if constexpr (STAGES == 1) {
+        // one LDS stage: the products of k-block kt read it, a barrier retires the reads, the registers (k-block kt + 1, loaded
+        // during iteration kt - 1) are written over it, the loads of k-block kt + 2 are issued, a second barrier publishes the
+        // writes.  Nothing of THIS workgroup runs on the matrix pipe between the two barriers - the co-resident workgroup does.
+        for (; kt + 1 < nk; ++kt) {
+            compute_staged(0, 0, 2);
+            __syncthreads();
+            lstore(0);
+            if (kt + 2 < nk) gload(kt + 2);
+            __syncthreads();
+        }
+        compute_staged(0, 0, 2);
+    } else {
     for (; kt + 2 < nk; ++kt) {
         if constexpr (TERMS == 3) {
             compute_staged(kt & 1, kt + 2, 0);
@@ -572,7 +603,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
     }
     if constexpr (TERMS == 3) compute_staged(kt & 1, 0, 2);
     else compute(kt & 1);
+    }
 
+#ifdef GEMM_TIMELINE
+    asm volatile("s_nop 0" ::: "memory");
+    const unsigned long long tl_t2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
     // Interior workgroups take the unguarded path (no per-element exec masking).  Residual values are fetched one
     // 32 x 32 MFMA tile (16 per lane) at a time BEFORE that tile's stores: C may alias res (in-place residual
@@ -606,6 +642,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void hgemm3_kernel(GemmArgs
         else
             epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane, wave_lds);
     }
+#ifdef GEMM_TIMELINE
+    {
+        const unsigned long long tl_t3 = __builtin_amdgcn_s_memtime();       // epilogue stores ISSUED
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tl_t4 = __builtin_amdgcn_s_memtime();       // ... and acknowledged
+        const unsigned wg = (blockIdx.y * gridDim.x + blockIdx.x);
+        if (g_gemm_tl != nullptr && lane == 0 && wg < (unsigned)g_gemm_tl_cap) {
+            unsigned long long* o = g_gemm_tl + ((size_t)wg * (NT / 64) + wave) * 8;
+            o[0] = tl_t0; o[1] = tl_t1; o[2] = tl_t2; o[3] = tl_t3; o[4] = tl_t4;
+            o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);               // HW_ID: wave / simd / cu / sh / se
+            o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);              // XCC_ID
+            o[7] = ((unsigned long long)m_tile << 32) | (unsigned)n_tile;
+        }
+    }
+#endif
 }
 
 // ---- ring variant: 128 x 256 tile, 4 waves (2 x 2, each 64 x 128), TWO workgroups per CU -----------------------
@@ -737,6 +788,27 @@ hipError_t launch_ring(const GemmArgs& a, hipStream_t s) {
     constexpr size_t LDS_BYTES = 3 * (size_t)(BM + BN) * 64;
     static DeviceOnce attr_once;
     auto kern = &hgemm3_ring_kernel<EPI, OUT_SPLIT>;
+    if (attr_once.need()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_once.mark();
+    }
+    int n_max = 0;
+    for (int g = 0; g < a.groups; ++g) n_max = a.g[g].N > n_max ? a.g[g].N : n_max;
+    const int m_tiles = (a.M - a.m_begin + BM - 1) / BM, n_tiles = (n_max + BN - 1) / BN;
+    GemmArgs b = a;
+    b.n_tiles = n_tiles;
+    dim3 grid((unsigned)((m_tiles + 7) / 8 * 8 * n_tiles), (unsigned)a.groups, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, s, b);
+    return hipGetLastError();
+}
+
+template <int EPI, bool OUT_SPLIT, bool TR = false>
+hipError_t launch_single(const GemmArgs& a, hipStream_t s) {
+    constexpr int BM = 128, BN = 256;
+    constexpr size_t LDS_BYTES = (size_t)(BM + BN) * LDT * sizeof(float);
+    static DeviceOnce attr_once;
+    auto kern = &hgemm3_kernel<2, 2, 2, 4, EPI, OUT_SPLIT, 3, TR, false, 1>;
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -1112,6 +1184,7 @@ hipError_t launch_epi(const GemmArgs& a, int tile, hipStream_t s) {
         for (int g = 0; g < a.groups; ++g) tr = tr && (a.g[g].N % 64) == 0;
         if (tr) {
             switch (tile) {
+                case 5: return launch_single<EPI, OUT_SPLIT, true>(a, s);
                 case 4: return launch_cfg<2, 2, 1, 2, EPI, OUT_SPLIT, 3, true>(a, s);
                 case 0: return launch_cfg<2, 2, 2, 2, EPI, OUT_SPLIT, 3, true>(a, s);
                 case 1: return launch_cfg<4, 2, 2, 2, EPI, OUT_SPLIT, 3, true>(a, s);
@@ -1124,6 +1197,7 @@ hipError_t launch_epi(const GemmArgs& a, int tile, hipStream_t s) {
         case 0: return launch_cfg<2, 2, 2, 2, EPI, OUT_SPLIT>(a, s);    // 128 x 128, 4 waves
         case 1: return launch_cfg<4, 2, 2, 2, EPI, OUT_SPLIT>(a, s);    // 256 x 128, 8 waves
         case 3: return launch_ring<EPI, OUT_SPLIT>(a, s);               // 128 x 256, 4 waves, DMA ring, 2 workgroups / CU
+        case 5: return launch_single<EPI, OUT_SPLIT>(a, s);             // 128 x 256, 4 waves, ONE LDS stage, 2 workgroups / CU (round 6)
         default: return launch_cfg<4, 2, 2, 4, EPI, OUT_SPLIT>(a, s);   // 256 x 256, 8 waves
     }
 }
@@ -1209,7 +1283,7 @@ hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a_in, bool out_split, 
         tile = blocks(256, 256) >= 512 ? 2 : blocks(256, 128) >= 512 ? 1 : blocks(128, 128) >= 256 ? 0 : 4;
     }
     if (a.k_slices > 1) {
-        if (epi != EPI_NONE || out_split || tile == 3) return hipErrorInvalidValue;
+        if (epi != EPI_NONE || out_split || tile == 3 || tile == 5) return hipErrorInvalidValue;
         return launch_one(epi, a, false, tile, s);
     }
     // Wave quantisation: every workgroup of the 256-row tiles takes the same time and one fits per CU, so a grid
@@ -1217,7 +1291,7 @@ hipError_t launch_gemm_f16x3(GemmEpi epi, const GemmArgs& a_in, bool out_split, 
     // Launch the largest row range whose workgroup count is a whole number of rounds with the big tile and give
     // the remaining rows to the 128 x 128 kernel (two workgroups per CU, a quarter of the time each).
     if (tile >= 2) {
-        const int BM = tile == 3 ? 128 : 256, BN = 256, slots = tile == 3 ? 512 : 256;
+        const int BM = (tile == 3 || tile == 5) ? 128 : 256, BN = 256, slots = (tile == 3 || tile == 5) ? 512 : 256;
         int n_max = 0;
         for (int g = 0; g < a.groups; ++g) n_max = a.g[g].N > n_max ? a.g[g].N : n_max;
         const int per_m = ((n_max + BN - 1) / BN) * a.groups;                 // workgroups per row block

@@ -311,6 +311,15 @@ class Engine:
             _ptr(out['n_notes']), _ptr(f2i), _ptr(val), _ptr(rest), _ptr(sc), sc.numel(), self._stream()))
         return out
 
+    # ---- graph replay of a whole step ------------------------------------------------------------
+    def graph_runner(self, audio: torch.Tensor, batch: ClipBatch, head_mode: int = _lib.HEAD_LOGITS, quantized: bool = False,
+                     reflect: bool = False) -> 'GraphStep':
+        """log-mel -> forward -> decode for ONE batch shape captured into a hipGraph (every entry point only enqueues on the caller's
+        stream, include/some_amd.h): ``runner(new_audio)`` copies the samples into the captured input buffer and replays ~220 launches
+        with one hipGraphLaunch.  For callers that see the same (clip lengths) again and again - fixed-length chunks, the latency leg
+        of bench.py, a service with a chunk-length grid (the reference's loop being replaced: inference/base_infer.py:46-53)."""
+        return GraphStep(self, audio, batch, head_mode, quantized, reflect)
+
     # ---- measurement ----------------------------------------------------------------------------
     def profile_enable(self, on: bool):
         _lib.check(self.handle, self.lib.some_profile_enable(self.handle, 1 if on else 0))
@@ -326,3 +335,41 @@ class Engine:
         out = np.empty((self.indim, 1 + self.c_config.win_size // 2), dtype=np.float32)
         _lib.check(self.handle, self.lib.some_mel_filterbank(self.handle, C.c_void_p(out.ctypes.data)))
         return out
+
+
+class GraphStep:
+    """One captured step of an Engine for a fixed batch shape (see ``Engine.graph_runner``).  Owns its workspace, decode scratch, input and
+    output buffers (the engine may grow or replace its own afterwards); outputs are overwritten by every replay.  Results are bit-identical to
+    the eager calls (same kernels, same launch order per stream; tests/test_gpu_parity.py)."""
+
+    def __init__(self, eng: Engine, audio: torch.Tensor, batch: ClipBatch, head_mode: int, quantized: bool, reflect: bool):
+        assert audio.is_cuda and audio.dtype == torch.float32 and audio.numel() == int(batch.sample_offsets[-1])
+        self.eng, self.batch = eng, batch
+        self.audio = audio.clone()                    # the captured input buffer
+        saved = (eng._ws, eng._scratch)
+        eng._ws = eng._scratch = None                 # buffers of its own, allocated by the warm-up below and kept alive here
+
+        def step():
+            units = eng.logmel(self.audio, batch, reflect=reflect)
+            probs, bounds = eng.forward(units, batch, head_mode=head_mode)
+            out = eng.decode(probs, bounds, batch, quantized=quantized)
+            out['probs'], out['bounds'] = probs, bounds
+            return out
+        try:
+            side = torch.cuda.Stream(eng.device)
+            side.wait_stream(torch.cuda.current_stream(eng.device))
+            with torch.cuda.stream(side):             # warm-up on the capture stream: workspace, helper stream, per-device tables
+                step()
+            side.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side):
+                self.out = step()
+            self._keep = (eng._ws, eng._scratch)
+        finally:
+            eng._ws, eng._scratch = saved
+
+    def __call__(self, audio: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        if audio is not None and audio.data_ptr() != self.audio.data_ptr():
+            self.audio.copy_(audio, non_blocking=True)
+        self.graph.replay()
+        return self.out

@@ -110,6 +110,9 @@ class DsBatchSampler:
         if self.rank < len(spare):
             mine.append(spare[self.rank])
         elif spare:                                            # fewer spare batches than ranks: repeat one of this rank's own
+            if steps == 0:       # the reference divides by zero here (utils/training_utils.py:115): same exception, with the reason
+                raise ZeroDivisionError(f'DsBatchSampler: {len(pool)} batch(es) for {world} replicas - rank {self.rank} has none '
+                                        f'(dataset too small for this world size)')
             mine.append(mine[self.epoch % steps])
         mult = self.required_batch_count_multiple
         if mult > 1 and total % mult != 0:                     # whole gradient-accumulation groups

@@ -214,7 +214,7 @@ def test_dwconv_silu(eng, lens):
 
 
 # ---- 3-term split-f16 GEMM (gemm_f16x3.hip) ----------------------------------------------------------
-@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize('M,N,K', [(128, 128, 32), (300, 512, 512), (257, 1536, 512), (130, 512, 2048), (77, 129, 512), (64, 1, 512), (515, 2048, 512)])
 def test_gemm_f16x3_matches_fp64(eng, M, N, K, tile):
     from some_amd import _lib
@@ -244,7 +244,7 @@ def test_gemm_f16x3_small_magnitudes_need_f16_subnormals(eng):
     assert rel < 2e-5, rel
 
 
-@pytest.mark.parametrize('tile', [0, 2, 3, 4])
+@pytest.mark.parametrize('tile', [0, 2, 3, 4, 5])
 def test_gemm_f16x3_epilogues(eng, tile):
     from some_amd import _lib as L
     g = torch.Generator(device='cuda').manual_seed(50 + tile)
@@ -274,6 +274,34 @@ def test_gemm_f16x3_epilogues(eng, tile):
     mask = (torch.rand(M, device='cuda', generator=g) > 0.2).to(torch.uint8)
     out = _gemm(eng, L.EPI_GLU_RES, A, _interleave_glu(Wg), bias=bgi, res=R, mask=mask, n_out=512, split=True, tile=tile)
     assert (out - (R + glu) * mask[:, None]).abs().max().item() < 2e-5
+
+
+def test_gemm_single_stage_tile_equals_the_double_buffered_tile_bit_for_bit(eng):
+    """Tile 5 (round 6: 128 x 256, ONE LDS stage, two independent workgroups per CU) keeps the 256 x 256 kernel's wave tile, fragment
+    schedule and product order per output element - so every epilogue's output is the big tile's, bit for bit, on ragged shapes too
+    (the packing-invariance gates of the model rest on all tile variants agreeing)."""
+    from some_amd import _lib as L
+    g = torch.Generator(device='cuda').manual_seed(77)
+    M, K = 1000, 512
+    A = torch.randn(M, K, device='cuda', generator=g)
+    W = torch.randn(2048, K, device='cuda', generator=g) / 20
+    b = torch.randn(2048, device='cuda', generator=g)
+    X = torch.randn(M, 512, device='cuda', generator=g)
+    W2 = torch.randn(512, 2048, device='cuda', generator=g) / 40
+    b2 = torch.randn(512, device='cuda', generator=g)
+    Wg = _interleave_glu(torch.randn(1024, K, device='cuda', generator=g) / 20)
+    bg = torch.randn(1024, device='cuda', generator=g)
+    mask = (torch.rand(M, device='cuda', generator=g) > 0.2).to(torch.uint8)
+    outs = {}
+    for tile in (2, 5):
+        h = _gemm(eng, L.EPI_BIAS_SILU, A, W, bias=b, split=True, tile=tile)
+        outs[tile] = [h, _gemm(eng, L.EPI_BIAS_SILU, A, W, bias=b, split=True, tile=tile, out_split=True),
+                      _gemm(eng, L.EPI_BIAS_RES, h, W2, bias=b2, res=X, alpha=0.5, split=True, tile=tile),
+                      _gemm(eng, L.EPI_NONE, A, W, split=True, tile=tile), _gemm(eng, L.EPI_BIAS, A, W, bias=b, split=True, tile=tile),
+                      _gemm(eng, L.EPI_GLU, A, Wg, bias=bg, n_out=512, split=True, tile=tile),
+                      _gemm(eng, L.EPI_GLU_RES, A, Wg, bias=bg, res=X, mask=mask, n_out=512, split=True, tile=tile)]
+    for a, c in zip(outs[2], outs[5]):
+        assert torch.equal(a, c)
 
 
 @pytest.mark.parametrize('lens', [[64], [1], [33], [130, 257], [128, 1, 300, 65], [862], [2584, 100], [2584] * 9 + [64, 200]])
@@ -349,7 +377,7 @@ def test_qkv_attention_f16x3_is_packing_independent(eng):
             assert torch.equal(out[s:s + lens[i]], alone[i]), (order, pos)
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2, 4])
+@pytest.mark.parametrize('tile', [0, 1, 2, 4, 5])
 @pytest.mark.parametrize('epi', ['bias_res', 'bias_silu_split', 'glu_res'])
 def test_gemm_f16x3_never_writes_past_row_m(eng, tile, epi):
     """Partial row tiles (M not a multiple of the tile height): the epilogues rely on the buffer descriptors' range check

@@ -197,7 +197,7 @@ def test_eight_rank_data_parallel_training_equals_eight_micro_batches_on_one_ran
 def test_train_cli_with_eight_gloo_ranks(tmp_path):
     """train.py under torch.distributed.run with 8 ranks on this GPU: DsBatchSampler(num_replicas=8) columns, core binding, the loader
     threads of eight processes, checkpoint from rank 0 - and the checkpoint loads into the inference class."""
-    r = _torchrun(8, [str(ROOT / 'train.py'), '--config', 'two_head_model', '--exp_name', 'w8', '--work_dir', str(tmp_path), '--synthetic', '48',
+    r = _torchrun(8, [str(ROOT / 'train.py'), '--config', 'two_head_model', '--exp_name', 'w8', '--work_dir', str(tmp_path), '--synthetic', '96',
                       '--max_updates', '4', '--log_interval', '1', '--val_clips', '2'], env={'SOME_AMD_DIST_BACKEND': 'gloo'}, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert 'step 4:' in r.stdout and r.stdout.count('step 1:') == 1            # rank 0 alone reports

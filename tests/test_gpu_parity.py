@@ -825,6 +825,38 @@ def test_forward_is_capturable_in_a_hip_graph(engines):
     assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1]) and not torch.equal(out[0], eager[0])
 
 
+def test_graph_runner_replays_the_whole_step_bit_for_bit(engines):
+    """Engine.graph_runner: log-mel -> forward -> decode of one batch shape as ONE hipGraph launch.  New audio through the captured
+    input buffer gives the eager calls' probabilities, bounds and notes bit for bit; the runner owns its workspace - a bigger batch
+    through the same engine afterwards (which replaces the engine's own workspace) does not disturb it."""
+    from some_amd import _lib
+    from some_amd.engine import ClipBatch
+    eng = engines("midi_conformer", 2, 41)
+    clips = [synth.synth_clip(90 + i, 2.3) for i in range(2)]
+    batch = ClipBatch.from_sample_counts([len(c) for c in clips], eng.hop, 'cuda')
+    audio = torch.from_numpy(np.concatenate(clips)).cuda()
+    runner = eng.graph_runner(audio, batch, head_mode=_lib.HEAD_SIGMOID, quantized=False)
+
+    def eager(a, b):
+        pr, bo = eng.forward(eng.logmel(a, b), b, head_mode=_lib.HEAD_SIGMOID)
+        return pr, bo, eng.decode(pr, bo, b, quantized=False)
+    big = [synth.synth_clip(95 + i, 4.0) for i in range(6)]                 # grows the ENGINE's workspace between capture and replay
+    bb = ClipBatch.from_sample_counts([len(c) for c in big], eng.hop, 'cuda')
+    eager(torch.from_numpy(np.concatenate(big)).cuda(), bb)
+    for seed in (90, 120):
+        a = torch.from_numpy(np.concatenate([synth.synth_clip(seed + i, 2.3) for i in range(2)])).cuda()
+        out = runner(a)
+        torch.cuda.synchronize()
+        pr, bo, dec = eager(a, batch)
+        assert torch.equal(out['probs'], pr) and torch.equal(out['bounds'], bo)
+        n = dec['n_notes'].cpu().numpy()
+        assert np.array_equal(out['n_notes'].cpu().numpy(), n) and n.min() > 0
+        for b in range(batch.B):
+            s0 = int(batch.frame_offsets[b])
+            for k in ('note_midi', 'note_dur', 'note_rest'):
+                assert torch.equal(out[k][s0:s0 + int(n[b])], dec[k][s0:s0 + int(n[b])])
+
+
 @pytest.mark.parametrize('quantized', [False, True])
 def test_decode_edge_cases_vs_oracle_bit_exact(quantized):
     """Decode corner cases of utils/infer_utils.py:9-76 on the GPU vs the order-fixed oracle, bit for bit: exact argmax ties (first

@@ -158,6 +158,13 @@ def test_eval_sampler_and_batch_by_size_equal_the_reference(golden_dir):
     assert [list(map(int, b)) for b in got] == g['batch_by_size_multiple']
     with pytest.raises(AssertionError, match='exceeds'):
         batch_by_size([0], lambda i: 5000, max_batch_frames=4000)
+    # fewer batches than replicas: the reference's sampler divides by zero for the ranks left without one (utils/training_utils.py:115);
+    # the same exception type here, naming the cause
+    from some_amd.training.samplers import DsBatchSampler
+    few = _Lengths([100] * 6)
+    assert len(list(DsBatchSampler(few, 20000, 1, num_replicas=8, rank=5, shuffle_sample=True, seed=1))) == 1
+    with pytest.raises(ZeroDivisionError, match='6 batch'):
+        list(DsBatchSampler(few, 20000, 1, num_replicas=8, rank=6, shuffle_sample=True, seed=1))
 
 
 _SYNC_WORKER = r'''

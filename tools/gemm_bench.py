@@ -44,7 +44,7 @@ def main():
             _lib.check(eng.handle, eng.lib.some_op_split_rows(eng.handle, p(A), p(As), M, K, st))
             _lib.check(eng.handle, eng.lib.some_op_split_rows(eng.handle, p(W), p(Ws), N, K, st))
             A, W = As, Ws
-            flags = _lib.GEMM_SPLIT_IN | (args.tile << 8)
+            flags = _lib.GEMM_SPLIT_IN | (args.tile << 8) | (_lib.GEMM_SPLIT_OUT if epi == _lib.EPI_BIAS_SILU else 0)     # FFN1 as the model runs it: SPLIT32 output, row-per-lane epilogue
 
         def run():
             _lib.check(eng.handle, eng.lib.some_op_gemm(eng.handle, epi, p(A), K, p(W), p(bias), p(res), n_out, p(Cm), n_out,

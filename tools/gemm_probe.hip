@@ -1,0 +1,123 @@
+// Timeline of the split-f16 GEMM workgroups (round 6, VERDICT r05 item 1: "or a timeline showing which condition fails").
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DGEMM_TIMELINE -I some_amd/csrc tools/gemm_probe.hip -o tools/_bin/gemm_probe
+// Every workgroup's wavefronts record s_memtime at: kernel entry (t0), behind the prologue barrier - first k-block in LDS, second in
+// registers - (t1), behind the last product (t2), behind the last epilogue store instruction (t3), behind s_waitcnt vmcnt(0) (t4), plus
+// the CU they ran on.  Reported per shape / tile: where a CU's time goes (dispatch gap between consecutive workgroups of a CU,
+// prologue, k-loop, epilogue issue, store drain), in microseconds (the counter is calibrated against the HIP event time of the launch).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../some_amd/csrc/gemm_f16x3.hip"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+static void fill_split(std::vector<uint16_t>& v, float scale, unsigned seed) {
+    srand(seed);
+    for (size_t i = 0; i < v.size(); i += 64) {
+        for (int k = 0; k < 32; ++k) {
+            const float x = ((rand() / (float)RAND_MAX) * 2.f - 1.f) * scale;
+            half_t h, l;
+            split_f16(x, h, l);
+            v[i + k] = __builtin_bit_cast(uint16_t, h);
+            v[i + 32 + k] = __builtin_bit_cast(uint16_t, l);
+        }
+    }
+}
+
+int main(int argc, char** argv) {
+    // row counts that make whole rounds of workgroups for both tiles (no wave-quantisation tail launch to tell apart)
+    struct Shape { const char* name; GemmEpi epi; int N, K; bool out_split; int M; };
+    const Shape shapes[] = {{"ffn1 512->2048 bias+SiLU, SPLIT32 out", EPI_BIAS_SILU, 2048, 512, true, 81920},
+                            {"ffn2 2048->512 bias+residual", EPI_BIAS_RES, 512, 2048, false, 65536},
+                            {"glu 512->2x512", EPI_GLU, 1024, 512, false, 81920}};
+    (void)argc; (void)argv;
+    const int cap = 8192;
+    unsigned long long* tl_d;
+    CK(hipMalloc(&tl_d, (size_t)cap * 8 * 8 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_tl), &tl_d, sizeof(tl_d)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_tl_cap), &cap, sizeof(cap)));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (const Shape& sh : shapes) {
+        const int M = sh.M;
+        std::vector<uint16_t> ha((size_t)M * sh.K * 2), hw((size_t)sh.N * sh.K * 2);
+        fill_split(ha, 1.0f, 1);
+        fill_split(hw, 0.05f, 2);
+        float *A, *W, *bias, *C, *res;
+        const int n_out = sh.epi == EPI_GLU ? sh.N / 2 : sh.N;
+        CK(hipMalloc(&A, ha.size() * 2)); CK(hipMalloc(&W, hw.size() * 2)); CK(hipMalloc(&bias, sh.N * 4));
+        CK(hipMalloc(&C, (size_t)M * n_out * 4)); CK(hipMalloc(&res, (size_t)M * n_out * 4));
+        CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemset(bias, 0, sh.N * 4)); CK(hipMemset(res, 0, (size_t)M * n_out * 4));
+        for (int tile : {2, 5}) {
+            GemmArgs a{};
+            a.g[0] = GemmGroup{A, W, bias, res, C, nullptr, sh.N, 0};
+            a.groups = 1; a.M = M; a.K = sh.K; a.lda = sh.K; a.ldc = n_out; a.ldr = n_out; a.alpha = 0.5f; a.flags = GEMM_FLAG_TR;
+            for (int i = 0; i < 3; ++i) CK(launch_gemm_f16x3(sh.epi, a, sh.out_split, tile, 0));
+            CK(hipDeviceSynchronize());
+            CK(hipMemset(tl_d, 0, (size_t)cap * 8 * 8 * 8));
+            CK(hipEventRecord(e0, 0));
+            CK(launch_gemm_f16x3(sh.epi, a, sh.out_split, tile, 0));
+            CK(hipEventRecord(e1, 0));
+            CK(hipDeviceSynchronize());
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const int waves = tile == 2 ? 8 : 4;
+            std::vector<unsigned long long> tl((size_t)cap * 8 * 8);
+            CK(hipMemcpy(tl.data(), tl_d, tl.size() * 8, hipMemcpyDeviceToHost));
+            // records of wave 0 of every workgroup of the MAIN launch (the tail launch of the wave-quantisation split overwrites the
+            // first slots with its own, smaller, workgroups: told apart by a k-loop that is far shorter)
+            struct Rec { unsigned long long t0, t1, t2, t3, t4; unsigned long long cu; unsigned long long skew; };
+            std::vector<Rec> recs;
+            unsigned long long tmin = ~0ull, tmax = 0;
+            for (int wg = 0; wg < cap; ++wg) {
+                const unsigned long long* o = &tl[((size_t)wg * waves) * 8];
+                if (o[0] == 0) continue;
+                unsigned long long lo2 = ~0ull, hi2 = 0;
+                for (int w = 0; w < waves; ++w) { const unsigned long long t2 = tl[((size_t)wg * waves + w) * 8 + 2]; lo2 = std::min(lo2, t2); hi2 = std::max(hi2, t2); }
+                // HW_ID (gfx9): [11:8] cu_id, [12] sh_id, [15:13] se_id; XCC_ID [3:0]
+                const unsigned long long key = ((o[6] & 0xf) << 16) | ((o[5] >> 8) & 0xff);
+                recs.push_back(Rec{o[0], o[1], o[2], o[3], o[4], key, hi2 - lo2});
+                tmin = std::min(tmin, o[0]); tmax = std::max(tmax, o[4]);
+            }
+            if (recs.empty()) { printf("%s tile %d: no records\n", sh.name, tile); continue; }
+            const double tick_us = ms * 1e3 / (double)(tmax - tmin);          // the launch spans (almost exactly) the event interval
+            std::map<unsigned long long, std::vector<Rec>> per_cu;
+            for (const Rec& r : recs) per_cu[r.cu].push_back(r);
+            double pro = 0, loop = 0, epi = 0, drain = 0, gap = 0, first = 0, skew = 0;
+            size_t n = 0, ngap = 0;
+            for (auto& kv : per_cu) {
+                auto& v = kv.second;
+                std::sort(v.begin(), v.end(), [](const Rec& x, const Rec& y) { return x.t0 < y.t0; });
+                first += (double)(v[0].t0 - tmin);
+                for (size_t i = 0; i < v.size(); ++i) {
+                    pro += (double)(v[i].t1 - v[i].t0); loop += (double)(v[i].t2 - v[i].t1); epi += (double)(v[i].t3 - v[i].t2);
+                    drain += (double)(v[i].t4 - v[i].t3); skew += (double)v[i].skew; ++n;
+                    // next workgroup on the same CU slot: the first that starts after this one ends (two slots per CU for tile 5)
+                    for (size_t j = i + 1; j < v.size(); ++j)
+                        if (v[j].t0 >= v[i].t4) { gap += (double)(v[j].t0 - v[i].t4); ++ngap; break; }
+                }
+            }
+            const double wg_us = (pro + loop + epi + drain) / n * tick_us;
+            printf("%-40s tile %d: %.4f ms, %zu workgroups on %zu CU ids, %.1f workgroups per CU id; counter tick %.4f us\n", sh.name, tile, ms, n,
+                   per_cu.size(), (double)n / per_cu.size(), tick_us);
+            printf("    per workgroup (us): prologue %.2f | k-loop %.2f | epilogue to the last store issued %.2f | store drain %.2f | total %.2f | gap to "
+                   "the next workgroup of the CU slot %.2f | last-product skew between the wavefronts %.2f | first dispatch after launch %.2f\n",
+                   pro / n * tick_us, loop / n * tick_us, epi / n * tick_us, drain / n * tick_us, wg_us, ngap ? gap / ngap * tick_us : 0.0,
+                   skew / n * tick_us, first / per_cu.size() * tick_us);
+            printf("    share of a workgroup's residency: prologue %.1f %% | k-loop %.1f %% | epilogue %.1f %% | drain %.1f %%;  dispatch gap = %.1f %% on top\n",
+                   100 * pro / (pro + loop + epi + drain), 100 * loop / (pro + loop + epi + drain), 100 * epi / (pro + loop + epi + drain),
+                   100 * drain / (pro + loop + epi + drain), ngap ? 100 * (gap / ngap) / ((pro + loop + epi + drain) / n) : 0.0);
+        }
+        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(C)); CK(hipFree(res));
+    }
+    return 0;
+}
