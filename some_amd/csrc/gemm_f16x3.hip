@@ -13,6 +13,7 @@
 // rows (16-byte global loads -> registers -> ds_write_b128 into [rows][36 dwords], conflict-free ds_read_b128);
 // neither operand is converted in this kernel: weights are split once at pack time, activations by the
 // epilogue of whichever kernel produced them (LayerNorm, SiLU epilogue below, attention, dwconv).
+#include <atomic>
 #include <type_traits>
 
 #include "internal.h"
@@ -55,7 +56,9 @@ __device__ __forceinline__ uint32_t pack_split_pair(float v, int lane) {
     return (lane & 1) ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, bool FULL>
+// PFMAX: residual look-ahead in tiles of 16 values per lane (the persistent kernel, whose staging registers stay live across the
+// epilogue, takes 2)
+template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, bool FULL, int PFMAX = 3>
 __device__ __forceinline__ void epilogue(const GemmArgs& a, const GemmGroup& g, f32x16 (&acc)[TM][TN], int m0, int n0,
                                          int wm, int wn, int lane, char* wave_lds = nullptr) {
     const int l31 = lane & 31, hi = lane >> 5;
@@ -69,7 +72,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const GemmGroup& g, 
         // residual rows are fetched kPrefetch tiles ahead of the tile being finished (C may alias res, so the compiler
         // keeps every load behind the earlier tiles' stores: without the explicit look-ahead each tile pays a full
         // memory round trip)
-        constexpr int NTILE = (TN / 2) * TM, PF = NTILE < 3 ? NTILE : 3;
+        constexpr int NTILE = (TN / 2) * TM, PF = NTILE < PFMAX ? NTILE : PFMAX;
         auto tile_np = [&](int t) { return n0 + (wn * TN + 2 * (t / TM)) * 32 + l31; };
         auto load_res = [&](int t, float (&dst)[16]) {
             const int np = tile_np(t);
@@ -175,7 +178,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const GemmGroup& g, 
         }
     } else {
         const __amdgpu_buffer_rsrc_t rres = make_rsrc(EPI == EPI_BIAS_RES ? (const void*)g.res : (const void*)g.C, (size_t)a.M * row_r);
-        constexpr int NTILE = TN * TM, PF = NTILE < 3 ? NTILE : 3;      // residual look-ahead, see the GLU path
+        constexpr int NTILE = TN * TM, PF = NTILE < PFMAX ? NTILE : PFMAX;      // residual look-ahead, see the GLU path
         auto load_res = [&](int t, float (&dst)[16]) {
             const int n = n0 + (wn * TN + t / TM) * 32 + l31;
             const bool nv = FULL || n < g.N;
@@ -657,6 +660,258 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 1 ? 2 : 1) void h
         }
     }
 #endif
+}
+
+// ---- persistent stream variant of the 256 x 256 kernel (round 6) ---------------------------------------------------------
+// What the workgroup timeline of the kernel above shows (tools/gemm_probe.hip, profiles/r06_gemm_timeline.txt): of a workgroup's
+// residency on its CU the FFN1 shape spends 8 % in the PROLOGUE (first k-block: HBM / L2 latency with nothing to overlap it - one
+// workgroup per CU) and the CU then waits another 9 % of that time for the NEXT workgroup to be dispatched (147 KB of LDS, 8
+// wavefronts); pw1 + GLU 10 % + 5 %, FFN2 2 % + 3 %.  Here one workgroup per CU stays resident and walks the tiles that the
+// non-persistent grid would have handed to it (virtual block vb = blockIdx.x + r gridDim.x, the same vb -> (XCD, row tile,
+// column tile) map), and its k-blocks form ONE stream across tile boundaries: the last two iterations of a tile already load /
+// store the first two k-blocks of the next tile (second offset set), so the pipeline never drains - the epilogue runs with the
+// next tile's first k-block in LDS and its second in flight into the staging registers.  Same products in the same order per
+// output element: bit-identical to the kernel above (tests/test_gpu_kernels.py).  nk must be even (stream position parity = LDS
+// buffer) and >= 4; no split-K.
+template <int EPI, bool OUT_SPLIT, bool TR = false>
+__global__ __launch_bounds__(512) void hgemm3p_kernel(GemmArgs a) {
+    constexpr int WAVES_M = 4, WAVES_N = 2, TM = 2, TN = 4;
+    constexpr int NT = 512, BM = 256, BN = 256;
+    constexpr int STAGE = (BM + BN) * LDT;               // dwords
+    constexpr int NLD = (BM + BN) * 8 / NT;              // 8 chunks of 16 bytes per thread and k-block
+    constexpr int RPP = NT / 8;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef GEMM_TIMELINE
+    unsigned long long tl_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    const GemmGroup g = a.g[blockIdx.y];
+    // (scalars out of the argument block: lambdas that loop over `a.` fields make hipcc keep a copy of the whole block in scratch)
+    const int n_tiles = a.n_tiles;
+    const int vb_count = a.vb_count;                     // virtual blocks of one group: ((m_tiles + 7) / 8 * 8) n_tiles
+    const int a_M = a.M, a_mbeg = a.m_begin, g_N = g.N, stride = (int)gridDim.x;
+    const uint32_t row_a = (uint32_t)a.lda * 4u, row_w = (uint32_t)a.K * 4u;
+    const int32_t* __restrict__ row_map = a.row_map;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int nk = a.K >> 5;
+
+    // virtual block -> tile origin (the map of hgemm3_kernel); false: the block lies outside the matrix
+    auto origin = [=](int vb, int& m0, int& n0) -> bool {
+        const int xcd = vb & 7, j = vb >> 3;
+        m0 = a_mbeg + ((j / n_tiles) * 8 + xcd) * BM;
+        n0 = (j % n_tiles) * BN;
+        return m0 < a_M && n0 < g_N;
+    };
+    auto next_valid = [=](int vb, int& m0, int& n0) -> int {      // first valid virtual block of this workgroup at or behind vb
+        while (vb < vb_count && !origin(vb, m0, n0)) vb += stride;
+        return vb;
+    };
+
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(g.A, (size_t)a.a_rows * a.lda * 4);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(g.W, (size_t)g.N * a.K * 4);
+    const int srow = tid >> 3, scol = tid & 7;
+    auto offsets = [=](int m0, int n0, uint32_t (&vo)[NLD]) {
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+            const int row = srow + p * RPP;
+            if (row < BM) {
+                if (row_map != nullptr) {                // row gather (QKV projection into clip-aligned rows)
+                    const int src = m0 + row < a_M ? row_map[m0 + row] : -1;
+                    vo[p] = src >= 0 ? (uint32_t)src * row_a + scol * 16u : kOob;
+                } else {
+                    vo[p] = (uint32_t)(m0 + row) * row_a + scol * 16u;
+                }
+            } else {
+                vo[p] = (uint32_t)(n0 + row - BM) * row_w + scol * 16u;
+            }
+        }
+    };
+    const int dst0 = srow * LDT + scol * 4;
+    f32x4 stage[NLD];
+    uint32_t voff[NLD];
+
+    f32x16 acc[TM][TN];
+    const int a_off = (wm * TM * 32 + l31) * LDT + kg * 4;
+    const int w_off = (BM + wn * TN * 32 + (TR ? pi32(l31) : l31)) * LDT + kg * 4;
+    auto mma = [](half8 x, half8 w, f32x16 c) { return TR ? mfma_hi<false>(w, x, c) : mfma_hi<false>(x, w, c); };
+    auto frag = [&](const float* base, int tile, int s, int lo) {
+        return *reinterpret_cast<const half8*>(base + tile * 32 * LDT + lo * 16 + s * 8);
+    };
+    // One k-block out of LDS buffer `buf`, hand-scheduled exactly as hgemm3_kernel's compute_staged.  mode 0: store the staged
+    // k-block into the other buffer and load the k-block at byte offset `koff` of the rows `vo`; 1: store only; 2: neither.
+    auto compute_staged = [&](int buf, const uint32_t (&vo)[NLD], uint32_t koff, int mode) {
+        const float* As = lds + buf * STAGE + a_off;
+        const float* Ws = lds + buf * STAGE + w_off;
+        float* wbase = lds + (buf ^ 1) * STAGE + dst0;
+        half8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) al[i] = frag(As, i, 0, 1);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) bh[jn] = frag(Ws, jn, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ah[i] = frag(As, i, 0, 0);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) bl[jn] = frag(Ws, jn, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        auto stage_ops = [&](int q) {
+            if (q < NLD && mode < 2) {
+                *reinterpret_cast<f32x4*>(wbase + q * RPP * LDT) = stage[q];
+                if (mode == 0)
+                    stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q * RPP < BM ? rsa : rsw, vo[q], koff, 0));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                acc[i][jn] = mma(al[i], bh[jn], acc[i][jn]);
+                stage_ops(i * TN + jn);
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                acc[i][jn] = mma(ah[i], bl[jn], acc[i][jn]);
+                stage_ops(TM * TN + i * TN + jn);
+            }
+        half8 al1[TM], bh1[TN], ah1[TM], bl1[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) al1[i] = frag(As, i, 1, 1);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) bh1[jn] = frag(Ws, jn, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mma(ah[i], bh[jn], acc[i][jn]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ah1[i] = frag(As, i, 1, 0);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) bl1[jn] = frag(Ws, jn, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mma(al1[i], bh1[jn], acc[i][jn]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mma(ah1[i], bl1[jn], acc[i][jn]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mma(ah1[i], bh1[jn], acc[i][jn]);
+    };
+
+    int m0, n0;
+    int vb = next_valid((int)blockIdx.x, m0, n0);
+    if (vb >= vb_count) return;
+    offsets(m0, n0, voff);
+    // prologue of the FIRST tile only: k-block 0 -> LDS buffer 0, k-block 1 -> registers
+#pragma unroll
+    for (int q = 0; q < NLD; ++q)
+        stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q * RPP < BM ? rsa : rsw, voff[q], 0u, 0));
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) *reinterpret_cast<f32x4*>(lds + dst0 + q * RPP * LDT) = stage[q];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q)
+        stage[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q * RPP < BM ? rsa : rsw, voff[q], 128u, 0));
+    __syncthreads();
+
+    while (true) {
+#ifdef GEMM_TIMELINE
+        const unsigned long long tl_t1 = __builtin_amdgcn_s_memtime();
+#endif
+        int m0n, n0n;
+        const int vbn = next_valid(vb + stride, m0n, n0n);
+        const bool has_next = vbn < vb_count;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+        // ONE steady-state iteration body for the whole stream: iteration kt stores k-block kt + 1 and loads k-block kt + 2 - which for
+        // the last two iterations of a tile are the first two k-blocks of the NEXT tile (nk is even: block nk - 2 sits in buffer 0, so
+        // the next tile's block 0 lands in buffer 0 again).  Behind the last tile the offsets point outside the buffers: the loads
+        // return zeros into registers nobody reads and the stores fill LDS buffers nobody reads - no second code path.
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt == nk - 2) {                          // this tile's loads have all been issued: the offsets turn to the next tile
+                if (has_next) offsets(m0n, n0n, voff);
+                else {
+#pragma unroll
+                    for (int q = 0; q < NLD; ++q) voff[q] = kOob;
+                }
+            }
+            const int kl = kt + 2 < nk ? kt + 2 : kt + 2 - nk;
+            compute_staged(kt & 1, voff, (uint32_t)kl * 128u, 0);
+            __syncthreads();                             // (behind the last iteration: buffer 1 retired, the next tile's block 0 visible)
+        }
+        char* wave_lds = nullptr;
+        if constexpr (EPI == EPI_QKV)                    // the V^T patch lives in buffer 1 (buffer 0 already holds the next tile's first k-block)
+            wave_lds = reinterpret_cast<char*>(lds + STAGE) + wave * (2 * 32 * (TM * 64 + 16));
+#ifdef GEMM_TIMELINE
+        asm volatile("s_nop 0" ::: "memory");
+        const unsigned long long tl_t2 = __builtin_amdgcn_s_memtime();
+#endif
+        if constexpr (TR) {
+            if (n0 + BN <= g.N) epilogue_tr<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, true>(a, g, acc, m0, n0, wm, wn, lane);
+            else epilogue_tr<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane);
+        } else {
+            if (m0 + BM <= a.M && n0 + BN <= g.N) epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, true, 2>(a, g, acc, m0, n0, wm, wn, lane, wave_lds);
+            else epilogue<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false, 2>(a, g, acc, m0, n0, wm, wn, lane, wave_lds);
+        }
+#ifdef GEMM_TIMELINE
+        {
+            const unsigned long long tl_t3 = __builtin_amdgcn_s_memtime();
+            const unsigned wgi = (unsigned)(blockIdx.y * vb_count + vb);
+            if (g_gemm_tl != nullptr && lane == 0 && wgi < (unsigned)g_gemm_tl_cap) {
+                unsigned long long* o = g_gemm_tl + ((size_t)wgi * 8 + wave) * 8;
+                o[0] = tl_t0; o[1] = tl_t1; o[2] = tl_t2; o[3] = tl_t3; o[4] = tl_t3;
+                o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                o[7] = ((unsigned long long)m0 << 32) | (unsigned)n0;
+            }
+            tl_t0 = tl_t3;
+        }
+#endif
+        if (!has_next) break;
+        if constexpr (EPI == EPI_QKV) __syncthreads();   // the patches in buffer 1 have been read: the next iteration stores a k-block there
+        vb = vbn; m0 = m0n; n0 = n0n;
+    }
+}
+
+template <int EPI, bool OUT_SPLIT, bool TR = false>
+hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
+    constexpr int BM = 256, BN = 256;
+    constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LDT * sizeof(float);
+    static DeviceOnce attr_once;
+    static std::atomic<int> cus{0};
+    auto kern = &hgemm3p_kernel<EPI, OUT_SPLIT, TR>;
+    if (attr_once.need()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+        int dev = 0, n = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        cus.store(n > 0 ? n : 256);
+        attr_once.mark();
+    }
+    int n_max = 0;
+    for (int g = 0; g < a.groups; ++g) n_max = a.g[g].N > n_max ? a.g[g].N : n_max;
+    const int m_tiles = (a.M - a.m_begin + BM - 1) / BM, n_tiles = (n_max + BN - 1) / BN;
+    GemmArgs b = a;
+    b.n_tiles = n_tiles;
+    b.vb_count = (m_tiles + 7) / 8 * 8 * n_tiles;
+    // one resident workgroup per CU, the groups side by side; a multiple of 8 per group keeps vb & 7 == blockIdx.x & 7 (the XCD)
+    int per_group = cus.load() / (a.groups > 0 ? a.groups : 1) / 8 * 8;
+    if (per_group < 8) per_group = 8;
+    if (per_group > b.vb_count) per_group = b.vb_count;
+    dim3 grid((unsigned)per_group, (unsigned)a.groups, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(512), LDS_BYTES, s, b);
+    return hipGetLastError();
 }
 
 // ---- ring variant: 128 x 256 tile, 4 waves (2 x 2, each 64 x 128), TWO workgroups per CU -----------------------
@@ -1179,6 +1434,16 @@ hipError_t launch_gemm16_cfg(const Gemm16Args& a_in, hipStream_t s) {
 template <int EPI, bool OUT_SPLIT>
 hipError_t launch_epi(const GemmArgs& a, int tile, hipStream_t s) {
     constexpr bool kCanTr = EPI == EPI_BIAS_SILU && OUT_SPLIT;
+    // the persistent stream kernel takes the 256 x 256 launches whose k-blocks pair up (even count >= 4, no split-K)
+    const bool persist = tile == 2 && (a.flags & GEMM_FLAG_PERSIST) != 0 && a.k_slices <= 1 && ((a.K >> 5) & 1) == 0 && (a.K >> 5) >= 4;
+    if (persist) {
+        if constexpr (kCanTr) {
+            bool tr = (a.flags & GEMM_FLAG_TR) != 0;
+            for (int g = 0; g < a.groups; ++g) tr = tr && (a.g[g].N % 64) == 0;
+            if (tr) return launch_persist<EPI, OUT_SPLIT, true>(a, s);
+        }
+        return launch_persist<EPI, OUT_SPLIT>(a, s);
+    }
     if constexpr (kCanTr) {
         bool tr = (a.flags & GEMM_FLAG_TR) != 0 && tile != 3;
         for (int g = 0; g < a.groups; ++g) tr = tr && (a.g[g].N % 64) == 0;

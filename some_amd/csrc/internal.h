@@ -67,8 +67,10 @@ struct GemmArgs {
     // a_rows the rows of A.  The QKV projection uses it to write Q | K | V^T in clip-aligned coordinates (launch_attn_plan).
     const int32_t* row_map;
     int a_rows;            // rows of A (0: M)
+    int vb_count;          // persistent kernel (hgemm3p_kernel): virtual blocks per group, filled by its launcher (last: the other kernels' argument offsets stay put)
 };
 constexpr int GEMM_FLAG_TR = 1;   // row-per-lane (transposed accumulator) epilogues where the epilogue has one (gemm_f16x3.hip)
+constexpr int GEMM_FLAG_PERSIST = 2;   // 256 x 256 launches through the persistent stream kernel (hgemm3p_kernel, round 6)
 
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);
 // 3-term split-f16 path (gemm_f16x3.hip): A and W in SPLIT32 format (split.h); out_split: C written in SPLIT32

@@ -304,6 +304,76 @@ def test_gemm_single_stage_tile_equals_the_double_buffered_tile_bit_for_bit(eng)
         assert torch.equal(a, c)
 
 
+def _engine_with_gemm_flags(flags, lay=1):
+    """An Engine whose handle read SOME_AMD_GEMM_FLAGS = flags at creation (bit 0 row-per-lane epilogues, bit 1 the persistent stream
+    kernel for the 256 x 256 launches)."""
+    import os
+    from some_amd.configs import get_config
+    from some_amd.engine import Engine
+    old = os.environ.get('SOME_AMD_GEMM_FLAGS')
+    os.environ['SOME_AMD_GEMM_FLAGS'] = str(flags)
+    try:
+        return Engine(get_config('midi_conformer', lay=lay), device='cuda')
+    finally:
+        if old is None:
+            del os.environ['SOME_AMD_GEMM_FLAGS']
+        else:
+            os.environ['SOME_AMD_GEMM_FLAGS'] = old
+
+
+@pytest.mark.parametrize('M', [40000, 10007, 65536 + 300])
+def test_persistent_stream_gemm_equals_the_one_tile_per_workgroup_kernel_bit_for_bit(M):
+    """hgemm3p_kernel (round 6): one resident workgroup per CU walks its tiles with the k-blocks of consecutive tiles as ONE stream (the
+    last two iterations of a tile load / store the first two k-blocks of the next).  Same products in the same order per output
+    element: every epilogue's output equals the non-persistent 256 x 256 kernel's bit for bit - with several tiles per workgroup
+    (M = 40 000: 320 virtual blocks for N = 512; 1 280 for N = 2048), ragged last row tiles, the wave-quantisation tail, K = 512 and
+    K = 2048."""
+    from some_amd import _lib as L
+    base, pers = _engine_with_gemm_flags(1), _engine_with_gemm_flags(3)
+    g = torch.Generator(device='cuda').manual_seed(M)
+    K = 512
+    A = torch.randn(M, K, device='cuda', generator=g)
+    W = torch.randn(2048, K, device='cuda', generator=g) / 20
+    b = torch.randn(2048, device='cuda', generator=g)
+    X = torch.randn(M, 512, device='cuda', generator=g)
+    W2 = torch.randn(512, 2048, device='cuda', generator=g) / 40
+    b2 = torch.randn(512, device='cuda', generator=g)
+    Wg = _interleave_glu(torch.randn(1024, K, device='cuda', generator=g) / 20)
+    bg = torch.randn(1024, device='cuda', generator=g)
+    mask = (torch.rand(M, device='cuda', generator=g) > 0.2).to(torch.uint8)
+    outs = []
+    for e in (base, pers):
+        h = _gemm(e, L.EPI_BIAS_SILU, A, W, bias=b, split=True, tile=2)
+        outs.append([h, _gemm(e, L.EPI_BIAS_SILU, A, W, bias=b, split=True, tile=2, out_split=True),
+                     _gemm(e, L.EPI_BIAS_RES, h, W2, bias=b2, res=X, alpha=0.5, split=True, tile=2),
+                     _gemm(e, L.EPI_NONE, A, W, split=True, tile=2), _gemm(e, L.EPI_BIAS, A, W2[:, :K].contiguous(), bias=b2, split=True, tile=2),
+                     _gemm(e, L.EPI_GLU, A, Wg, bias=bg, n_out=512, split=True, tile=2),
+                     _gemm(e, L.EPI_GLU_RES, A, Wg, bias=bg, res=X, mask=mask, n_out=512, split=True, tile=2)])
+    for i, (a, c) in enumerate(zip(*outs)):
+        assert torch.isfinite(c).all(), i
+        assert torch.equal(a, c), (i, float((a - c).abs().max()))
+
+
+def test_forward_with_the_persistent_gemms_equals_the_default_bit_for_bit():
+    """The whole forward (QKV projection with its row gather and V^T patch included) at a size where every 256 x 256 launch has several
+    tiles per workgroup: 16 x 30 s + ragged clips, lay 2."""
+    from some_amd import _lib, synth
+    from some_amd.engine import ClipBatch
+    engines = [_engine_with_gemm_flags(f, lay=2) for f in (1, 3)]
+    sd = synth.synth_state_dict(engines[0].config, 11)
+    counts = [2584] * 15 + [1000, 333, 77]
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    res = []
+    for e in engines:
+        e.load_state_dict(sd)
+        batch = ClipBatch(counts, 'cuda')
+        units = torch.randn(batch.total_frames, 80, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5)) * 2 - 4
+        res.append(e.forward(units, batch, head_mode=_lib.HEAD_SIGMOID))
+    torch.cuda.synchronize()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.isfinite(res[1][0]).all()
+
+
 @pytest.mark.parametrize('lens', [[64], [1], [33], [130, 257], [128, 1, 300, 65], [862], [2584, 100], [2584] * 9 + [64, 200]])
 def test_qkv_attention_f16x3(eng, lens):
     """Split-f16 QKV projection (Q | K SPLIT32 planes + transposed V) + split-f16 flash attention vs fp64."""
