@@ -22,6 +22,12 @@
 #ifdef GEMM_TIMELINE
 __device__ unsigned long long* g_gemm_tl;      // [workgroup][wave][8] (tools/gemm_probe.hip)
 __device__ int g_gemm_tl_cap;
+__device__ unsigned long long* g_gemm_it;      // [wave][1024]: s_memtime behind every k-block barrier of the workgroups with blockIdx.x == 8
+__device__ int g_gemm_it_n[8];
+#define GEMM_IT_STAMP() do { if (g_gemm_it != nullptr && blockIdx.x == 8 && blockIdx.y == 0 && lane == 0) { \
+        const int i_ = g_gemm_it_n[wave]; if (i_ < 1024) { g_gemm_it[wave * 1024 + i_] = __builtin_amdgcn_s_memtime(); g_gemm_it_n[wave] = i_ + 1; } } } while (0)
+#else
+#define GEMM_IT_STAMP() do {} while (0)
 #endif
 
 namespace {
@@ -593,6 +599,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 1 ? 2 : 1) void h
             compute(kt & 1);
         }
         __syncthreads();
+        GEMM_IT_STAMP();
     }
     if (kt + 1 < nk) {
         if constexpr (TERMS == 3) {
@@ -849,6 +856,7 @@ __global__ __launch_bounds__(512) void hgemm3p_kernel(GemmArgs a) {
             const int kl = kt + 2 < nk ? kt + 2 : kt + 2 - nk;
             compute_staged(kt & 1, voff, (uint32_t)kl * 128u, 0);
             __syncthreads();                             // (behind the last iteration: buffer 1 retired, the next tile's block 0 visible)
+            GEMM_IT_STAMP();
         }
         char* wave_lds = nullptr;
         if constexpr (EPI == EPI_QKV)                    // the V^T patch lives in buffer 1 (buffer 0 already holds the next tile's first k-block)

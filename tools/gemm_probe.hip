@@ -42,6 +42,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&tl_d, (size_t)cap * 8 * 8 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_tl), &tl_d, sizeof(tl_d)));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_tl_cap), &cap, sizeof(cap)));
+    unsigned long long* it_d;
+    CK(hipMalloc(&it_d, 8 * 1024 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_it), &it_d, sizeof(it_d)));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -57,13 +60,35 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
         CK(hipMemset(bias, 0, sh.N * 4)); CK(hipMemset(res, 0, (size_t)M * n_out * 4));
-        for (int tile : {2, 5}) {
+        for (int variant : {2, 5, 6}) {                  // 2: 256 x 256, one tile per workgroup; 5: single stage, two per CU; 6: persistent stream
+            const int tile = variant == 6 ? 2 : variant;
             GemmArgs a{};
             a.g[0] = GemmGroup{A, W, bias, res, C, nullptr, sh.N, 0};
-            a.groups = 1; a.M = M; a.K = sh.K; a.lda = sh.K; a.ldc = n_out; a.ldr = n_out; a.alpha = 0.5f; a.flags = GEMM_FLAG_TR;
+            a.groups = 1; a.M = M; a.K = sh.K; a.lda = sh.K; a.ldc = n_out; a.ldr = n_out; a.alpha = 0.5f;
+            a.flags = GEMM_FLAG_TR | (variant == 6 ? GEMM_FLAG_PERSIST : 0);
+            // STEADY STATE first: the package power limit sets the clock over ~milliseconds, so a lone launch behind an idle gap runs at
+            // a boost clock a stream of launches never sees.  ~0.4 s of warm-up, ~1 s timed: `steady` is what a model step experiences.
             for (int i = 0; i < 3; ++i) CK(launch_gemm_f16x3(sh.epi, a, sh.out_split, tile, 0));
             CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, 0));
+            CK(launch_gemm_f16x3(sh.epi, a, sh.out_split, tile, 0));
+            CK(hipEventRecord(e1, 0));
+            CK(hipDeviceSynchronize());
+            float one_ms = 0;
+            CK(hipEventElapsedTime(&one_ms, e0, e1));
+            const int reps = (int)(1000.f / one_ms) + 1;
+            for (int i = 0; i < reps * 2 / 5; ++i) CK(launch_gemm_f16x3(sh.epi, a, sh.out_split, tile, 0));
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < reps; ++i) CK(launch_gemm_f16x3(sh.epi, a, sh.out_split, tile, 0));
+            CK(hipEventRecord(e1, 0));
+            CK(hipDeviceSynchronize());
+            float steady_ms = 0;
+            CK(hipEventElapsedTime(&steady_ms, e0, e1));
+            steady_ms /= reps;
+            // the timeline below is taken from ONE more launch right behind that stream (no idle gap in front of it)
             CK(hipMemset(tl_d, 0, (size_t)cap * 8 * 8 * 8));
+            CK(hipMemset(it_d, 0, 8 * 1024 * 8));
+            { int zero[8] = {0, 0, 0, 0, 0, 0, 0, 0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_it_n), zero, sizeof(zero))); }
             CK(hipEventRecord(e0, 0));
             CK(launch_gemm_f16x3(sh.epi, a, sh.out_split, tile, 0));
             CK(hipEventRecord(e1, 0));
@@ -88,8 +113,19 @@ int main(int argc, char** argv) {
                 recs.push_back(Rec{o[0], o[1], o[2], o[3], o[4], key, hi2 - lo2});
                 tmin = std::min(tmin, o[0]); tmax = std::max(tmax, o[4]);
             }
-            if (recs.empty()) { printf("%s tile %d: no records\n", sh.name, tile); continue; }
-            const double tick_us = ms * 1e3 / (double)(tmax - tmin);          // the launch spans (almost exactly) the event interval
+            if (recs.empty()) { printf("%s variant %d: no records\n", sh.name, variant); continue; }
+            // every XCD counts its own s_memtime (different bases): the launch spans (almost exactly) the event interval on each of them
+            std::map<unsigned long long, std::pair<unsigned long long, unsigned long long>> xspan;
+            for (const Rec& r : recs) {
+                auto it = xspan.find(r.cu >> 16);
+                if (it == xspan.end()) xspan[r.cu >> 16] = {r.t0, r.t4};
+                else { it->second.first = std::min(it->second.first, r.t0); it->second.second = std::max(it->second.second, r.t4); }
+            }
+            double span = 0;
+            for (auto& kv : xspan) span += (double)(kv.second.second - kv.second.first);
+            const double ticks_launch = span / xspan.size();                 // counter ticks from the first dispatch to the last store, mean over the XCDs
+            const double tick_us = ms * 1e3 / ticks_launch;
+            (void)tmin; (void)tmax;
             std::map<unsigned long long, std::vector<Rec>> per_cu;
             for (const Rec& r : recs) per_cu[r.cu].push_back(r);
             double pro = 0, loop = 0, epi = 0, drain = 0, gap = 0, first = 0, skew = 0;
@@ -97,7 +133,7 @@ int main(int argc, char** argv) {
             for (auto& kv : per_cu) {
                 auto& v = kv.second;
                 std::sort(v.begin(), v.end(), [](const Rec& x, const Rec& y) { return x.t0 < y.t0; });
-                first += (double)(v[0].t0 - tmin);
+                first += (double)(v[0].t0 - xspan[kv.first >> 16].first);
                 for (size_t i = 0; i < v.size(); ++i) {
                     pro += (double)(v[i].t1 - v[i].t0); loop += (double)(v[i].t2 - v[i].t1); epi += (double)(v[i].t3 - v[i].t2);
                     drain += (double)(v[i].t4 - v[i].t3); skew += (double)v[i].skew; ++n;
@@ -106,9 +142,19 @@ int main(int argc, char** argv) {
                         if (v[j].t0 >= v[i].t4) { gap += (double)(v[j].t0 - v[i].t4); ++ngap; break; }
                 }
             }
+            {   // k-block barrier stamps of the workgroup(s) with blockIdx.x == 8, wavefront 0: iteration lengths in counter ticks
+                std::vector<unsigned long long> it(8 * 1024);
+                CK(hipMemcpy(it.data(), it_d, it.size() * 8, hipMemcpyDeviceToHost));
+                int cnt[8];
+                CK(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_gemm_it_n), sizeof(cnt)));
+                printf("    k-block lengths (ticks) seen by wavefront 0 of blockIdx.x == 8, %d stamps:", cnt[0]);
+                for (int i = 1; i < cnt[0] && i < 100; ++i) printf(" %llu", it[i] - it[i - 1]);
+                printf("\n");
+            }
             const double wg_us = (pro + loop + epi + drain) / n * tick_us;
-            printf("%-40s tile %d: %.4f ms, %zu workgroups on %zu CU ids, %.1f workgroups per CU id; counter tick %.4f us\n", sh.name, tile, ms, n,
-                   per_cu.size(), (double)n / per_cu.size(), tick_us);
+            printf("%-40s %s: STEADY %.4f ms per launch (%d back to back); the traced launch %.4f ms = %.0f counter ticks -> %.0f MHz if the counter is the "
+                   "shader clock; %zu tiles on %zu CU ids, %.1f per CU id\n", sh.name, variant == 2 ? "256x256" : variant == 5 ? "128x256 single stage x 2" : "256x256 persistent",
+                   steady_ms, reps, ms, ticks_launch, ticks_launch / (ms * 1e3), n, per_cu.size(), (double)n / per_cu.size());
             printf("    per workgroup (us): prologue %.2f | k-loop %.2f | epilogue to the last store issued %.2f | store drain %.2f | total %.2f | gap to "
                    "the next workgroup of the CU slot %.2f | last-product skew between the wavefronts %.2f | first dispatch after launch %.2f\n",
                    pro / n * tick_us, loop / n * tick_us, epi / n * tick_us, drain / n * tick_us, wg_us, ngap ? gap / ngap * tick_us : 0.0,

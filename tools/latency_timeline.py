@@ -5,7 +5,7 @@
     analyse:  python tools/latency_timeline.py analyse DIR > profiles/r06_latency_timeline.txt
 
 ``run`` prints the host-side wall time per step (synchronised) and marks nothing on the device - the analysis finds the steps in the
-kernel trace by the log-mel kernel that opens each one.  ``analyse`` reports, for the steady-state steps: the span from the first kernel's
+kernel trace by the idle gap the runner leaves between them.  ``analyse`` reports, for the steady-state steps: the span from the first kernel's
 start to the last kernel's end, the time at least one kernel is running (union of the intervals), the time TWO kernels overlap (the midi /
 bound model streams run on two HIP streams), the idle time inside the span (no kernel resident: launch / dependency gaps), the serial sum
 per kernel family, and the largest idle gaps with the kernels either side."""
@@ -46,6 +46,7 @@ def run(args):
     lat = []
     for _ in range(args.steps):
         torch.cuda.synchronize()
+        time.sleep(0.004)                      # an idle gap in the kernel trace: how `analyse` tells the steps apart
         t = time.perf_counter()
         out = runner()
         torch.cuda.synchronize()
@@ -60,6 +61,9 @@ def family(name: str) -> str:
     if m:
         wm, wn, tm, tn, epi = map(int, m.groups())
         return f'gemm {wm * tm * 32}x{wn * tn * 32} epi{epi}'
+    m = re.match(r'hgemm3p_kernel<(\d+)', name)
+    if m:
+        return f'gemm 256x256 persistent epi{m.group(1)}'
     return re.sub(r'<.*', '', name)[:32]
 
 
@@ -71,10 +75,21 @@ def analyse(args):
     rows.sort()
     if not rows:
         raise SystemExit('no *kernel_trace.csv under ' + args.dir)
-    starts = [i for i, r in enumerate(rows) if 'logmel' in r[2]]
-    steps = [rows[a:b] for a, b in zip(starts, starts[1:] + [len(rows)])]
-    steps = [s for s in steps if len(s) == len(steps[-1])][2:]            # steady state: same launch count as the last, warm-ups dropped
-    print(f'{len(rows)} kernel records, {len(starts)} steps found, {len(steps)} steady-state steps of {len(steps[-1])} launches analysed')
+    # steps: the runner sleeps between them, so a step is a run of kernels with no idle gap longer than 1.5 ms
+    steps, cur, end = [], [], None
+    for r in rows:
+        if cur and r[0] - end > 1_500_000:
+            steps.append(cur)
+            cur = []
+        cur.append(r)
+        end = r[1] if len(cur) == 1 else max(end, r[1])
+    steps.append(cur)
+    n_found = len(steps)
+    common = max(set(len(s) for s in steps), key=lambda c: sum(1 for s in steps if len(s) == c))
+    steps = [s for s in steps if len(s) == common][2:]                     # steady state: the usual launch count, warm-ups dropped
+    if not steps:
+        raise SystemExit(f'{len(rows)} kernel records in {n_found} runs, none repeated often enough; first names: ' + '; '.join(r[2][:40] for r in rows[:12]))
+    print(f'{len(rows)} kernel records, {n_found} steps found, {len(steps)} steady-state steps of {common} launches analysed')
     agg = {'span': 0.0, 'busy': 0.0, 'overlap2': 0.0, 'idle': 0.0, 'serial': 0.0}
     fam = {}
     gaps = []
