@@ -92,7 +92,7 @@ def _live_pmc(kernel_name: str, config_args) -> dict:
     if key is None or exe is None or os.environ.get('SOME_AMD_BENCH_CHILD'):
         return {}
     child = [sys.executable, str(ROOT / 'bench.py'), '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--no-kernel-profile', '--no-latency',
-             '--no-f32-leg', '--no-secondary', '--no-live-pmc', '--no-e2e', '--no-train', '--no-calibration'] + list(config_args)
+             '--no-f32-leg', '--no-fast-leg', '--no-secondary', '--no-live-pmc', '--no-e2e', '--no-train', '--no-calibration'] + list(config_args)
     # (a child must not join the parent's process group: drop the torch.distributed.run variables)
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'GROUP_RANK',
                                                               'LOCAL_WORLD_SIZE', 'ROLE_RANK', 'ROLE_WORLD_SIZE') and not k.startswith('TORCHELASTIC')}
@@ -153,11 +153,12 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='clips per GPU per step')
     ap.add_argument('--seconds', type=float, default=30.0, help='clip length')
     ap.add_argument('--lay', type=int, default=None, help='override lay (debug only; invalidates the metric)')
-    ap.add_argument('--precision', default=None, choices=['f32', 'f16x3'], help='GEMM arithmetic (default: library default)')
+    ap.add_argument('--precision', default=None, choices=['f32', 'f16x3', 'f16x3_fast'], help='GEMM arithmetic (default: library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-latency', action='store_true', help='skip the B=1 p50 latency leg')
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the secondary exact-f32 measurement')
+    ap.add_argument('--no-fast-leg', action='store_true', help='skip the opt-in f16x3_fast measurement')
     ap.add_argument('--no-secondary', action='store_true', help='skip the quant_two_head_model (BASELINE configs[2]) leg')
     ap.add_argument('--cpu-clips', type=int, default=10, help='clips in the bounded CPU-baseline sample (N-thread figure)')
     ap.add_argument('--cpu-single-thread-seconds', type=float, default=10.0, help='length of the one clip the 1-thread CPU figure runs')
@@ -337,7 +338,7 @@ def main():
             dom = next((k for k in kernels if 'tflops' in k), None)
             if dom is not None:
                 flops_per_launch = dom['tflops'] * 1e12 * dom['avg_ms'] * 1e-3
-                if precision_name == 'f16x3' and 'in->512' not in dom['name']:
+                if precision_name in ('f16x3', 'f16x3_fast') and 'in->512' not in dom['name']:
                     # achieved = ALGORITHMIC FLOPs per launch / average launch time, against the
                     # dense f16 MFMA peak of the pipe the kernel runs on.  The 3-term split executes three f16 MFMA
                     # products per logical fp32 multiply-add; that issued-work figure is reported separately, as is the
@@ -442,6 +443,31 @@ def main():
             result['exact_f32_mode'] = {'value': round(args.batch * args.seconds / dt32, 2), 'unit': 'audio-s/s',
                                         'ms_per_step': round(dt32 * 1e3, 3), 'dtype': 'f32 (v_mfma_f32_32x32x2_f32)'}
             del eng32, arena32
+        # ---- the opt-in fast mode (f16x3_fast: attention P V on two terms; never the headline) --------------------------------------
+        if world == 1 and precision_name == 'f16x3' and not args.no_fast_leg:
+            cfgf = dict(cfg, some_amd_precision='f16x3_fast')
+            engf = Engine(cfgf, device=device)
+            engf.attach_arena(arena)                      # same packed weights (the GEMM operands are the f16x3 ones)
+
+            def stepf():
+                u = engf.logmel(audio, batch)
+                p, b = engf.forward(u, batch, head_mode=head)
+                return p, b, engf.decode(p, b, batch, quantized=quant)
+            stepf()
+            torch.cuda.synchronize(device)
+            tf0 = time.perf_counter()
+            for _ in range(args.steps):
+                pf, bf, outf = stepf()
+            torch.cuda.synchronize(device)
+            dtf = (time.perf_counter() - tf0) / args.steps
+            u0 = eng.logmel(audio, batch)
+            p0, b0 = eng.forward(u0, batch, head_mode=head)
+            out0 = eng.decode(p0, b0, batch, quantized=quant)
+            result['fast_mode'] = {'value': round(args.batch * args.seconds / dtf, 2), 'unit': 'audio-s/s', 'ms_per_step': round(dtf * 1e3, 3),
+                                   'dtype': 'f16x3 with the attention product P V on two terms (SOME_PRECISION_F16X3_FAST, opt-in)',
+                                   'max_abs_dprob_vs_default': float((pf - p0).abs().max()), 'max_abs_dbound_vs_default': float((bf - b0).abs().max()),
+                                   'notes_decoded': int(outf['n_notes'].sum()), 'notes_decoded_default': int(out0['n_notes'].sum())}
+            del engf
         # ---- BASELINE.json configs[2]: quant_two_head_model (lay 3, 129 bins, softmax head + argmax decode), same batch ----
         if world == 1 and args.config == 'midi_conformer' and not args.no_secondary:
             cfg_q = get_config('quant_two_head_model')

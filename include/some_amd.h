@@ -64,6 +64,9 @@ typedef struct SomeConfig {
 #define SOME_PRECISION_F32 0    /* exact fp32 on the f32 matrix pipe (v_mfma_f32_32x32x2_f32)                      */
 #define SOME_PRECISION_F16X3 1  /* fp32-equivalent 3-term split on the f16 matrix pipe: x = hi + lo (two f16),      */
                                 /* a*b = ah*bh + ah*bl + al*bh, fp32 accumulate; needs |GEMM inputs| < 65504        */
+#define SOME_PRECISION_F16X3_FAST 2 /* OPT-IN: f16x3 everywhere except the attention product P V, which drops its vh*pl term  */
+                                /* (P enters as rn_f16(2^11 p), normalised by the sum of the rounded values): attention  */
+                                /* output within 2^-12 relative instead of 2^-21; GEMMs unchanged.  Never the default.    */
 
 /* One entry of a PyTorch state_dict, host memory, contiguous, as produced by
  * torch.load(ckpt)['state_dict'] after the 'model.' prefix strip (inference/base_infer.py:27-32). */

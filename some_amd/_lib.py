@@ -16,7 +16,7 @@ SOME_OK = 0
 SOME_EINVAL, SOME_EKEY, SOME_ESHAPE, SOME_EHIP, SOME_ESTATE, SOME_ENOMEM = -1, -2, -3, -4, -5, -6
 HEAD_LOGITS, HEAD_SIGMOID, HEAD_SOFTMAX = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_SILU, EPI_BIAS_RES, EPI_GLU, EPI_GLU_RES = range(6)
-PRECISION_F32, PRECISION_F16X3 = 0, 1
+PRECISION_F32, PRECISION_F16X3, PRECISION_F16X3_FAST = 0, 1, 2
 PAD_ZERO, PAD_REFLECT = 0, 1
 SAMPLE_F32, SAMPLE_PCM16 = 0, 1
 (ELT_SILU_FWD, ELT_SILU_BWD, ELT_SIGMOID_FWD, ELT_SIGMOID_BWD, ELT_AXPY, ELT_DROPOUT, ELT_SILU_DROP_FWD, ELT_SILU_DROP_BWD,

@@ -250,11 +250,16 @@ int some_create(const SomeConfig* cfg, SomeHandle** out) {
     REQUIRE(cfg->indim == kMels, "front end is compiled for %d mel bands, got units_dim=%d", kMels, cfg->indim);
     REQUIRE(cfg->sample_rate > 0 && cfg->fmin >= 0, "bad sample_rate/fmin");
 #undef REQUIRE
-    if (cfg->precision != SOME_PRECISION_F32 && cfg->precision != SOME_PRECISION_F16X3)
-        return fail(nullptr, SOME_EINVAL, "unsupported precision (0 = f32, 1 = f16x3)");
+    if (cfg->precision != SOME_PRECISION_F32 && cfg->precision != SOME_PRECISION_F16X3 && cfg->precision != SOME_PRECISION_F16X3_FAST)
+        return fail(nullptr, SOME_EINVAL, "unsupported precision (0 = f32, 1 = f16x3, 2 = f16x3_fast)");
     SomeHandle* h = new SomeHandle();
     h->cfg = *cfg;
     h->precision = cfg->precision;
+    if (cfg->precision == SOME_PRECISION_F16X3_FAST) {     // everything is the f16x3 path; only the attention kernel differs
+        h->precision = SOME_PRECISION_F16X3;
+        h->attn_fast = 1;
+        if (const char* t = getenv("SOME_AMD_ATTN_FAST")) h->attn_fast = atoi(t) == 2 ? 2 : 1;      // (2: the measured-only variant without kh * ql)
+    }
     h->tile = -1;                                    // -1: pick per launch from the grid size
     if (const char* t = getenv("SOME_AMD_TILE")) h->tile = atoi(t);
     if (const char* t = getenv("SOME_AMD_GEMM_FLAGS")) h->gemm_flags = atoi(t);
@@ -650,6 +655,7 @@ int some_forward(SomeHandle* h, const float* units_dev, const int32_t* frame_off
             a.K = kDim; a.lda = kDim; a.ldc = kDim; a.row_map = row_map; a.a_rows = M;
             if ((rc = gemm("gemm[512->1536 qkv]", EPI_QKV, a, ng, 3 * kDim, st, false, Mc))) return rc;
             t.frame_offsets = frame_offsets_dev; t.pad_offsets = pad_off; t.groups = ng; t.B = B; t.max_frames = max_frames; t.M = Mc; t.ldv = ldv;
+            t.fast = h->attn_fast;
             Scope sc(h, st, "attention", 4.0 * kHeadDim * kHeads * ng * sumT2, 0.0);
             HIP_TRY(h, launch_attention_f16x3(t, st));
         } else {
@@ -949,6 +955,7 @@ int some_op_qkv_attention_f16x3(SomeHandle* h, const float* h_split_dev, const f
     Attn3Args t{};
     t.q[0] = qp; t.k[0] = kp; t.vt[0] = vt; t.out[0] = out_split_dev;
     t.frame_offsets = frame_offsets_dev; t.pad_offsets = pad_off; t.groups = 1; t.B = B; t.max_frames = max_frames; t.M = Mc; t.ldv = ldv;
+    t.fast = h->attn_fast;
     HIP_TRY(h, launch_attention_f16x3(t, s));
     return SOME_OK;
 }

@@ -445,7 +445,12 @@ struct Flag { static constexpr bool value = V; };
 // ds_read_b128 lane group hold 16 rows with distinct r & 15, i.e. 16 distinct positions = all 64 banks.  The swizzle costs nothing
 // on the write side (a lane fetches the global chunk that belongs at its position) and nothing on the read side (the eight chunk
 // offsets a lane ever needs - kg ^ (r & 15) ^ {0, 2, .. 14} - are kept in eight registers; ring slot and row + 32 are immediates).
-template <bool DMA>
+// FAST (SOME_PRECISION_F16X3_FAST, opt-in - never the default): products the softmax average is least sensitive to are left out.
+//   FAST >= 1: P V without its `vh * pl` term - P enters as ph = rn_f16(2^11 p) alone (round to NEAREST: no bias; the shipped split
+//              truncates ph because pl carries the remainder), so 16 instead of 24 MFMAs in phase B and one conversion instead of the
+//              four-instruction split per pair.  O = sum ph v / sum p: relative error <= 2^-12 per term, unbiased.
+//   FAST == 2: additionally Q K^T without `kh * ql` (16 MFMAs in phase A): the scores lose ~2^-12 |s| - measured, not shipped as a mode.
+template <bool DMA, int FAST = 0>
 __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nqb) {
     constexpr int QB = 128;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -599,9 +604,21 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
     uint32_t lpk[4][4];            // [slab][pair] packed lo halves
     float lo0_[4][4];              // first half-step's leftover
     auto pel = [&](const f32x16& c0, const f32x16& c1, int e) -> float { return e < 16 ? c0[e] : c1[e - 16]; };
+    float ps0 = 0.f, ps1 = 0.f;                       // row sums of the tile in flight (two chains)
     auto split_half = [&](f32x16& c0, f32x16& c1, int q, int j, int half) {
         const float p0 = pel(c0, c1, 8 * q + 2 * j), p1 = pel(c0, c1, 8 * q + 2 * j + 1);
-        if (half == 0) {
+        if constexpr (FAST >= 1) {
+            if (half == 0) {
+                typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                const f32x2_ pp = {p0, p1};
+                const half2_t hh = __builtin_convertvector(pp, half2_t);                             // v_cvt_pk_f16_f32: round to nearest even
+                hpk[q][j] = __builtin_bit_cast(uint32_t, hh);
+                // the row sum counts what the matrix pipe will see: the weights ph / sum ph add up to exactly 1, so a query whose
+                // softmax is one key (the worst case for a rounded P) gets that key's V row exactly
+                ps0 += (float)hh[0];
+                ps1 += (float)hh[1];
+            }
+        } else if (half == 0) {
             const half2_t hh = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(p0, p1));
             hpk[q][j] = __builtin_bit_cast(uint32_t, hh);
             lo0_[q][j] = mix_sub_(hh[0], mone, p0);
@@ -616,7 +633,6 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
         const u32x4 v = {w[0], w[1], w[2], w[3]};
         return __builtin_bit_cast(half8, v);
     };
-    float ps0 = 0.f, ps1 = 0.f;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // One tile step.  c0 / c1: raw scores of tile i on entry, its probabilities afterwards.  n0 / n1: receive S(i+1).
@@ -637,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
                 const half8& ka = kf[u == 0 ? 1 : u == 1 ? 3 : (u & 1) ? 2 : 0];
                 const half8& qb_ = (u == 2 || u == 3) ? ql[s] : qh[s];
                 f32x16& acc = (u & 1) ? n1 : n0;
-                acc = mfma_hi<false>(ka, qb_, (t < 2) ? zero16 : acc);
+                if (!(FAST == 2 && (u == 2 || u == 3))) acc = mfma_hi<false>(ka, qb_, (t < 2) ? zero16 : acc);
                 // the next slab's fragments into the registers that have just been read for the last time
                 if (s < 3) {
                     if (u == 0) read_k1(i + 1, s + 1, 1);
@@ -684,9 +700,11 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
             {
                 // vl0 ph, vl1 ph, vh0 pl, vh1 pl, vh0 ph, vh1 ph
                 const half8& va = vf[u == 0 ? 1 : u == 1 ? 3 : (u & 1) ? 2 : 0];
-                const half8 pb = (u == 2 || u == 3) ? frag_of(lpk[q]) : frag_of(hpk[q]);
-                if (u & 1) o1 = mfma_hi<false>(va, pb, o1);
-                else o0 = mfma_hi<false>(va, pb, o0);
+                if (!(FAST >= 1 && (u == 2 || u == 3))) {
+                    const half8 pb = (u == 2 || u == 3) ? frag_of(lpk[q]) : frag_of(hpk[q]);
+                    if (u & 1) o1 = mfma_hi<false>(va, pb, o1);
+                    else o0 = mfma_hi<false>(va, pb, o0);
+                }
                 if (q < 3) {
                     if (u == 0) read_v1(i, q + 1, 1);
                     if (u == 1) read_v1(i, q + 1, 3);
@@ -699,7 +717,7 @@ __global__ __launch_bounds__(256, 2) void attention3i_kernel(Attn3Args a, int nq
             if (t >= 2 && t < 10) split_half(c0, c1, 2, (t - 2) >> 1, (t - 2) & 1);
             if (t >= 8 && t < 16) split_half(c0, c1, 3, (t - 8) >> 1, (t - 8) & 1);
             // row sums: 32 probabilities over slots 0 - 15
-            if (t < 16) { ps0 += pel(c0, c1, 2 * t); ps1 += pel(c0, c1, 2 * t + 1); }
+            if (FAST == 0 && t < 16) { ps0 += pel(c0, c1, 2 * t); ps1 += pel(c0, c1, 2 * t + 1); }
             }
             // staging: K tile i + 2 and V^T tile i + 1 out of the registers into the rings, the next loads behind them
             // row maximum of S(i+1): two chains over slots 16 - 23
@@ -877,6 +895,10 @@ hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3i_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3i_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3i_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention3_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
@@ -894,6 +916,8 @@ hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s) {
     if (!inference && a.hi_only == 2) hipLaunchKernelGGL((attention3_kernel<true, 1, true>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else if (!inference && a.hi_only) hipLaunchKernelGGL((attention3_kernel<true, 1>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else if (!inference) hipLaunchKernelGGL(attention3_kernel<true>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    else if (placed && dma && a.fast == 1) hipLaunchKernelGGL((attention3i_kernel<true, 1>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
+    else if (placed && dma && a.fast == 2) hipLaunchKernelGGL((attention3i_kernel<true, 2>), dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else if (placed && dma) hipLaunchKernelGGL(attention3i_kernel<true>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else if (placed) hipLaunchKernelGGL(attention3i_kernel<false>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);
     else hipLaunchKernelGGL(attention3_kernel<false>, dim3((unsigned)(slots * nqb * 8)), dim3(256), LDS_BYTES, s, a, nqb);

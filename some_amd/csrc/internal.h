@@ -153,6 +153,7 @@ struct Attn3Args {
     float* out32[kStreams];
     float* lse[kStreams];
     int hi_only;                   // training forward only: 1 = plain f16 operands (one product instead of three), 2 = bf16 operands
+    int fast;                      // inference only (SOME_PRECISION_F16X3_FAST): 1 = P V without vh * pl, 2 = also Q K^T without kh * ql (attention3i_kernel<DMA, FAST>)
 };
 hipError_t launch_attention_f16x3(const Attn3Args& a, hipStream_t s);
 inline int vt_ld(int64_t M) { return (int)((M + 255) / 256 * 256); }
@@ -294,8 +295,9 @@ struct SomeHandle {
     std::string err;
     bool profiling = false;
     int precision = 0;          // SOME_PRECISION_*
+    int attn_fast = 0;          // SOME_PRECISION_F16X3_FAST: attention3i_kernel<DMA, FAST> variant (precision itself then reads F16X3)
     int tile = 2;               // f16x3 GEMM tile selector (tuning knob)
-    int gemm_flags = GEMM_FLAG_TR;   // SOME_AMD_GEMM_FLAGS overrides (A/B runs)
+    int gemm_flags = GEMM_FLAG_TR | GEMM_FLAG_PERSIST;   // SOME_AMD_GEMM_FLAGS overrides (A/B runs: 1 = one tile per workgroup)
     bool dual_stream = true;         // midi / bound model streams on two HIP streams (SOME_AMD_DUAL_STREAM=0: grouped launches)
     // helper stream + fork / join events of the dual-stream forward, one set per caller stream (two forwards enqueued on
     // different streams must not share a helper stream); enqueues are serialised by fwd_mu

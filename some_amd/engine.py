@@ -39,13 +39,15 @@ def make_some_config(config: dict) -> _lib.SomeConfig:
     return c
 
 
-PRECISIONS = {'f32': _lib.PRECISION_F32, 'f16x3': _lib.PRECISION_F16X3}
+PRECISIONS = {'f32': _lib.PRECISION_F32, 'f16x3': _lib.PRECISION_F16X3,
+              'f16x3_fast': _lib.PRECISION_F16X3_FAST}     # opt-in: the attention product P V with two terms instead of three (include/some_amd.h)
 DEFAULT_PRECISION = 'f16x3'
 
 
 def resolve_precision(config: dict) -> int:
     """GEMM arithmetic: config key ``some_amd_precision`` > env ``SOME_AMD_PRECISION`` > default.
-    'f32' = exact fp32 MFMA; 'f16x3' = fp32-equivalent 3-term split on the f16 matrix pipe."""
+    'f32' = exact fp32 MFMA; 'f16x3' = fp32-equivalent 3-term split on the f16 matrix pipe; 'f16x3_fast' = f16x3 with
+    the attention product P V on two terms (attention output to 2^-12 relative instead of 2^-21): an opt-in speed mode, never the default."""
     import os
     name = config.get('some_amd_precision') or os.environ.get('SOME_AMD_PRECISION') or DEFAULT_PRECISION
     if name not in PRECISIONS:

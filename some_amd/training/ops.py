@@ -89,7 +89,7 @@ class TrainOps:
         self._lane_version = [0, 0]                # operators enqueued per lane
         self._lane_seen = {(0, 1): -1, (1, 0): -1} # (producer, consumer) -> the producer's version the consumer has waited for
         self._fork_cover = None                    # inside lane(i, after=fork): (the fork's lane, its version at the fork point)
-        self.gemm_precision = 'f16x3' if engine.c_config.precision == _lib.PRECISION_F16X3 else 'f32'
+        self.gemm_precision = 'f32' if engine.c_config.precision == _lib.PRECISION_F32 else 'f16x3'     # (f16x3_fast only changes the INFERENCE attention kernel)
         self.attention_precision = self.gemm_precision      # forward + backward: split-f16 or exact-f32 MFMA kernels
         self._hi = 0                                        # GEMM flag bits of the one-product modes (set_mixed_precision)
         self._hi_mode = 0                                   # the `hi_only` argument: 0 three products, 1 f16, 2 bf16

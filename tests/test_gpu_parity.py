@@ -602,7 +602,7 @@ def _boundaries(dur_frames):
     return set(np.cumsum(np.asarray(dur_frames, dtype=np.int64))[:-1].tolist())
 
 
-@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
+@pytest.mark.parametrize('precision', ['f16x3', 'f32', 'f16x3_fast'])
 @pytest.mark.parametrize('name', ['full_conf', 'full_quant'])
 def test_fullsize_batch_vs_reference_golden(golden_dir, name, precision):
     """BASELINE.json configs[1] / configs[2] as bench.py runs them - ONE packed batch of 32 x 30 s clips (82 688 frames,

@@ -3,7 +3,7 @@
 # each leg one JSON line under gpurun_out/<tag>_<name>.json.  Usage: tools/exp_ab.sh <tag> "name|ENV=.. ENV=.." ...
 TAG=$1; shift
 O=gpurun_out; mkdir -p $O
-B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-f32-leg --no-secondary --no-e2e --no-train"
+B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-f32-leg --no-fast-leg --no-calibration --no-secondary --no-e2e --no-train --no-live-pmc"
 for spec in "$@"; do
     name=${spec%%|*}; envs=${spec#*|}
     env $envs timeout 300 $B > $O/${TAG}_${name}.json 2> $O/${TAG}_${name}.err
