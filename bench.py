@@ -166,6 +166,8 @@ def main():
     ap.add_argument('--no-e2e', action='store_true', help='skip the whole-command leg of BASELINE configs[3]: batch_infer.py over --e2e-rows '
                     'synthetic 30 s WAVs on disk -> CSV (tools/batch_infer_bench.py), both arithmetic modes, rows re-checked one by one')
     ap.add_argument('--e2e-rows', type=int, default=10000, help='rows of the e2e leg (BASELINE configs[3] names 10 000 x 30 s clips)')
+    ap.add_argument('--e2e-distinct', type=int, default=0, help='distinct WAV files of the e2e dataset (the other rows are hard links to them); 0 = rows / 8 '
+                    '(3.3 GB for 10 000 rows, stays in the page cache); 10000 = every row a file of its own (26.5 GB, SURVEY 8(d))')
     ap.add_argument('--e2e-f32-rows', type=int, default=2000, help='rows the exact-f32 arm of the e2e leg annotates (the first N of the same dataset)')
     ap.add_argument('--no-train', action='store_true', help='skip the whole-command leg of BASELINE configs[4] on this GPU: one epoch of train.py '
                     'two_head_model bf16 over a synthetic 3 h binarised dataset (tools/train_epoch_bench.py)')
@@ -538,9 +540,10 @@ def main():
             # with a briefly trained checkpoint (realistic note counts), dataset cached under --scratch.  Three child runs: cold (torch.load +
             # weight pack), warm (cached weight arena) with sampled rows recomputed ONE BY ONE through host Slicer + infer() and compared as
             # CSV strings, and the same in the exact-f32 arithmetic mode.
-            ds = os.path.join(args.scratch, f'e2e_{args.e2e_rows}')
+            distinct = args.e2e_distinct if args.e2e_distinct > 0 else max(8, args.e2e_rows // 8)
+            ds = os.path.join(args.scratch, f'e2e_{args.e2e_rows}' + (f'_d{distinct}' if args.e2e_distinct > 0 else ''))
             tool = [sys.executable, str(ROOT / 'tools' / 'batch_infer_bench.py'), '--clips', str(args.e2e_rows), '--distinct',
-                    str(max(8, args.e2e_rows // 8)), '--seconds', '30', '--lay', str(lay), '--dir', ds, '--train_updates', '300', '--json']
+                    str(distinct), '--seconds', '30', '--lay', str(lay), '--dir', ds, '--train_updates', '300', '--json']
             t_leg = time.perf_counter()
             cold = _tool_json(tool, 1500)
             warm = _tool_json(tool + ['--check', '24'], 1500)

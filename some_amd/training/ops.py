@@ -35,12 +35,7 @@ class TrainOps:
         self._pinned_stream = None
         self.tape: Optional['Tape'] = None        # set by the trainer for the duration of a forward + backward pass
         self._partials: Dict[int, torch.Tensor] = {}
-        self._block_scratch: Dict[int, torch.Tensor] = {}
         self._size_cache: Dict[tuple, int] = {}
-        # Block-level library calls (round 5): one call per FFN sub-block and direction (some_train_ffn_block_fwd / _bwd: the same launches in
-        # the same order as the call-by-call path, bit-identical) - the step is bound by the host's enqueue path at the reference's batch
-        # shape.  SOME_AMD_TRAIN_BLOCK_CALLS=0: the call-by-call path (A/B runs, and the reference for the bit-identity test).
-        self.block_calls = os.environ.get('SOME_AMD_TRAIN_BLOCK_CALLS', '1') != '0'
         self.device_prep = os.environ.get('SOME_AMD_TRAIN_DEVICE_PREP', '1') != '0'    # 0: round 4's torch-side operand preparation (A / B runs)
         # Two LANES (trainer's tape only): the midi and the bound stream of a Gcf layer are independent between the cross gates
         # (Gconform.py:82-87), forward and backward, so the model issues the bound stream's block on lane 1 = a second HIP stream.
@@ -362,13 +357,6 @@ class TrainOps:
         buf = self._scratch.get(self._lane)
         if buf is None or buf.numel() < need:
             buf = self._scratch[self._lane] = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return buf
-
-    def block_scratch(self, need: int) -> torch.Tensor:
-        """Temporaries of a block-level backward call (dy16 | dh16 | dn ...), one buffer per lane, grown on demand."""
-        buf = self._block_scratch.get(self._lane)
-        if buf is None or buf.numel() < need:
-            buf = self._block_scratch[self._lane] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return buf
 
     def partial(self, need: int, wgrad: bool = False) -> torch.Tensor:
@@ -944,308 +932,6 @@ class _Linear(torch.autograd.Function):
         return None, dx, dw, db
 
 
-class _Ffn16(torch.autograd.Function):
-    """The FFN of a conformer block in mixed precision with 16-bit intermediates: x [M, K] fp32 -> y [M, N] fp32.
-    forward:  x16 = rn16(x);  (h16 | a16) = epilogue(x16 W1_16^T + b1) [h16 = rn16(.), a16 = rn16(dropout(silu(h16)))];  y = a16 W2_16^T + b2
-    backward: dy16 = rn16(dy);  dh16 = rn16((dy16 W2_16) * mask / (1 - p) * silu'(h16));  dx = dh16 W1_16;
-              dW2 += dy16^T a16, db2 += 1^T dy16, dW1 += dh16^T x16, db1 += 1^T dh16
-    - what nn.Linear / SiLU / Dropout compute under the reference's bf16 / fp16 autocast (16-bit linear outputs, fp32 accumulation)."""
-
-    @staticmethod
-    def forward(ctx, ops: TrainOps, x, w1, b1, w2, b2, p, seed):
-        M, K = x.shape
-        H, N = w1.shape[0], w2.shape[0]
-        x16 = ops.cast16(x.contiguous())
-        w1_16, _ = ops.shadow16(w1)
-        w2_16, _ = ops.shadow16(w2)
-        ha = torch.empty((2, M, H), dtype=ops.dtype16, device=ops.device)            # h16 plane, a16 plane
-        ops.gemm16s(1, x16, w1_16, b1, ha, H, M, H, K, plane=M * H, p=p, seed=seed)
-        y = ops.new(M, N)
-        ops.gemm16s(0, ha[1], w2_16, b2, y, N, M, N, H)
-        ctx.ops, ctx.p, ctx.seed = ops, p, seed
-        ctx.save_for_backward(x16, ha)
-        ctx.params = (w1, b1, w2, b2)                                                # identities: shadows and gradient sinks
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        ops: TrainOps = ctx.ops
-        x16, ha = ctx.saved_tensors
-        w1, b1, w2, b2 = ctx.params
-        M, K = x16.shape
-        H, N = w1.shape[0], w2.shape[0]
-        dy16 = ops.cast16(dy.contiguous())
-        dh16 = torch.empty((M, H), dtype=ops.dtype16, device=ops.device)
-        ops.gemm16s(2, dy16, ops.shadow16(w2)[1], None, dh16, H, M, H, N, h16=ha[0], p=ctx.p, seed=ctx.seed)
-        dx = None
-        if ctx.needs_input_grad[1]:
-            dx = ops.new(M, K)
-            ops.gemm16s(0, dh16, ops.shadow16(w1)[1], None, dx, K, M, K, H)
-        grads = []
-        for (w, b, g16, in16, iw, ib) in ((w1, b1, dh16, x16, 2, 3), (w2, b2, dy16, ha[1], 4, 5)):
-            dw = db = None
-            want_w, want_b = ctx.needs_input_grad[iw], b is not None and ctx.needs_input_grad[ib]
-            sw = ops.sink(w) if want_w else None
-            sb = ops.sink(b) if want_b else None
-            if want_w and sw is not None and (sb is not None or not want_b):
-                ops.wgrad16(g16, in16, sw, sb, accumulate=True)                      # into the parameters' gradient arrays
-                ops.deposited(w)
-                if sb is not None:
-                    ops.deposited(b)
-            elif want_w or want_b:
-                dw = ops.new(*w.shape)
-                db = ops.new(w.shape[0]) if want_b else None
-                ops.wgrad16(g16, in16, dw, db, accumulate=False)
-                if not want_w:
-                    dw = None
-            grads += [dw, db]
-        return None, dx, grads[0], grads[1], grads[2], grads[3], None, None
-
-
-class _FfnBlock16(torch.autograd.Function):
-    """x + alpha * dropout(ffn(LayerNorm(x))) in mixed precision, every intermediate written once and in 16 bits where a GEMM reads it:
-    forward:  n16 = rn16(LayerNorm(x)) (one kernel, no cast pass);  (h16 | a16) = FFN1 epilogue;  out = x + alpha * dropout(a16 W2^T + b2)
-              in FFN2's epilogue (no separate residual pass)
-    backward: dy16 = rn16(alpha * mask / (1 - p) * d) (one kernel);  dh16, weight gradients as in _Ffn16;  dn = dh16 W1;
-              dx = d + LayerNorm'(dn) with the addition inside the LayerNorm-backward kernel."""
-
-    @staticmethod
-    def forward(ctx, ops: TrainOps, x, gamma, beta, w1, b1, w2, b2, alpha, p_latent, seed_latent, p_out, seed_out):
-        x = x.contiguous()
-        M, K = x.shape
-        H, N = w1.shape[0], w2.shape[0]
-        ctx.ops = ops
-        ctx.drop = (alpha, p_latent, seed_latent, p_out, seed_out)
-        ctx.params = (gamma, beta, w1, b1, w2, b2)                                   # identities: shadows and gradient sinks
-        if ops.block_calls and b1 is not None and b2 is not None:
-            # one library call for the sub-block (some_train_ffn_block_fwd: the same three launches); ONE allocation holds what the backward needs
-            save = torch.empty(ops._bytes('some_train_ffn_block_save_bytes', M, K, H), dtype=torch.uint8, device=ops.device)
-            out = ops.new(M, N)
-            ops.check(ops.lib.some_train_ffn_block_fwd(ops.h, _p(x), _p(gamma), _p(beta), _p(ops.shadow16(w1)[0]), _p(b1), _p(ops.shadow16(w2)[0]), _p(b2),
-                                                       M, K, H, N, ops._hi_mode, float(alpha), float(p_latent), seed_latent, float(p_out), seed_out,
-                                                       _p(save), save.numel(), _p(out), ops.stream()))
-            ctx.block = True
-            ctx.save_for_backward(x, gamma, save)
-            return out
-        ctx.block = False
-        n16 = torch.empty((M, K), dtype=ops.dtype16, device=ops.device)
-        mean, rstd = ops.new(M), ops.new(M)
-        ops.check(ops.lib.some_train_layernorm_fwd16(ops.h, _p(x), _p(gamma), _p(beta), _p(n16), _p(mean), _p(rstd), M, ops._hi_mode, ops.stream()))
-        ha = torch.empty((2, M, H), dtype=ops.dtype16, device=ops.device)            # h16 plane, a16 plane
-        ops.gemm16s(1, n16, ops.shadow16(w1)[0], b1, ha, H, M, H, K, plane=M * H, p=p_latent, seed=seed_latent)
-        out = ops.new(M, N)
-        ops.gemm16s(3, ha[1], ops.shadow16(w2)[0], b2, out, N, M, N, H, h16=x, p=p_out, seed=seed_out, alpha=alpha)
-        ctx.save_for_backward(x, gamma, mean, rstd, n16, ha)
-        return out
-
-    @staticmethod
-    def backward(ctx, d):
-        ops: TrainOps = ctx.ops
-        gamma, beta, w1, b1, w2, b2 = ctx.params
-        alpha, p_latent, seed_latent, p_out, seed_out = ctx.drop
-        d = d.contiguous()
-        if ctx.block:
-            x, gamma_t, save = ctx.saved_tensors
-            M, K = x.shape
-            H, N = w1.shape[0], w2.shape[0]
-            sinks = [ops.sink(t) for t in (w1, b1, w2, b2, gamma, beta)]
-            if all(t is not None for t in sinks) and all(ctx.needs_input_grad[i] for i in (2, 3, 4, 5, 6, 7)):
-                # one library call (some_train_ffn_block_bwd): every gradient lands in the flat gradient buffer, dx = d + LayerNorm'(dn)
-                dx = torch.empty_like(x)
-                need = ops._bytes('some_train_ffn_block_scratch_bytes', M, K, H, N)
-                # (weight-gradient lanes: dy16 / dh16 in the scratch block are read on the side stream after this call has returned -
-                # a block of its own per call, released with the other operands when the lanes are joined)
-                scr = torch.empty(need, dtype=torch.uint8, device=ops.device) if ops._wg_active else ops.block_scratch(need)
-                sc = ops.scratch(M, 512)
-                n1, n2 = ops._bytes('some_train_gemm16_bytes', H, K, M, K + 4), ops._bytes('some_train_gemm16_bytes', N, H, M, H + 4)
-                # (deferred reductions: planes for both weight gradients, the second behind the first rounded up to 256 bytes)
-                part, part_bytes = ops.wgrad_planes((n1 + 255) // 256 * 256 + n2 if ops._wg_active and ops.wgrad_defer else max(n1, n2))
-                ops.check(ops.lib.some_train_ffn_block_bwd(ops.h, _p(d), _p(x), _p(gamma_t), _p(save), _p(ops.shadow16(w1)[1]), _p(ops.shadow16(w2)[1]),
-                                                           M, K, H, N, ops._hi_mode, float(alpha), float(p_latent), seed_latent, float(p_out), seed_out,
-                                                           _p(sinks[0]), _p(sinks[1]), _p(sinks[2]), _p(sinks[3]), _p(sinks[4]), _p(sinks[5]),
-                                                           1 if ctx.needs_input_grad[1] else 0, _p(dx), _p(scr), scr.numel(), _p(sc), sc.numel(),
-                                                           part, part_bytes, ops.stream()))
-                ops.wgrad_issued(save, scr)
-                for t in (w1, b1, w2, b2, gamma, beta):
-                    ops.deposited(t)
-                return None, dx, None, None, None, None, None, None, None, None, None, None, None
-            # (a parameter without a gradient sink: unpack the save block into the tensors of the call-by-call path below)
-            o0 = (M * K * 2 + 255) // 256 * 256
-            o1 = o0 + (M * 4 + 255) // 256 * 256
-            o2 = o1 + (M * 4 + 255) // 256 * 256
-            n16 = save[:M * K * 2].view(ops.dtype16).view(M, K)
-            mean, rstd = save[o0:o0 + M * 4].view(torch.float32), save[o1:o1 + M * 4].view(torch.float32)
-            ha = save[o2:o2 + 2 * M * H * 2].view(ops.dtype16).view(2, M, H)
-        else:
-            x, gamma_t, mean, rstd, n16, ha = ctx.saved_tensors
-        M, K = x.shape
-        H, N = w1.shape[0], w2.shape[0]
-        dy16 = torch.empty((M, N), dtype=ops.dtype16, device=ops.device)
-        ops.check(ops.lib.some_train_dropcast16(ops.h, _p(d), _p(dy16), M, N, float(alpha), float(p_out), seed_out, ops._hi_mode, ops.stream()))
-        dh16 = torch.empty((M, H), dtype=ops.dtype16, device=ops.device)
-        ops.gemm16s(2, dy16, ops.shadow16(w2)[1], None, dh16, H, M, H, N, h16=ha[0], p=p_latent, seed=seed_latent)
-        dn = ops.new(M, K)
-        ops.gemm16s(0, dh16, ops.shadow16(w1)[1], None, dn, K, M, K, H)
-        grads = []
-        for (w, b, g16, in16, iw, ib) in ((w1, b1, dh16, n16, 4, 5), (w2, b2, dy16, ha[1], 6, 7)):
-            dw = db = None
-            want_w, want_b = ctx.needs_input_grad[iw], b is not None and ctx.needs_input_grad[ib]
-            sw = ops.sink(w) if want_w else None
-            sb = ops.sink(b) if want_b else None
-            if want_w and sw is not None and (sb is not None or not want_b):
-                ops.wgrad16(g16, in16, sw, sb, accumulate=True)                      # into the parameters' gradient arrays
-                ops.deposited(w)
-                if sb is not None:
-                    ops.deposited(b)
-            elif want_w or want_b:
-                dw = ops.new(*w.shape)
-                db = ops.new(w.shape[0]) if want_b else None
-                ops.wgrad16(g16, in16, dw, db, accumulate=False)
-                if not want_w:
-                    dw = None
-            grads += [dw, db]
-        # dx = d (the residual branch) + LayerNorm'(dn); gamma / beta gradients as in _LayerNorm
-        dx = torch.empty_like(x)
-        sc = ops.scratch(M, 512)
-        sg, sbeta = ops.sink(gamma), ops.sink(beta)
-        add = d if ctx.needs_input_grad[1] else None
-        if sg is not None and sbeta is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
-            ops.check(ops.lib.some_train_layernorm_bwd_add(ops.h, _p(dn), _p(x), _p(gamma_t), _p(mean), _p(rstd), _p(add), _p(dx), _p(sg), _p(sbeta), 1, M,
-                                                           _p(sc), sc.numel(), ops.stream()))
-            ops.deposited(gamma)
-            ops.deposited(beta)
-            dg = dbeta = None
-        else:
-            dg, dbeta = torch.empty_like(gamma_t), torch.empty_like(gamma_t)
-            ops.check(ops.lib.some_train_layernorm_bwd_add(ops.h, _p(dn), _p(x), _p(gamma_t), _p(mean), _p(rstd), _p(add), _p(dx), _p(dg), _p(dbeta), 0, M,
-                                                           _p(sc), sc.numel(), ops.stream()))
-        return None, dx, dg, dbeta, grads[0], grads[1], grads[2], grads[3], None, None, None, None, None
-
-
-def _sub(fn, *args):
-    """Run the body of another operator inside a fused one: (output, its context for the backward body)."""
-    c = _Ctx()
-    c.needs_input_grad = tuple(isinstance(a, torch.Tensor) for a in args)
-    return fn.forward(c, *args), c
-
-
-def _ln16(ops: TrainOps, x, gamma, beta):
-    M = x.shape[0]
-    n16 = torch.empty(x.shape, dtype=ops.dtype16, device=ops.device)
-    mean, rstd = ops.new(M), ops.new(M)
-    ops.check(ops.lib.some_train_layernorm_fwd16(ops.h, _p(x), _p(gamma), _p(beta), _p(n16), _p(mean), _p(rstd), M, ops._hi_mode, ops.stream()))
-    return n16, mean, rstd
-
-
-def _ln_bwd_add_into_sinks(ops: TrainOps, dn, x, gamma_t, mean, rstd, add, gamma, beta):
-    """dx = add + LayerNorm'(dn); dgamma / dbeta accumulate in the parameters' gradient arrays."""
-    M = x.shape[0]
-    dx = torch.empty_like(x)
-    sc = ops.scratch(M, 512)
-    ops.check(ops.lib.some_train_layernorm_bwd_add(ops.h, _p(dn), _p(x), _p(gamma_t), _p(mean), _p(rstd), _p(add), _p(dx), _p(ops.sink(gamma)),
-                                                   _p(ops.sink(beta)), 1, M, _p(sc), sc.numel(), ops.stream()))
-    ops.deposited(gamma)
-    ops.deposited(beta)
-    return dx
-
-
-def _wgrad16_into_sinks(ops: TrainOps, g16, in16, w, b):
-    ops.wgrad16(g16, in16, ops.sink(w), ops.sink(b) if b is not None else None, accumulate=True)
-    ops.deposited(w)
-    if b is not None:
-        ops.deposited(b)
-
-
-class _AttnBlock16(torch.autograd.Function):
-    """x + dropout(Wo attention(Wqkv LayerNorm(x)) + bo) in mixed precision (ops.can_block16: every parameter has a gradient sink):
-    LayerNorm writes the 16-bit GEMM operand, to_q | to_kv are one [1536, 512] matrix (adjacent in the flat buffer: no concatenation),
-    residual + dropout sit in the output projection's epilogue, their gradient and the 16-bit cast in one kernel, the residual gradient is
-    summed inside LayerNorm-backward; the attention core is the _Attention operator's own forward / backward."""
-
-    @staticmethod
-    def forward(ctx, ops: TrainOps, x, gamma, beta, wq, wkv, wo, bo, batch, p, seed):
-        x = x.contiguous()
-        M = x.shape[0]
-        wqkv, _ = ops.joined(wq, wkv)
-        n16, mean, rstd = _ln16(ops, x, gamma, beta)
-        qkv = ops.new(M, 1536)
-        ops.gemm16s(0, n16, ops.shadow16(wqkv)[0], None, qkv, 1536, M, 1536, 512)
-        att, actx = _sub(_Attention, ops, qkv, batch)
-        att16 = ops.cast16(att)
-        out = ops.new(M, 512)
-        ops.gemm16s(3, att16, ops.shadow16(wo)[0], bo, out, 512, M, 512, 512, h16=x, p=p, seed=seed, alpha=1.0)
-        ctx.ops, ctx.actx, ctx.drop = ops, actx, (p, seed)
-        ctx.save_for_backward(x, gamma, mean, rstd, n16, att16)
-        ctx.params = (gamma, beta, wq, wkv, wo, bo)
-        return out
-
-    @staticmethod
-    def backward(ctx, d):
-        ops: TrainOps = ctx.ops
-        x, gamma_t, mean, rstd, n16, att16 = ctx.saved_tensors
-        gamma, beta, wq, wkv, wo, bo = ctx.params
-        d = d.contiguous()
-        M = x.shape[0]
-        dy16 = ops.dropcast16(d, 1.0, *ctx.drop)
-        datt = ops.new(M, 512)
-        ops.gemm16s(0, dy16, ops.shadow16(wo)[1], None, datt, 512, M, 512, 512)
-        _wgrad16_into_sinks(ops, dy16, att16, wo, bo)
-        dqkv16 = _attention_bwd16(ctx.actx, datt) if ctx.actx.prec == 'f16x3' else ops.cast16(_Attention.backward(ctx.actx, datt)[1])
-        wqkv, gqkv = ops.joined(wq, wkv)
-        dn = ops.new(M, 512)
-        ops.gemm16s(0, dqkv16, ops.shadow16(wqkv)[1], None, dn, 512, M, 512, 1536)
-        ops.wgrad16(dqkv16, n16, gqkv, None, accumulate=True)
-        ops.deposited(wq)
-        ops.deposited(wkv)
-        dx = _ln_bwd_add_into_sinks(ops, dn, x, gamma_t, mean, rstd, d, gamma, beta)
-        return None, dx, None, None, None, None, None, None, None, None, None
-
-
-class _ConvBlock16(torch.autograd.Function):
-    """x + dropout(pw2 silu(BatchNorm(dwconv(GLU(pw1 LayerNorm(x)))))) in mixed precision: LayerNorm and SiLU write the 16-bit GEMM operands,
-    residual + dropout sit in pointwise_conv2's epilogue; GLU, the depthwise convolution and BatchNorm are their operators' own bodies."""
-
-    @staticmethod
-    def forward(ctx, ops: TrainOps, x, gamma, beta, pw1_w, pw1_b, dw_w, dw_b, bn_g, bn_b, bn_rm, bn_rv, pw2_w, pw2_b, batch, p, seed):
-        x = x.contiguous()
-        M = x.shape[0]
-        n16, mean, rstd = _ln16(ops, x, gamma, beta)
-        p1 = ops.new(M, 1024)
-        ops.gemm16s(0, n16, ops.shadow16(pw1_w)[0], pw1_b, p1, 1024, M, 1024, 512)
-        g, gctx = _sub(_Glu, ops, p1)
-        c, cctx = _sub(_DwConv, ops, g, dw_w, dw_b, batch)
-        bn, bctx = _sub(_BatchNorm, ops, c, bn_g, bn_b, bn_rm, bn_rv, 0.1, 1e-5)
-        s16 = ops.silu16(bn)
-        out = ops.new(M, 512)
-        ops.gemm16s(3, s16, ops.shadow16(pw2_w)[0], pw2_b, out, 512, M, 512, 512, h16=x, p=p, seed=seed, alpha=1.0)
-        ctx.ops, ctx.sub, ctx.drop = ops, (gctx, cctx, bctx), (p, seed)
-        ctx.save_for_backward(x, gamma, mean, rstd, n16, bn, s16)
-        ctx.params = (gamma, beta, pw1_w, pw1_b, pw2_w, pw2_b)
-        return out
-
-    @staticmethod
-    def backward(ctx, d):
-        ops: TrainOps = ctx.ops
-        x, gamma_t, mean, rstd, n16, bn, s16 = ctx.saved_tensors
-        gamma, beta, pw1_w, pw1_b, pw2_w, pw2_b = ctx.params
-        gctx, cctx, bctx = ctx.sub
-        d = d.contiguous()
-        M = x.shape[0]
-        dy16 = ops.dropcast16(d, 1.0, *ctx.drop)
-        ds = ops.new(M, 512)
-        ops.gemm16s(0, dy16, ops.shadow16(pw2_w)[1], None, ds, 512, M, 512, 512)
-        _wgrad16_into_sinks(ops, dy16, s16, pw2_w, pw2_b)
-        dbn = ops.eltwise(_lib.ELT_SILU_BWD, ds, bn)
-        _, dc, dbn_g, dbn_b = _BatchNorm.backward(bctx, dbn)[:4]
-        _, dg, ddw_w, ddw_b = _DwConv.backward(cctx, dc)[:4]
-        dp1_16 = ops.cast16(_Glu.backward(gctx, dg)[1])
-        dn = ops.new(M, 512)
-        ops.gemm16s(0, dp1_16, ops.shadow16(pw1_w)[1], None, dn, 512, M, 512, 1024)
-        _wgrad16_into_sinks(ops, dp1_16, n16, pw1_w, pw1_b)
-        dx = _ln_bwd_add_into_sinks(ops, dn, x, gamma_t, mean, rstd, d, gamma, beta)
-        return None, dx, None, None, None, None, ddw_w, ddw_b, dbn_g, dbn_b, None, None, None, None, None, None, None
-
-
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ops: TrainOps, x, gamma, beta):
@@ -1598,3 +1284,7 @@ class _Emd(torch.autograd.Function):
     def backward(ctx, g):
         (dp,) = ctx.saved_tensors
         return None, dp * g, None, None, None
+
+
+# the fused 16-bit sub-block operators (mixed precision) live in blocks16.py; imported last: they are built from the operators above
+from .blocks16 import _AttnBlock16, _ConvBlock16, _Ffn16, _FfnBlock16  # noqa: E402,F401

@@ -457,3 +457,60 @@ def test_attention_backward_poisons_the_gradient_when_dO_is_not_finite(ops):
         assert not torch.isfinite(got.float()).all()                  # the trainer's non-finite check sees it (task.py)
     finally:
         ops.set_mixed_precision(False)
+
+
+def test_ffn_block_library_calls_equal_the_call_by_call_operator_bit_for_bit():
+    """some_train_ffn_block_fwd / _bwd (one library call per direction for the FFN sub-block; round 5) are entry points of the C ABI the
+    shipped trainer no longer takes (no measured gain: profiles/r05aa_train_ab.txt; the caller is kept in tools/patches/r06_ffn_block_calls.patch).
+    They stay pinned here: same launches in the same order as _FfnBlock16's call-by-call body - output, dx and all six parameter
+    gradients (into preallocated gradient arrays) bit for bit, dropout on."""
+    import ctypes as C
+    from some_amd.configs import get_config
+    from some_amd.engine import Engine
+    from some_amd.training.ops import TrainOps, _FfnBlock16, _Ctx
+    ops = TrainOps(Engine(get_config('two_head_model', lay=1), device='cuda'))
+    ops.set_mixed_precision(True, 'bf16')
+    g = torch.Generator(device='cuda').manual_seed(12)
+    M, K, H = 700, 512, 2048
+    x = torch.randn(M, K, device='cuda', generator=g)
+    gamma, beta = torch.rand(K, device='cuda', generator=g) + 0.5, torch.randn(K, device='cuda', generator=g) * 0.1
+    w1, b1 = torch.randn(H, K, device='cuda', generator=g) / 22, torch.randn(H, device='cuda', generator=g) * 0.1
+    w2, b2 = torch.randn(K, H, device='cuda', generator=g) / 45, torch.randn(K, device='cuda', generator=g) * 0.1
+    d = torch.randn(M, K, device='cuda', generator=g)
+    params = [gamma, beta, w1, b1, w2, b2]
+    for t in params:
+        t.grad = torch.zeros_like(t)
+    ops.register_grad_sinks(params)
+    alpha, p_lat, s_lat, p_out, s_out = 0.5, 0.1, 1234, 0.1, 5678
+    # the operator's own (call-by-call) body
+    c = _Ctx()
+    c.needs_input_grad = (False, True, True, True, True, True, True, True, False, False, False, False, False)
+    ops.pin_stream()
+    try:
+        want = _FfnBlock16.forward(c, ops, x, gamma, beta, w1, b1, w2, b2, alpha, p_lat, s_lat, p_out, s_out)
+        dx_want = _FfnBlock16.backward(c, d)[1]
+        torch.cuda.synchronize()
+        grads_want = [t.grad.clone() for t in params]
+        for t in params:
+            t.grad.zero_()
+        # the two library calls
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        lib, h = ops.lib, ops.h
+        save = torch.empty(int(lib.some_train_ffn_block_save_bytes(h, M, K, H)), dtype=torch.uint8, device='cuda')
+        out = torch.empty(M, K, device='cuda')
+        ops.check(lib.some_train_ffn_block_fwd(h, p(x), p(gamma), p(beta), p(ops.shadow16(w1)[0]), p(b1), p(ops.shadow16(w2)[0]), p(b2), M, K, H, K,
+                                               ops._hi_mode, alpha, p_lat, s_lat, p_out, s_out, p(save), save.numel(), p(out), ops.stream()))
+        dx = torch.empty_like(x)
+        scr = torch.empty(int(lib.some_train_ffn_block_scratch_bytes(h, M, K, H, K)), dtype=torch.uint8, device='cuda')
+        sc = ops.scratch(M, 512)
+        n1, n2 = ops._bytes('some_train_gemm16_bytes', H, K, M, K + 4), ops._bytes('some_train_gemm16_bytes', K, H, M, H + 4)
+        part = torch.empty(max(n1, n2), dtype=torch.uint8, device='cuda')
+        ops.check(lib.some_train_ffn_block_bwd(h, p(d), p(x), p(gamma), p(save), p(ops.shadow16(w1)[1]), p(ops.shadow16(w2)[1]), M, K, H, K, ops._hi_mode,
+                                               alpha, p_lat, s_lat, p_out, s_out, p(w1.grad), p(b1.grad), p(w2.grad), p(b2.grad), p(gamma.grad), p(beta.grad),
+                                               1, p(dx), p(scr), scr.numel(), p(sc), sc.numel(), part.data_ptr(), part.numel(), ops.stream()))
+        torch.cuda.synchronize()
+    finally:
+        ops.unpin_stream()
+    assert torch.equal(out, want) and torch.equal(dx, dx_want)
+    for t, gw in zip(params, grads_want):
+        assert torch.equal(t.grad, gw) and float(gw.abs().sum()) > 0
