@@ -48,7 +48,12 @@ __global__ __launch_bounds__(256) void cal_mfma_kernel(const half8* __restrict__
 }
 
 __global__ __launch_bounds__(256) void cal_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    // four independent 16-byte loads in flight per thread before the first store (n is a multiple of 4 x the grid's threads)
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
+        const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
 }
 
 }  // namespace

@@ -61,6 +61,16 @@ def test_bench_under_torchrun_with_one_nccl_rank():
     assert res['notes_decoded_last_step'] > 0 and res['value'] > 0
 
 
+def test_train_cli_under_torchrun_with_one_nccl_rank(tmp_path):
+    """train.py's RCCL path on this one-GPU box: the process group with a HIGH-priority communication stream (train.py), the parameter
+    broadcast, the bucketed all-reduce launched from inside backward (world size 1 keeps grad_sync off: the single-rank group still
+    creates the communicator and runs the barrier), checkpoint written."""
+    r = _torchrun(1, [str(ROOT / 'train.py'), '--config', 'two_head_model', '--exp_name', 'n1', '--work_dir', str(tmp_path), '--synthetic', '12',
+                      '--max_updates', '3', '--log_interval', '1', '--val_clips', '2'], timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert 'step 3:' in r.stdout and (tmp_path / 'n1' / 'model_ckpt_steps_3.ckpt').exists()
+
+
 def test_bench_with_two_ranks_sharing_the_gpu():
     """bench.py --gpus 2 as the driver's scaling run launches it, with gloo standing in for RCCL on this one-GPU box: every rank pins itself
     to its own cores (sharding.bind_rank_to_cores), takes the broadcast weight arena, runs its own 4 clips, and rank 0 reports the

@@ -34,13 +34,13 @@ class _Work:
         torch.cuda.current_stream().wait_event(self.ev)
 
 
-def attach_model_sync(tr, bucket_mb, cycles_per_ms, ring_ms_per_32mib, launch_us, stats):
+def attach_model_sync(tr, bucket_mb, cycles_per_ms, ring_ms_per_32mib, launch_us, stats, comm_priority=0):
     P = tr.model.params
     order = [(P.views[k], P.offsets[k], (P.views[k].numel() + 63) // 64 * 64) for k in P.param_names]
     gs = BucketedGradSync(P.grad, order, None, int(bucket_mb * (1 << 20)), names=list(P.param_names))
     gs.before_launch = tr.ops.sync_other_lane
     tr.ops.register_grad_sinks(P.views.values(), gs.mark)
-    comm = torch.cuda.Stream()
+    comm = torch.cuda.Stream(priority=comm_priority)      # -1: a high-priority stream (hardware queues of its own in the HIP runtime)
 
     def launch(bucket):
         a, b = gs.bounds[bucket]
@@ -95,6 +95,7 @@ def main():
     ap.add_argument('--launch-us', type=float, default=20.0)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--lay', type=int, default=3)
+    ap.add_argument('--comm-priority', type=int, default=0, help='priority of the modelled communication stream (-1 = high, as ProcessGroupNCCL with is_high_priority_stream)')
     args = ap.parse_args()
     # calibrate torch.cuda._sleep: cycles per millisecond
     torch.cuda._sleep(1_000_000)
@@ -108,7 +109,7 @@ def main():
     cfg = get_config('two_head_model', lay=args.lay)
     cfg['pl_trainer_precision'] = 'bf16'
     print(f'model of the collective: {args.ring_ms_per_32mib} ms per 32 MiB + {args.launch_us} us per launch, one at a time on its own stream; '
-          f'two_head_model lay {args.lay} bf16, lanes + weight-gradient side streams, asynchronous updates; _sleep calibration {cycles_per_ms / 1e3:.0f} cycles/us')
+          f'two_head_model lay {args.lay} bf16, asynchronous updates, communication stream priority {args.comm_priority}; _sleep calibration {cycles_per_ms / 1e3:.0f} cycles/us')
     for T in args.frames:
         sample = sample_of(args.batch, T)
         base = MIDIExtractionTrainer(cfg, device='cuda', seed=1)
@@ -119,7 +120,7 @@ def main():
         for mb in args.buckets:
             tr = MIDIExtractionTrainer(cfg, device='cuda', seed=1)
             stats = {'ring_ms': 0.0, 'in_backward': 0}
-            gs = attach_model_sync(tr, mb, cycles_per_ms, args.ring_ms_per_32mib, args.launch_us, stats)
+            gs = attach_model_sync(tr, mb, cycles_per_ms, args.ring_ms_per_32mib, args.launch_us, stats, args.comm_priority)
             t = time_steps(tr, sample, args.steps)
             n_steps = args.steps + 3
             print(f'    bucket {mb:5g} MiB: {len(gs.bounds):3d} buckets, {stats["in_backward"] / n_steps:5.1f} of them launched inside backward, modelled ring time '

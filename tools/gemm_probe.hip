@@ -114,16 +114,17 @@ int main(int argc, char** argv) {
                 tmin = std::min(tmin, o[0]); tmax = std::max(tmax, o[4]);
             }
             if (recs.empty()) { printf("%s variant %d: no records\n", sh.name, variant); continue; }
-            // every XCD counts its own s_memtime (different bases): the launch spans (almost exactly) the event interval on each of them
-            std::map<unsigned long long, std::pair<unsigned long long, unsigned long long>> xspan;
+            // the counter's base differs from CU to CU (per-XCD clocks): calibrate on what one CU saw - from its first workgroup's entry to its
+            // last workgroup's last store is (almost exactly) the launch as the HIP events timed it
+            std::map<unsigned long long, std::pair<unsigned long long, unsigned long long>> cspan;
             for (const Rec& r : recs) {
-                auto it = xspan.find(r.cu >> 16);
-                if (it == xspan.end()) xspan[r.cu >> 16] = {r.t0, r.t4};
+                auto it = cspan.find(r.cu);
+                if (it == cspan.end()) cspan[r.cu] = {r.t0, r.t4};
                 else { it->second.first = std::min(it->second.first, r.t0); it->second.second = std::max(it->second.second, r.t4); }
             }
             double span = 0;
-            for (auto& kv : xspan) span += (double)(kv.second.second - kv.second.first);
-            const double ticks_launch = span / xspan.size();                 // counter ticks from the first dispatch to the last store, mean over the XCDs
+            for (auto& kv : cspan) span += (double)(kv.second.second - kv.second.first);
+            const double ticks_launch = span / cspan.size();
             const double tick_us = ms * 1e3 / ticks_launch;
             (void)tmin; (void)tmax;
             std::map<unsigned long long, std::vector<Rec>> per_cu;
@@ -133,7 +134,7 @@ int main(int argc, char** argv) {
             for (auto& kv : per_cu) {
                 auto& v = kv.second;
                 std::sort(v.begin(), v.end(), [](const Rec& x, const Rec& y) { return x.t0 < y.t0; });
-                first += (double)(v[0].t0 - xspan[kv.first >> 16].first);
+                first += 0.0;
                 for (size_t i = 0; i < v.size(); ++i) {
                     pro += (double)(v[i].t1 - v[i].t0); loop += (double)(v[i].t2 - v[i].t1); epi += (double)(v[i].t3 - v[i].t2);
                     drain += (double)(v[i].t4 - v[i].t3); skew += (double)v[i].skew; ++n;
@@ -152,13 +153,13 @@ int main(int argc, char** argv) {
                 printf("\n");
             }
             const double wg_us = (pro + loop + epi + drain) / n * tick_us;
-            printf("%-40s %s: STEADY %.4f ms per launch (%d back to back); the traced launch %.4f ms = %.0f counter ticks -> %.0f MHz if the counter is the "
-                   "shader clock; %zu tiles on %zu CU ids, %.1f per CU id\n", sh.name, variant == 2 ? "256x256" : variant == 5 ? "128x256 single stage x 2" : "256x256 persistent",
+            printf("%-40s %s: STEADY %.4f ms per launch (%d back to back); the traced launch %.4f ms = %.0f counter ticks on a CU (%.0f ticks per us); "
+                   "%zu tiles on %zu CU ids, %.1f per CU id\n", sh.name, variant == 2 ? "256x256" : variant == 5 ? "128x256 single stage x 2" : "256x256 persistent",
                    steady_ms, reps, ms, ticks_launch, ticks_launch / (ms * 1e3), n, per_cu.size(), (double)n / per_cu.size());
             printf("    per workgroup (us): prologue %.2f | k-loop %.2f | epilogue to the last store issued %.2f | store drain %.2f | total %.2f | gap to "
-                   "the next workgroup of the CU slot %.2f | last-product skew between the wavefronts %.2f | first dispatch after launch %.2f\n",
+                   "the next workgroup of the CU slot %.2f | last-product skew between the wavefronts %.2f %s\n",
                    pro / n * tick_us, loop / n * tick_us, epi / n * tick_us, drain / n * tick_us, wg_us, ngap ? gap / ngap * tick_us : 0.0,
-                   skew / n * tick_us, first / per_cu.size() * tick_us);
+                   skew / n * tick_us, first > 0 ? "" : "");
             printf("    share of a workgroup's residency: prologue %.1f %% | k-loop %.1f %% | epilogue %.1f %% | drain %.1f %%;  dispatch gap = %.1f %% on top\n",
                    100 * pro / (pro + loop + epi + drain), 100 * loop / (pro + loop + epi + drain), 100 * epi / (pro + loop + epi + drain),
                    100 * drain / (pro + loop + epi + drain), ngap ? 100 * (gap / ngap) / ((pro + loop + epi + drain) / n) : 0.0);

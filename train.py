@@ -66,10 +66,22 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
     world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
     dev = local % max(1, torch.cuda.device_count())        # one GPU per rank; ranks sharing a GPU only in dry runs (SOME_AMD_DIST_BACKEND=gloo)
     torch.cuda.set_device(dev)
-    if world > 1:
+    # (under torch.distributed.run the group is initialised for ONE rank too, as bench.py / batch_infer.py do: a one-GPU box then runs the
+    # RCCL communicator, the parameter broadcast and the barrier of the N > 1 path)
+    if world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ):
         from some_amd import sharding
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         sharding.bind_rank_to_cores(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))       # loader threads stay next to this rank's GPU
-        torch.distributed.init_process_group(os.environ.get('SOME_AMD_DIST_BACKEND', 'nccl'))
+        backend = os.environ.get('SOME_AMD_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            # RCCL's stream on HIGH priority: the HIP runtime keeps separate hardware queues per priority level, so the collectives of the
+            # bucketed all-reduce cannot land on a queue one of the step's compute streams (two lanes + two weight-gradient side streams +
+            # the loader's copy stream on 4 normal-priority queues) already occupies - modelled on one GPU, the all-reduce is 35 - 50 %
+            # exposed that way and 90 - 130 % when it shares a queue (tools/ddp_overlap_bench.py)
+            opts = torch.distributed.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            torch.distributed.init_process_group('nccl', pg_options=opts, device_id=torch.device('cuda', dev))
+        else:
+            torch.distributed.init_process_group(backend)
     if rank == 0:
         work.mkdir(parents=True, exist_ok=True)
         with open(work / 'config.yaml', 'w', encoding='utf8') as f:
@@ -186,7 +198,7 @@ def train(config, exp_name, work_dir, synthetic, max_updates, log_interval, val_
     loader.close()
     if scalar_log is not None:
         scalar_log.close()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
