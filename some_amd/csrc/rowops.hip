@@ -25,6 +25,10 @@ __device__ __forceinline__ float wave_max(float v) {
 #ifndef LN_ROWS
 #define LN_ROWS 2               // rows per wavefront and iteration (independent load -> reduce -> store chains in flight)
 #endif
+#ifndef LN_STORE16
+#define LN_STORE16 0            // 1: SPLIT32 output as 16-byte stores (lane pairs exchange halves by DPP: the even lane stores the pair's 8 hi
+                                // halves, the odd lane its 8 lo halves) instead of four 8-byte stores per lane - same values, same arithmetic
+#endif
 #ifndef LN_NT
 #define LN_NT 0                 // 1: non-temporal stores (the output is re-read by a GEMM after 0.7 GB of other traffic)
 #endif
@@ -84,11 +88,33 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
                     split_f16(o0[i], h, l); h0[i] = h; l0[i] = l;
                     split_f16(o1[i], h, l); h1[i] = h; l1[i] = l;
                 }
+#if LN_STORE16
+                // lanes 2 j, 2 j + 1 hold elements 8 j .. 8 j + 7 of a 32-element k-block (4 each): after the exchange the even lane owns
+                // the 16 bytes of hi halves, the odd lane the 16 bytes of lo halves of those 8 elements
+                typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+                typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+                const bool odd = lane & 1;
+                auto xchg = [&](half4 mine_keep, half4 mine_give) -> u32x4_ {
+                    const u32x2_ keep = __builtin_bit_cast(u32x2_, mine_keep), give = __builtin_bit_cast(u32x2_, mine_give);
+                    // quad permute [1, 0, 3, 2]: every lane reads its pair partner's `give`
+                    const uint32_t o0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)give[0], 0xB1, 0xF, 0xF, true);
+                    const uint32_t o1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)give[1], 0xB1, 0xF, 0xF, true);
+                    // even lane: [own hi (elements 0-3) | partner's hi (4-7)]; odd lane: [partner's lo (0-3) | own lo (4-7)]
+                    return odd ? u32x4_{o0, o1, keep[0], keep[1]} : u32x4_{keep[0], keep[1], o0, o1};
+                };
+                // even lane keeps hi and gives lo; odd lane keeps lo and gives hi
+                const u32x4_ w0 = xchg(odd ? l0 : h0, odd ? h0 : l0);
+                const u32x4_ w1 = xchg(odd ? l1 : h1, odd ? h1 : l1);
+                char* row = ys + (size_t)m * kDim * 4 + (lane >> 3) * 128 + ((lane & 7) >> 1) * 16 + (odd ? 64 : 0);
+                ln_store(reinterpret_cast<u32x4_*>(row), w0);
+                ln_store(reinterpret_cast<u32x4_*>(row + 1024), w1);
+#else
                 char* row = ys + (size_t)m * kDim * 4 + (lane >> 3) * 128 + (lane & 7) * 8;
                 ln_store(reinterpret_cast<half4*>(row), h0);
                 ln_store(reinterpret_cast<half4*>(row + 64), l0);
                 ln_store(reinterpret_cast<half4*>(row + 1024), h1);
                 ln_store(reinterpret_cast<half4*>(row + 1024 + 64), l1);
+#endif
             }
         }
     }

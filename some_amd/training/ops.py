@@ -434,7 +434,7 @@ class TrainOps:
             if self._wg_since_mark >= self._WG_MARK_EVERY:
                 self._wg_mark()
 
-    _WG_MARK_EVERY = 16
+    _WG_MARK_EVERY = int(os.environ.get('SOME_AMD_TRAIN_WG_MARK_EVERY', '16'))     # calls between two release marks (A/B runs: a huge value = release at the end of the pass)
 
     def _wg_mark(self):
         """An event on every side stream that has work; everything kept so far may go once those events have completed (the side
