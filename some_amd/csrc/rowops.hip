@@ -26,7 +26,7 @@ __device__ __forceinline__ float wave_max(float v) {
 #define LN_ROWS 2               // rows per wavefront and iteration (independent load -> reduce -> store chains in flight)
 #endif
 #ifndef LN_STORE16
-#define LN_STORE16 0            // 1: SPLIT32 output as 16-byte stores (lane pairs exchange halves by DPP: the even lane stores the pair's 8 hi
+#define LN_STORE16 1            // 1 (round 6: LayerNorm 0.1326 -> 0.1251 ms, profiles/r06k_step_ab_ln16.txt): SPLIT32 output as 16-byte stores (lane pairs exchange halves by DPP: the even lane stores the pair's 8 hi
                                 // halves, the odd lane its 8 lo halves) instead of four 8-byte stores per lane - same values, same arithmetic
 #endif
 #ifndef LN_NT
