@@ -47,7 +47,8 @@ def _offline_evidence(kernel_name: str) -> dict:
     out = {}
     if key is None:
         return out
-    for hbm_file, busy_file in (('r06z_pmc_hbm_traffic.json', 'r06z_pmc_mfma_busy.json'),      # newest committed passes first
+    for hbm_file, busy_file in (('r06zz_pmc_hbm_traffic.json', 'r06zz_pmc_mfma_busy.json'),      # newest committed passes first
+                                ('r06z_pmc_hbm_traffic.json', 'r06z_pmc_mfma_busy.json'),
                                 ('r05zy_pmc_hbm_traffic.json', 'r05zy_pmc_mfma_busy.json'),
                                 ('r05z_pmc_hbm_traffic.json', 'r05z_pmc_mfma_busy.json'),
                                 ('r04n_pmc_hbm_traffic.json', 'r04n_pmc_mfma_busy.json'),
