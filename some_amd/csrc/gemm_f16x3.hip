@@ -275,6 +275,60 @@ __device__ __forceinline__ void store16(__amdgpu_buffer_rsrc_t rc, uint32_t voff
     }
 }
 
+// Row-per-lane epilogue with WHOLE-LINE stores (round 6, persistent kernel only).  epilogue_tr stores 16 bytes per lane into 64 DIFFERENT
+// 128-byte lines per instruction (a lane owns a row); the timeline (tools/gemm_probe.hip) shows the FFN1 epilogue running at the rate the
+// CU's store path accepts such pieces (25 GB/s per CU).  Here a 32 x 32 tile of SPLIT32 results (32 rows x 128 bytes) goes through a
+// wave-private 4 KiB LDS patch - written as the lane holds it (row l31, pieces 2 h, 2 h + 1, 4 + 2 h, 5 + 2 h of the row's eight
+// 16-byte pieces; piece p of row r at slot p ^ (r & 7): conflict-free reads, two-way writes) - and read back eight lanes to a row, so
+// that every store instruction writes 8 complete lines.  Same values: bit-identical output.
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool FULL>
+__device__ __forceinline__ void epilogue_tr_lines(const GemmArgs& a, const GemmGroup& g, f32x16 (&acc)[TM][TN], int m0, int n0,
+                                                  int wm, int wn, int lane, char* patch) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    const uint32_t row_c = (uint32_t)a.ldc * 4u;
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(g.C, (size_t)a.M * row_c);
+    const int rrow = lane >> 3, rslot = lane & 7;                    // read side: row rrow + 8 k, slot rslot
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int nb = n0 + (wn * TN + jn) * 32;
+        if (!FULL && nb >= g.N) continue;
+        float bias[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(g.bias + nb + 16 * hi + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias[4 * q + e] = t[e];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            half8 h0, h1, l0, l1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x0 = acc[i][jn][e] + bias[e], x1 = acc[i][jn][8 + e] + bias[8 + e];
+                half_t h, l;
+                split_f16(x0 * sigmoidf_(x0), h, l); h0[e] = h; l0[e] = l;
+                split_f16(x1 * sigmoidf_(x1), h, l); h1[e] = h; l1[e] = l;
+            }
+            char* wrow = patch + l31 * 128;
+            const int sw = l31 & 7;
+            *reinterpret_cast<half8*>(wrow + (((2 * hi) ^ sw) << 4)) = h0;
+            *reinterpret_cast<half8*>(wrow + (((2 * hi + 1) ^ sw) << 4)) = h1;
+            *reinterpret_cast<half8*>(wrow + (((4 + 2 * hi) ^ sw) << 4)) = l0;
+            *reinterpret_cast<half8*>(wrow + (((5 + 2 * hi) ^ sw) << 4)) = l1;
+            __builtin_amdgcn_wave_barrier();
+            const int mbase = m0 + (wm * TM + i) * 32;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rrow + 8 * k;
+                const half8 v = *reinterpret_cast<const half8*>(patch + r * 128 + (rslot << 4));
+                const int piece = rslot ^ (r & 7);
+                st128h(rc, (uint32_t)(mbase + r) * row_c + (uint32_t)piece * 16u, (uint32_t)nb * 4u, v);      // rows >= M: past num_records, dropped
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI, bool OUT_SPLIT, bool FULL>
 __device__ __forceinline__ void epilogue_tr(const GemmArgs& a, const GemmGroup& g, f32x16 (&acc)[TM][TN], int m0, int n0,
                                             int wm, int wn, int lane) {
@@ -680,8 +734,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, STAGES == 1 ? 2 : 1) void h
 // next tile's first k-block in LDS and its second in flight into the staging registers.  Same products in the same order per
 // output element: bit-identical to the kernel above (tests/test_gpu_kernels.py).  nk must be even (stream position parity = LDS
 // buffer) and >= 4; no split-K.
-template <int EPI, bool OUT_SPLIT, bool TR = false>
+template <int EPI, bool OUT_SPLIT, bool TR = false, bool LINES = false>
 __global__ __launch_bounds__(512) void hgemm3p_kernel(GemmArgs a) {
+    static_assert(!LINES || (TR && OUT_SPLIT && EPI == EPI_BIAS_SILU), "whole-line stores: the SPLIT32 row-per-lane epilogue");
     constexpr int WAVES_M = 4, WAVES_N = 2, TM = 2, TN = 4;
     constexpr int NT = 512, BM = 256, BN = 256;
     constexpr int STAGE = (BM + BN) * LDT;               // dwords
@@ -865,7 +920,11 @@ __global__ __launch_bounds__(512) void hgemm3p_kernel(GemmArgs a) {
         asm volatile("s_nop 0" ::: "memory");
         const unsigned long long tl_t2 = __builtin_amdgcn_s_memtime();
 #endif
-        if constexpr (TR) {
+        if constexpr (LINES) {
+            char* patch = reinterpret_cast<char*>(lds + STAGE) + wave * 4096;      // buffer 1: retired by the barrier behind the last iteration
+            if (n0 + BN <= g.N) epilogue_tr_lines<WAVES_M, WAVES_N, TM, TN, true>(a, g, acc, m0, n0, wm, wn, lane, patch);
+            else epilogue_tr_lines<WAVES_M, WAVES_N, TM, TN, false>(a, g, acc, m0, n0, wm, wn, lane, patch);
+        } else if constexpr (TR) {
             if (n0 + BN <= g.N) epilogue_tr<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, true>(a, g, acc, m0, n0, wm, wn, lane);
             else epilogue_tr<WAVES_M, WAVES_N, TM, TN, EPI, OUT_SPLIT, false>(a, g, acc, m0, n0, wm, wn, lane);
         } else {
@@ -887,18 +946,18 @@ __global__ __launch_bounds__(512) void hgemm3p_kernel(GemmArgs a) {
         }
 #endif
         if (!has_next) break;
-        if constexpr (EPI == EPI_QKV) __syncthreads();   // the patches in buffer 1 have been read: the next iteration stores a k-block there
+        if constexpr (EPI == EPI_QKV || LINES) __syncthreads();   // the patches in buffer 1 have been read: the next iteration stores a k-block there
         vb = vbn; m0 = m0n; n0 = n0n;
     }
 }
 
-template <int EPI, bool OUT_SPLIT, bool TR = false>
+template <int EPI, bool OUT_SPLIT, bool TR = false, bool LINES = false>
 hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 256, BN = 256;
     constexpr size_t LDS_BYTES = 2 * (size_t)(BM + BN) * LDT * sizeof(float);
     static DeviceOnce attr_once;
     static std::atomic<int> cus{0};
-    auto kern = &hgemm3p_kernel<EPI, OUT_SPLIT, TR>;
+    auto kern = &hgemm3p_kernel<EPI, OUT_SPLIT, TR, LINES>;
     if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -1448,6 +1507,7 @@ hipError_t launch_epi(const GemmArgs& a, int tile, hipStream_t s) {
         if constexpr (kCanTr) {
             bool tr = (a.flags & GEMM_FLAG_TR) != 0;
             for (int g = 0; g < a.groups; ++g) tr = tr && (a.g[g].N % 64) == 0;
+            if (tr && (a.flags & GEMM_FLAG_LINES)) return launch_persist<EPI, OUT_SPLIT, true, true>(a, s);
             if (tr) return launch_persist<EPI, OUT_SPLIT, true>(a, s);
         }
         return launch_persist<EPI, OUT_SPLIT>(a, s);

@@ -70,6 +70,7 @@ struct GemmArgs {
     int vb_count;          // persistent kernel (hgemm3p_kernel): virtual blocks per group, filled by its launcher (last: the other kernels' argument offsets stay put)
 };
 constexpr int GEMM_FLAG_TR = 1;   // row-per-lane (transposed accumulator) epilogues where the epilogue has one (gemm_f16x3.hip)
+constexpr int GEMM_FLAG_LINES = 4;     // persistent FFN1: the SPLIT32 epilogue through a wave-private LDS patch, whole 128-byte lines per store (round 6)
 constexpr int GEMM_FLAG_PERSIST = 2;   // 256 x 256 launches through the persistent stream kernel (hgemm3p_kernel, round 6)
 
 hipError_t launch_gemm(GemmEpi epi, const GemmArgs& a, hipStream_t s);

@@ -329,7 +329,7 @@ def test_persistent_stream_gemm_equals_the_one_tile_per_workgroup_kernel_bit_for
     (M = 40 000: 320 virtual blocks for N = 512; 1 280 for N = 2048), ragged last row tiles, the wave-quantisation tail, K = 512 and
     K = 2048."""
     from some_amd import _lib as L
-    base, pers = _engine_with_gemm_flags(1), _engine_with_gemm_flags(3)
+    base, pers, lines = _engine_with_gemm_flags(1), _engine_with_gemm_flags(3), _engine_with_gemm_flags(7)     # 7: + whole-line stores in FFN1's SPLIT32 epilogue
     g = torch.Generator(device='cuda').manual_seed(M)
     K = 512
     A = torch.randn(M, K, device='cuda', generator=g)
@@ -342,16 +342,17 @@ def test_persistent_stream_gemm_equals_the_one_tile_per_workgroup_kernel_bit_for
     bg = torch.randn(1024, device='cuda', generator=g)
     mask = (torch.rand(M, device='cuda', generator=g) > 0.2).to(torch.uint8)
     outs = []
-    for e in (base, pers):
+    for e in (base, pers, lines):
         h = _gemm(e, L.EPI_BIAS_SILU, A, W, bias=b, split=True, tile=2)
         outs.append([h, _gemm(e, L.EPI_BIAS_SILU, A, W, bias=b, split=True, tile=2, out_split=True),
                      _gemm(e, L.EPI_BIAS_RES, h, W2, bias=b2, res=X, alpha=0.5, split=True, tile=2),
                      _gemm(e, L.EPI_NONE, A, W, split=True, tile=2), _gemm(e, L.EPI_BIAS, A, W2[:, :K].contiguous(), bias=b2, split=True, tile=2),
                      _gemm(e, L.EPI_GLU, A, Wg, bias=bg, n_out=512, split=True, tile=2),
                      _gemm(e, L.EPI_GLU_RES, A, Wg, bias=bg, res=X, mask=mask, n_out=512, split=True, tile=2)])
-    for i, (a, c) in enumerate(zip(*outs)):
-        assert torch.isfinite(c).all(), i
-        assert torch.equal(a, c), (i, float((a - c).abs().max()))
+    for other in outs[1:]:
+        for i, (a, c) in enumerate(zip(outs[0], other)):
+            assert torch.isfinite(c).all(), i
+            assert torch.equal(a, c), (i, float((a - c).abs().max()))
 
 
 def test_forward_with_the_persistent_gemms_equals_the_default_bit_for_bit():
