@@ -229,7 +229,7 @@ struct Scope {
 
 extern "C" {
 
-const char* some_version(void) { return "some_amd 0.4 gfx950 (f32 / split-f16 MFMA conformer, HIP)"; }
+const char* some_version(void) { return "some_amd 0.6 gfx950 (f32 / split-f16 MFMA conformer, HIP)"; }
 
 const char* some_last_error(const SomeHandle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
